@@ -1,0 +1,98 @@
+"""Seeded synthetic inputs shaped like the reference's per-tile arrays.
+
+Used by bench.py, the tests and tools/gen_golden.py (so that fixtures only need
+to store seeds + expected outputs).  numpy only; no device work here.
+
+Raw-tile layout (BASELINE.json `[12, 15, 618, 618]`), planar
+float32 [T, 15, H, W]:
+  0-3   S2 10 m bands (B2,B3,B4,B8)          4-9  S2 20/40 m bands, nearest-replicated
+  10-11 S1 VV/VH already in [0,1] dB scale   12   DEM / 90 (constant over T)
+  13    cloud probability                    14   binary cloud+shadow mask
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _smooth_field(rng, h, w, scale=32):
+    """Cheap smooth random field in [0,1]: bilinear-upsampled coarse noise."""
+    ch, cw = h // scale + 2, w // scale + 2
+    c = rng.random((ch, cw))
+    y = np.linspace(0, ch - 1.001, h)
+    x = np.linspace(0, cw - 1.001, w)
+    y0, x0 = y.astype(int), x.astype(int)
+    fy, fx = (y - y0)[:, None], (x - x0)[None, :]
+    a = c[y0][:, x0] * (1 - fy) * (1 - fx) + c[y0 + 1][:, x0] * fy * (1 - fx)
+    b = c[y0][:, x0 + 1] * (1 - fy) * fx + c[y0 + 1][:, x0 + 1] * fy * fx
+    return a + b
+
+
+def synth_dates(rng, T):
+    return np.sort(rng.choice(np.arange(0, 365), size=T, replace=False)).astype(np.int64)
+
+
+def synth_tile(seed=1234, T=12, H=618, W=618, cloud_frac=0.0):
+    """Reference-layout per-tile arrays, i.e. what process_tile (job.py:641-995) returns:
+    s2 [T,H,W,10] f32 in (0,1), dates [T], interp [T,H,W] f32, s1 [12,H,W,2] f32, dem [H,W] f32."""
+    rng = np.random.default_rng(seed)
+    dates = synth_dates(rng, T)
+    veg = _smooth_field(rng, H, W, 48).astype(np.float32)            # "tree-ness"
+    tex = rng.random((H, W), dtype=np.float32) * 0.04
+    season = (0.5 + 0.5 * np.sin(2 * np.pi * (dates[:, None, None] - 100) / 365.0)).astype(np.float32)
+    base = np.array([0.05, 0.08, 0.07, 0.30, 0.12, 0.22, 0.27, 0.30, 0.20, 0.12], dtype=np.float32)
+    vegd = np.array([-0.02, -0.02, -0.04, 0.15, 0.0, 0.08, 0.10, 0.12, -0.08, -0.06], dtype=np.float32)
+    s2 = (base[None, None, None, :]
+          + vegd[None, None, None, :] * (veg[None, :, :, None] * (0.6 + 0.4 * season[..., None]))
+          + tex[None, :, :, None]
+          + rng.random((T, H, W, 10), dtype=np.float32) * 0.02)
+    s2 = np.clip(s2, 0.002, 0.95).astype(np.float32)
+    s1 = np.clip(0.55 + 0.2 * veg[None, :, :, None] + rng.random((12, H, W, 2), dtype=np.float32) * 0.1
+                 - np.array([0.0, 0.2], dtype=np.float32), 0, 1).astype(np.float32)
+    dem = (_smooth_field(rng, H, W, 96) * 3.0).astype(np.float32)     # already / 90
+    interp = np.zeros((T, H, W), dtype=np.float32)
+    if cloud_frac > 0:
+        yy, xx = np.mgrid[0:H, 0:W]
+        for t in range(T):
+            for _ in range(rng.integers(0, 3)):
+                cy, cx = rng.integers(0, H), rng.integers(0, W)
+                ry, rx = rng.integers(20, int(60 + 300 * cloud_frac)), rng.integers(20, int(60 + 300 * cloud_frac))
+                d = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2
+                interp[t] = np.maximum(interp[t], np.clip(1.5 - d, 0, 1).astype(np.float32))
+    return s2, dates, interp, s1, dem
+
+
+def synth_raw_tile(seed=1234, T=12, H=618, W=618):
+    """BASELINE raw stack [T, 15, H, W] planar f32 + dates (see module docstring)."""
+    s2, dates, interp, s1, dem = synth_tile(seed, T, H, W, cloud_frac=0.15)
+    rng = np.random.default_rng(seed + 7)
+    raw = np.empty((T, 15, H, W), dtype=np.float32)
+    raw[:, 0:4] = np.moveaxis(s2[..., 0:4], -1, 1)
+    lo = s2[:, ::2, ::2, 4:10]                                        # 20 m grid
+    lo = np.repeat(np.repeat(lo, 2, axis=1), 2, axis=2)[:, :H, :W]
+    raw[:, 4:10] = np.moveaxis(lo, -1, 1)
+    s1t = s1[np.minimum(np.arange(T), 11)]
+    raw[:, 10:12] = np.moveaxis(s1t, -1, 1)
+    raw[:, 12] = dem[None]
+    mask = (interp > 0.5).astype(np.float32)
+    raw[:, 13] = np.clip(interp + rng.random((T, H, W), dtype=np.float32) * 0.1, 0, 1)
+    raw[:, 14] = mask
+    bright = 0.35 * mask[..., None]                                    # clouds are bright
+    raw[:, 0:10] += np.moveaxis(bright * np.ones(10, dtype=np.float32), -1, 1)
+    return np.clip(raw, 0, 1), dates
+
+
+def synth_windows(seed=0, N=1, L=4, W=172, C=17):
+    """U(-1,1) model inputs [N, L+1, W, W, C] (NHWC per frame, as fed to predict/Placeholder:0)."""
+    rng = np.random.default_rng(seed)
+    return (rng.random((N, L + 1, W, W, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+
+
+def synth_bright_window(seed=21, L=4, W=172):
+    """Un-normalised [L+1, W, W, 17] window with two bright-bare patches (job.py:1099-1122 test input)."""
+    rng = np.random.default_rng(seed)
+    img = (rng.random((L + 1, W, W, 17)) * 0.5).astype(np.float32)
+    for (a, b, c, d) in [(40, 70, 50, 90), (120, 124, 10, 13), (0, 12, 160, 172)]:
+        img[:, a:b, c:d, 8] = 0.6       # high SWIR
+        img[:, a:b, c:d, :3] = 0.3      # bright visible
+        img[:, a:b, c:d, 3] = 0.31      # NIR/SWIR < 0.9
+    return img
