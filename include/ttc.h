@@ -1,0 +1,162 @@
+/*
+ * ttc.h -- C ABI of libttc_hip.so: the MI355X (gfx950) implementation of the per-tile
+ * numeric hot path of wri/sentinel-tree-cover.
+ *
+ * The reference has NO native interface for this path: it is pure Python that drives two
+ * TensorFlow-1 frozen graphs through `Session.run` and numpy/scipy in between
+ * (SURVEY.md F1/F2).  Each entry point below therefore cites the reference *Python*
+ * function (file:line in the reference checkout) whose arithmetic it replaces; the
+ * reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md (and shipped as sentinel-tree-cover_amd/_lib.py).
+ *
+ * Conventions
+ *  - Every `d_*` pointer is a DEVICE pointer owned by the caller (e.g. a PyTorch-ROCm
+ *    allocation); `h_*` pointers are host memory.  The library owns only its context
+ *    (weights + workspace, sized at ttc_create).
+ *  - All work is enqueued on the caller's `stream` (a hipStream_t passed as void*);
+ *    no call synchronises the device except ttc_destroy and the ttc_debug_* helpers.
+ *  - Errors: integer status; ttc_last_error(ctx) returns a message.  No exceptions, no exit().
+ *  - A context is bound to one device and is not re-entrant.
+ *  - Array layouts are the reference's numpy layouts ([T, X, Y, C], C-contiguous float32)
+ *    unless a parameter says "planar".
+ */
+#ifndef TTC_H
+#define TTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ttc_ctx ttc_ctx;
+
+typedef enum {
+    TTC_OK = 0,
+    TTC_ERR_ARG = 1,      /* bad argument / unsupported geometry */
+    TTC_ERR_HIP = 2,      /* a HIP runtime call failed */
+    TTC_ERR_STATE = 3,    /* e.g. forward before weights are loaded */
+    TTC_ERR_NOMEM = 4
+} ttc_status;
+
+/* Model / window geometry.  Defaults mirror src/download_and_predict_job.py:60-61, :1715
+ * (SIZE = 172-14, length 4) and src/train/train-model.py:64-82 (base_filters 64, zoneout 0.75). */
+typedef struct {
+    int32_t win_in;        /* W: model input window, W % 4 == 0 (172, 168, ...)        */
+    int32_t length;        /* L: ConvGRU steps (4 or 12); frames per window = L + 1     */
+    int32_t max_windows;   /* workspace capacity in windows (36 per 618^2 tile)         */
+    int32_t n_bands;       /* 17                                                        */
+    int32_t hidden;        /* 32  (ConvGRU filters per direction = base_filters / 2)    */
+    int32_t base_filters;  /* 64                                                        */
+    float   zoneout;       /* 0.75: state' = z*state + (1-z)*new  (model.py:571-574)    */
+    int32_t precision;     /* 0 = fp32 MFMA (exact fp32 FMA chains)                     */
+} ttc_config;
+
+/* A named host tensor in TensorFlow layout (conv kernels HWIO). */
+typedef struct {
+    const char*  name;
+    const float* data;
+    int32_t      ndim;
+    int64_t      shape[4];
+} ttc_tensor;
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+const char* ttc_version(void);
+ttc_status  ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg);
+void        ttc_destroy(ttc_ctx* ctx);
+const char* ttc_last_error(const ttc_ctx* ctx);
+/* bytes of device memory the context holds (weights + workspace) */
+size_t      ttc_device_bytes(const ttc_ctx* ctx);
+
+/* ---- weights ------------------------------------------------------------------------
+ * ConvGRU/U-Net variables (names: see sentinel-tree-cover_amd/weights.py; shapes as in
+ * models-release/master-ckpt-nonfrozen/-0.meta).  Replaces
+ * tf.import_graph_def of predict_graph-{W}.pb, src/download_and_predict_job.py:1800-1824. */
+ttc_status ttc_load_weights(ttc_ctx* ctx, const ttc_tensor* tensors, int32_t n);
+/* DSen2-lite variables ({in,01,02,11,12,out}_conv/{kernel,bias}).  Replaces the import of
+ * models-release/supres-40k-swir/superresolve_graph.pb, job.py:1788-1796. */
+ttc_status ttc_load_dsen2_weights(ttc_ctx* ctx, const ttc_tensor* tensors, int32_t n);
+
+/* ---- model forward ------------------------------------------------------------------
+ * == sess.run(predict_logits, {predict_inp: x, predict_length: L}) inside
+ * predict_subtile, src/download_and_predict_job.py:353-357, batched over windows.
+ * d_in : [n, L+1, W, W, 17] float32 (already normalised, job.py:316-325)
+ * d_out: [n, W-14, W-14]    float32 probabilities                                      */
+ttc_status ttc_forward_windows(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, void* stream);
+
+/* ---- per-tile numeric core ----------------------------------------------------------
+ * == process_subtiles (job.py:1125-1483) up to and including the per-window post-masks,
+ * for one tile whose dates have already been screened on the host (deal_w_missing_px's
+ * date removal, job.py:1031-1037, is a host decision taken from ttc_tile_missing_counts).
+ *
+ * d_s2     [T, X, Y, 10]  cloud-free Sentinel-2 (output of process_tile + superresolve)
+ * h_wmat   [12, T]        float32 host: temporal operator = Whittaker(lambda=100, 24->12)
+ *                         o date-regrid (src/preprocessing/whittaker_smoother.py:25-67,
+ *                         src/downloading/utils.py:176-347), built by the host mirror
+ * d_interp [T, X, Y]      interpolated-area weights from the gap-fill
+ * d_s1     [12, X, Y, 2]  monthly Sentinel-1 (dB-scaled)
+ * d_dem    [X, Y]
+ * h_min/h_max [17]        normalisation vectors (job.py:1829-1842)
+ * size                    output window size (W - 14); windows follow job.py:1295-1317
+ * n_dates_ok              len(dates) after host screening (job.py:1418: < 2 -> no data)
+ * d_windows [36, size, size] float32: what the reference np.save()s per window
+ *                         (rounded to 3 decimals, 255 = no data), order = window index
+ * d_windows_raw           same before np.around / bright-surface product (may be NULL)
+ */
+ttc_status ttc_process_subtiles(ttc_ctx* ctx, const float* d_s2, int32_t T, int32_t X, int32_t Y,
+                                const float* h_wmat, const float* d_interp, const float* d_s1,
+                                const float* d_dem, const float* h_min, const float* h_max,
+                                int32_t size, int32_t n_dates_ok,
+                                float* d_windows, float* d_windows_raw, void* stream);
+
+/* per-date count of "missing" pixels, id_missing_px (src/preprocessing/interpolation.py:5-23);
+ * d_counts [T] int32 */
+ttc_status ttc_tile_missing_counts(ttc_ctx* ctx, const float* d_s2, int32_t T, int32_t X, int32_t Y,
+                                   int32_t* d_counts, void* stream);
+/* in-place repair of NaN / 0 / 1 samples with the running temporal median:
+ * interpolate_na_vals (interpolation.py:42-56) then deal_w_missing_px's value fixes
+ * (job.py:1039-1047).  d_s2 [T, X, Y, 10]. */
+ttc_status ttc_tile_fix_missing(ttc_ctx* ctx, float* d_s2, int32_t T, int32_t X, int32_t Y,
+                                int32_t do_nan, int32_t do_zero_one, void* stream);
+
+/* ---- Gaussian overlap mosaic --------------------------------------------------------
+ * == load_mosaic_predictions(out_folder, depth=1), job.py:1515-1641, from the 36 window
+ * arrays (not from .npy files).
+ * d_windows [n, size, size]; h_xy [n, 2] int32 = (folder_x, folder_y) of each window.
+ * d_out_u8 [max_y+size, max_x+size] uint8 -- TRANSPOSED like the reference (job.py:1578);
+ * d_out_f32 same shape, float32 percent before quantisation, NaN = no data (may be NULL). */
+ttc_status ttc_mosaic(ttc_ctx* ctx, const float* d_windows, int32_t n, const int32_t* h_xy,
+                      int32_t size, int32_t out_rows, int32_t out_cols,
+                      uint8_t* d_out_u8, float* d_out_f32, void* stream);
+
+/* ---- 20 m -> 10 m -------------------------------------------------------------------
+ * DSen2-lite on one padded window batch: == sess.run(superresolve_logits, ...) in
+ * superresolve_large_tile._worker_fn, job.py:112-118.
+ * d_in [n, H, W, 10], d_bilinear [n, H, W, 6] -> d_out [n, H, W, 6] */
+ttc_status ttc_dsen2_forward(ttc_ctx* ctx, const float* d_in, const float* d_bilinear, int32_t n,
+                             int32_t H, int32_t W, float* d_out, void* stream);
+/* whole-tile driver == superresolve_large_tile (job.py:95-147), in place on d_s2 [T, X, Y, 10];
+ * quirks != 0 reproduces the reference's skipped strip and double pass. */
+ttc_status ttc_superresolve_tile(ttc_ctx* ctx, float* d_s2, int32_t T, int32_t X, int32_t Y,
+                                 int32_t quirks, void* stream);
+/* bilinear x2 of the 20 m bands == the resize() loop of process_tile, job.py:734-782 (even grids):
+ * d_s2_10 [T, 2h, 2w, 4], d_s2_20 [T, h, w, 6] -> d_out [T, 2h, 2w, 10] */
+ttc_status ttc_upsample_20m(ttc_ctx* ctx, const float* d_s2_10, const float* d_s2_20, int32_t T,
+                            int32_t h, int32_t w, float* d_out, void* stream);
+
+/* ---- introspection for parity tests -------------------------------------------------
+ * Copies a named internal activation (device) to host after synchronising the device.
+ * Returns TTC_ERR_ARG for unknown names; *n_floats is the element count.  Test aid only. */
+ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t cap_floats,
+                           size_t* n_floats);
+/* average device time (ms) of the named kernel family over the launches since the last
+ * reset, measured with HIP events on the launch stream; name == NULL resets.  Only
+ * collected after ttc_debug_timing(ctx, 1). */
+ttc_status ttc_debug_timing(ttc_ctx* ctx, int32_t enable);
+ttc_status ttc_debug_kernel_ms(ttc_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTC_H */

@@ -85,8 +85,13 @@ def group_norm(x, gamma, beta, G=8, eps=1e-5):
 
 
 class TreeCoverNet:
-    def __init__(self, weights, zoneout=0.75, dtype=torch.float32):
+    def __init__(self, weights, zoneout=0.75, dtype=torch.float32, trace=None):
         self.w, self.z, self.dt = weights, float(zoneout), dtype
+        self.trace = trace          # optional dict: name -> ndarray of intermediates (NCHW)
+
+    def _t(self, name, x):
+        if self.trace is not None:
+            self.trace[name] = x.detach().numpy().copy()
 
     # -- ConvGRU cell, model.py:240-290 -----------------------------------------------
     def _cell(self, d, x, h):
@@ -94,12 +99,15 @@ class TreeCoverNet:
         p = f"gru/{d}/"
         inp = F.pad(torch.cat([x, h], 1), (1, 1, 1, 1), mode="reflect")
         y = F.conv2d(inp, _k(w, p + "gates/kernel", dt))
+        self._t(f"yg_{d}", y)
         r, u = torch.chunk(y, 2, dim=1)
         r = torch.sigmoid(group_norm(r, _v(w, p + "gates_r/gamma", dt), _v(w, p + "gates_r/beta", dt)))
         u = torch.sigmoid(group_norm(u, _v(w, p + "gates_u/gamma", dt), _v(w, p + "gates_u/beta", dt)))
         inp = F.pad(torch.cat([x, r * h], 1), (1, 1, 1, 1), mode="reflect")
         y = F.conv2d(inp, _k(w, p + "candidate/kernel", dt))
         y = y * torch.sigmoid(F.conv2d(y, _k(w, p + "candidate/kernel_1", dt)))
+        self._t(f"yc_{d}", y)
+        self._t(f"u_{d}", u)
         y = group_norm(y, _v(w, p + "candidate_y/gamma", dt), _v(w, p + "candidate_y/beta", dt))
         return u * h + (1 - u) * torch.tanh(y)
 
@@ -114,6 +122,7 @@ class TreeCoverNet:
                 hn = self._cell(d, x[:, t], h)
                 h = h * self.z + hn * (1 - self.z)      # state carried on = zoneout mix
             outs.append(h)                              # final STATE, not last output
+        self._t("gru", torch.cat(outs, 1))
         return torch.cat(outs, 1)
 
     # -- conv_swish_gn, model.py:448-538 ---------------------------------------------
@@ -128,6 +137,7 @@ class TreeCoverNet:
         else:
             y = F.conv2d(x, k)
         y = y * torch.sigmoid(y)                         # swish
+        self._t("raw_" + name, y)
         y = group_norm(y, _v(w, name + "/gamma", dt), _v(w, name + "/beta", dt))
         gate = torch.sigmoid(F.conv2d(y, _k(w, name + "/sse_kernel", dt), _v(w, name + "/sse_bias", dt)))
         return y * gate                                  # sSE, model.py:45-61

@@ -1,0 +1,197 @@
+"""ctypes binding of libttc_hip.so (include/ttc.h) -- the stub a maintainer of the
+reference would add next to src/download_and_predict_job.py.
+
+PyTorch-ROCm is used only as the device allocator / stream provider: tensors are passed
+to the library as raw device pointers.  There is NO CPU fallback: if the shared library
+is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttc_hip.so")
+
+EXPORTS = [
+    "ttc_version", "ttc_create", "ttc_destroy", "ttc_last_error", "ttc_device_bytes",
+    "ttc_load_weights", "ttc_load_dsen2_weights", "ttc_forward_windows", "ttc_process_subtiles",
+    "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
+    "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
+    "ttc_debug_kernel_ms",
+]
+
+
+class TTCConfig(C.Structure):
+    _fields_ = [("win_in", C.c_int32), ("length", C.c_int32), ("max_windows", C.c_int32),
+                ("n_bands", C.c_int32), ("hidden", C.c_int32), ("base_filters", C.c_int32),
+                ("zoneout", C.c_float), ("precision", C.c_int32)]
+
+
+class TTCTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libttc_hip.so and declare prototypes; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sentinel-tree-cover_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P, I32, F32P, VP = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p
+    lib.ttc_version.restype = C.c_char_p
+    lib.ttc_create.argtypes = [C.POINTER(P), I32, C.POINTER(TTCConfig)]
+    lib.ttc_destroy.argtypes = [P]
+    lib.ttc_destroy.restype = None
+    lib.ttc_last_error.argtypes = [P]
+    lib.ttc_last_error.restype = C.c_char_p
+    lib.ttc_device_bytes.argtypes = [P]
+    lib.ttc_device_bytes.restype = C.c_size_t
+    lib.ttc_load_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
+    lib.ttc_load_dsen2_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
+    lib.ttc_forward_windows.argtypes = [P, VP, I32, VP, VP]
+    lib.ttc_process_subtiles.argtypes = [P, VP, I32, I32, I32, F32P, VP, VP, VP, F32P, F32P, I32, I32, VP, VP, VP]
+    lib.ttc_tile_missing_counts.argtypes = [P, VP, I32, I32, I32, VP, VP]
+    lib.ttc_tile_fix_missing.argtypes = [P, VP, I32, I32, I32, I32, I32, VP]
+    lib.ttc_mosaic.argtypes = [P, VP, I32, C.POINTER(C.c_int32), I32, I32, I32, VP, VP, VP]
+    lib.ttc_dsen2_forward.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_superresolve_tile.argtypes = [P, VP, I32, I32, I32, I32, VP]
+    lib.ttc_upsample_20m.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.ttc_debug_timing.argtypes = [P, I32]
+    lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)          # AttributeError here == missing export
+        if name not in ("ttc_version", "ttc_destroy", "ttc_last_error", "ttc_device_bytes"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
+                           "the tree-cover hot path has no CPU fallback")
+    return torch
+
+
+def pack_tensors(weights: dict):
+    """dict name -> float32 ndarray  ==>  (ctypes array of TTCTensor, keepalive list)."""
+    arr = (TTCTensor * len(weights))()
+    keep = []
+    for i, (k, v) in enumerate(weights.items()):
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        keep.append(a)
+        arr[i].name = k.encode()
+        arr[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].ndim = min(a.ndim, 4)
+        for d in range(min(a.ndim, 4)):
+            arr[i].shape[d] = a.shape[d]
+    return arr, keep
+
+
+class Context:
+    """One libttc context: (device, window geometry, weights, workspace)."""
+
+    def __init__(self, win_in=172, length=4, max_windows=36, device=0, zoneout=0.75, precision=0):
+        self.lib = load()
+        self.torch = _torch()
+        self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision)
+        self.device = device
+        self._h = C.c_void_p()
+        st = self.lib.ttc_create(C.byref(self._h), device, C.byref(self.cfg))
+        if st != 0:
+            msg = self.lib.ttc_last_error(self._h).decode() if self._h else "ttc_create failed"
+            if self._h:
+                self.lib.ttc_destroy(self._h)
+                self._h = C.c_void_p()
+            raise RuntimeError(f"ttc_create: status {st}: {msg}")
+
+    # -- helpers ------------------------------------------------------------------------
+    def _check(self, st, what):
+        if st != 0:
+            raise RuntimeError(f"{what}: status {st}: {self.lib.ttc_last_error(self._h).decode()}")
+
+    def _dev(self, x, dtype=None):
+        """numpy / torch -> contiguous tensor on this context's device."""
+        t = self.torch
+        if not isinstance(x, t.Tensor):
+            x = t.from_numpy(np.ascontiguousarray(x))
+        if dtype is not None and x.dtype != dtype:
+            x = x.to(dtype)
+        return x.to(f"cuda:{self.device}", non_blocking=False).contiguous()
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ttc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.ttc_device_bytes(self._h))
+
+    # -- weights ------------------------------------------------------------------------
+    def load_weights(self, weights: dict):
+        arr, keep = pack_tensors(weights)
+        self._check(self.lib.ttc_load_weights(self._h, arr, len(weights)), "ttc_load_weights")
+
+    def load_dsen2_weights(self, weights: dict):
+        arr, keep = pack_tensors(weights)
+        self._check(self.lib.ttc_load_dsen2_weights(self._h, arr, len(weights)), "ttc_load_dsen2_weights")
+
+    # -- model ----------------------------------------------------------------------------
+    def forward_windows(self, x, out=None):
+        """x [n, L+1, W, W, 17] float32 (numpy or cuda tensor) -> cuda tensor [n, W-14, W-14]."""
+        t = self.torch
+        xd = self._dev(x, t.float32)
+        n, W = xd.shape[0], self.cfg.win_in
+        assert tuple(xd.shape[1:]) == (self.cfg.length + 1, W, W, 17), xd.shape
+        if out is None:
+            out = t.empty((n, W - 14, W - 14), dtype=t.float32, device=xd.device)
+        self._check(self.lib.ttc_forward_windows(self._h, C.c_void_p(xd.data_ptr()), n,
+                                                 C.c_void_p(out.data_ptr()), self._stream()),
+                    "ttc_forward_windows")
+        return out
+
+    # -- debug ----------------------------------------------------------------------------
+    def debug_fetch(self, name, shape=None):
+        n = C.c_size_t(0)
+        self._check(self.lib.ttc_debug_fetch(self._h, name.encode(), None, 0, C.byref(n)), "ttc_debug_fetch")
+        buf = np.empty(n.value, dtype=np.float32)
+        self._check(self.lib.ttc_debug_fetch(self._h, name.encode(), buf.ctypes.data_as(C.POINTER(C.c_float)),
+                                             n.value, C.byref(n)), "ttc_debug_fetch")
+        if shape is not None:
+            buf = buf[:int(np.prod(shape))].reshape(shape)
+        return buf
+
+    def timing(self, enable=True):
+        self._check(self.lib.ttc_debug_timing(self._h, int(enable)), "ttc_debug_timing")
+
+    def kernel_ms(self, name=None):
+        if name is None:
+            self._check(self.lib.ttc_debug_kernel_ms(self._h, None, None, None), "ttc_debug_kernel_ms")
+            return None
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._check(self.lib.ttc_debug_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(cnt)),
+                    "ttc_debug_kernel_ms")
+        return ms.value, cnt.value

@@ -1,0 +1,164 @@
+// extern "C" entry points of libttc_hip.so (see include/ttc.h for the contract).
+#include "ttc_internal.h"
+
+// tile.hip / mosaic.hip / dsen2.hip
+ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat,
+                                 const float* d_interp, const float* d_s1, const float* d_dem, const float* h_min,
+                                 const float* h_max, int size, int n_dates_ok, float* d_windows, float* d_windows_raw,
+                                 hipStream_t s);
+ttc_status tile_missing_counts(ttc_ctx* c, const float* d_s2, int T, int X, int Y, int32_t* d_counts, hipStream_t s);
+ttc_status tile_fix_missing(ttc_ctx* c, float* d_s2, int T, int X, int Y, int do_nan, int do_zero_one, hipStream_t s);
+ttc_status mosaic_run(ttc_ctx* c, const float* d_windows, int n, const int32_t* h_xy, int size, int rows, int cols,
+                      uint8_t* d_u8, float* d_f32, hipStream_t s);
+ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int n, int H, int W, float* d_out,
+                         hipStream_t s);
+ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, hipStream_t s);
+ttc_status upsample_20m(ttc_ctx* c, const float* d10, const float* d20, int T, int h, int w, float* d_out, hipStream_t s);
+
+static void flush_timing(ttc_ctx* c) {
+    for (auto& p : c->timing.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            auto& r = c->timing.recs[p.first];
+            r.ms += ms; r.n += 1;
+        }
+        (void)hipEventDestroy(p.second.first);
+        (void)hipEventDestroy(p.second.second);
+    }
+    c->timing.pending.clear();
+}
+
+extern "C" {
+
+const char* ttc_version(void) { return "ttc-hip 0.1 (gfx950)"; }
+
+ttc_status ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg) {
+    if (!out || !cfg) return TTC_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return TTC_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return TTC_ERR_HIP;
+    ttc_ctx* c = new ttc_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    *out = c;                       // returned even on failure so the caller can read ttc_last_error
+    if (cfg->precision != 0) return c->fail(TTC_ERR_ARG, "precision: only 0 (fp32 MFMA) is built");
+    if (cfg->max_windows < 1 || cfg->length < 1) return c->fail(TTC_ERR_ARG, "max_windows and length must be >= 1");
+    return model_alloc(c);
+}
+
+void ttc_destroy(ttc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    flush_timing(c);
+    for (void* p : c->allocs) (void)hipFree(p);
+    for (auto& kv : c->scratch) (void)hipFree(kv.second.first);
+    delete c;
+}
+
+const char* ttc_last_error(const ttc_ctx* c) { return c ? c->err.c_str() : "null context"; }
+size_t ttc_device_bytes(const ttc_ctx* c) { return c ? c->dev_bytes : 0; }
+
+ttc_status ttc_load_weights(ttc_ctx* c, const ttc_tensor* t, int32_t n) {
+    if (!c || !t) return TTC_ERR_ARG;
+    return model_load(c, t, n);
+}
+
+ttc_status ttc_load_dsen2_weights(ttc_ctx* c, const ttc_tensor* t, int32_t n) {
+    if (!c || !t) return TTC_ERR_ARG;
+    return dsen2_load(c, t, n);
+}
+
+ttc_status ttc_forward_windows(ttc_ctx* c, const float* d_in, int32_t n, float* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    if (!d_in || !d_out) return c->fail(TTC_ERR_ARG, "null buffer");
+    if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
+    return model_forward_frames(c, n, d_out, s);
+}
+
+ttc_status ttc_process_subtiles(ttc_ctx* c, const float* d_s2, int32_t T, int32_t X, int32_t Y, const float* h_wmat,
+                                const float* d_interp, const float* d_s1, const float* d_dem, const float* h_min,
+                                const float* h_max, int32_t size, int32_t n_dates_ok, float* d_windows,
+                                float* d_windows_raw, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return tile_process_subtiles(c, d_s2, T, X, Y, h_wmat, d_interp, d_s1, d_dem, h_min, h_max, size, n_dates_ok,
+                                 d_windows, d_windows_raw, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_tile_missing_counts(ttc_ctx* c, const float* d_s2, int32_t T, int32_t X, int32_t Y, int32_t* d_counts,
+                                   void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return tile_missing_counts(c, d_s2, T, X, Y, d_counts, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_tile_fix_missing(ttc_ctx* c, float* d_s2, int32_t T, int32_t X, int32_t Y, int32_t do_nan,
+                                int32_t do_zero_one, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return tile_fix_missing(c, d_s2, T, X, Y, do_nan, do_zero_one, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_mosaic(ttc_ctx* c, const float* d_windows, int32_t n, const int32_t* h_xy, int32_t size,
+                      int32_t out_rows, int32_t out_cols, uint8_t* d_out_u8, float* d_out_f32, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return mosaic_run(c, d_windows, n, h_xy, size, out_rows, out_cols, d_out_u8, d_out_f32,
+                      static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bilinear, int32_t n, int32_t H, int32_t W,
+                             float* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return dsen2_forward(c, d_in, d_bilinear, n, H, W, d_out, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_superresolve_tile(ttc_ctx* c, float* d_s2, int32_t T, int32_t X, int32_t Y, int32_t quirks,
+                                 void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return dsen2_tile(c, d_s2, T, X, Y, quirks, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_upsample_20m(ttc_ctx* c, const float* d_s2_10, const float* d_s2_20, int32_t T, int32_t h, int32_t w,
+                            float* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return upsample_20m(c, d_s2_10, d_s2_20, T, h, w, d_out, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_debug_fetch(ttc_ctx* c, const char* name, float* h_dst, size_t cap, size_t* n_floats) {
+    if (!c || !name) return TTC_ERR_ARG;
+    auto it = c->named.find(name);
+    if (it == c->named.end()) return c->fail(TTC_ERR_ARG, std::string("unknown activation: ") + name);
+    if (n_floats) *n_floats = it->second.second;
+    if (!h_dst) return TTC_OK;
+    TTC_HIP(c, hipDeviceSynchronize());
+    const size_t n = it->second.second < cap ? it->second.second : cap;
+    TTC_HIP(c, hipMemcpy(h_dst, it->second.first, n * sizeof(float), hipMemcpyDeviceToHost));
+    return TTC_OK;
+}
+
+ttc_status ttc_debug_timing(ttc_ctx* c, int32_t enable) {
+    if (!c) return TTC_ERR_ARG;
+    TTC_HIP(c, hipDeviceSynchronize());
+    flush_timing(c);
+    c->timing.enabled = enable != 0;
+    return TTC_OK;
+}
+
+ttc_status ttc_debug_kernel_ms(ttc_ctx* c, const char* name, double* avg_ms, int64_t* launches) {
+    if (!c) return TTC_ERR_ARG;
+    TTC_HIP(c, hipDeviceSynchronize());
+    flush_timing(c);
+    if (!name) { c->timing.recs.clear(); return TTC_OK; }
+    auto it = c->timing.recs.find(name);
+    if (it == c->timing.recs.end() || it->second.n == 0) {
+        if (avg_ms) *avg_ms = 0.0;
+        if (launches) *launches = 0;
+        return TTC_OK;
+    }
+    if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;
+    if (launches) *launches = it->second.n;
+    return TTC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// Implicit-GEMM 3x3 convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every tf.nn.convolution / Conv2D of the two reference graphs
+// (src/train/src/model.py:251, :276, :416-442; superresolve_graph.pb Conv2D nodes).
+//
+// Formulation ("flattened padded plane"): the producer of an activation stores it planar
+// and ALREADY padded, [n][Cin][Hp][Wp].  With q = y*Wp + x,
+//     out[co][q] = sum_{ci,dy,dx} w[co][ci][dy][dx] * in[ci][q + dy*Wp + dx]
+// so a tap is a linear offset, a workgroup owns BQ = 512 consecutive q of one window and
+// stages [CK][BQ + 2*Wp + 2] input floats + [9][CK][BN] weights in LDS per Cin chunk.
+// The two junk columns per row (x >= Wp-2) are computed and dropped: 1.2 % waste at
+// Wp = 174, versus 11.6 % for 32-pixel row tiles at W = 172.
+//
+// GEMM view per MFMA (32x32x2, D = A*B + C):  A[i = lane&31][k = lane>>5] = weight of
+// cout i, B[k][j = lane&31] = input of pixel j, D[row = cout][col = pixel]; a wave holds
+// NCG x QG accumulator tiles (NCG cout-groups of 32, QG pixel-groups of 32).
+// fp32 MFMA is an exact k-ordered fmaf chain, so results match an fp32 CPU reference to
+// summation-order rounding.
+#include "ttc_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kQG = 4;                       // pixel groups (of 32) per wave
+constexpr int kBQ = kWaves * kQG * 32;       // 512 flattened positions per workgroup
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int CK, int NCG, int EPI>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q) {
+    constexpr int BN = NCG * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Wp = a.Wp, Hp = a.Hp;
+    const int plane = Hp * Wp;
+    const int halo = 2 * Wp + 2;
+    const int TL = kBQ + halo;
+    const int TLp = (TL + 3) & ~3;
+    float* in_tile = smem;                   // [CK][TLp]
+    float* w_tile = smem + CK * TLp;         // [9][CK][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int bq = blockIdx.x, cb = blockIdx.y, n = blockIdx.z;
+    const int set = n / a.n_per_set, nn = n - set * a.n_per_set;
+    const int q0 = bq * kBQ;
+
+    const float* seg0 = a.seg[0].base + (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
+    const float* seg1 = a.seg[1].C > 0 ? a.seg[1].base + (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set] : nullptr;
+    const int C0 = a.seg[0].C;
+    const float* aux = a.aux ? a.aux + (long)set * a.aux_set_stride : nullptr;
+    const float* wsrc = a.w + (long)set * a.w_set_stride + (long)cb * nchunk * (9 * CK * BN);
+
+    f32x16 acc[NCG][kQG];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int j = 0; j < kQG; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
+
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = (t / 3) * Wp + (t % 3);
+
+    for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();
+        // ---- stage inputs: CK planes x TL contiguous floats (coalesced) ----
+        for (int lc = 0; lc < CK; ++lc) {
+            const int ci = c * CK + lc;
+            const float* src = nullptr;
+            if (ci < C0) src = seg0 + (long)ci * plane;
+            else if (ci < a.Cin) src = seg1 + (long)(ci - C0) * plane;
+            float* dst = in_tile + lc * TLp;
+            if (src) {
+                for (int i = tid; i < TL; i += kThreads) {
+                    const int q = q0 + i;
+                    dst[i] = q < plane ? src[q] : 0.0f;
+                }
+            } else {
+                for (int i = tid; i < TL; i += kThreads) dst[i] = 0.0f;
+            }
+        }
+        // ---- stage weights: 9*CK*BN contiguous floats ----
+        {
+            const float4* ws = reinterpret_cast<const float4*>(wsrc + (long)c * (9 * CK * BN));
+            float4* wd = reinterpret_cast<float4*>(w_tile);
+            for (int i = tid; i < 9 * CK * BN / 4; i += kThreads) wd[i] = ws[i];
+        }
+        __syncthreads();
+        // ---- MFMA ----
+        const float* ibase = in_tile + hi * TLp + wave * (kQG * 32) + lo;
+        const float* wbase = w_tile + hi * BN + lo;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int kp = 0; kp < CK / 2; ++kp) {
+                float av[NCG], bv[kQG];
+#pragma unroll
+                for (int g = 0; g < NCG; ++g) av[g] = wbase[(t * CK + 2 * kp) * BN + g * 32];
+#pragma unroll
+                for (int j = 0; j < kQG; ++j) bv[j] = ibase[(2 * kp) * TLp + toff[t] + j * 32];
+#pragma unroll
+                for (int g = 0; g < NCG; ++g)
+#pragma unroll
+                    for (int j = 0; j < kQG; ++j)
+                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], bv[j], acc[g][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    const int Hout = Hp - 2, Wout = Wp - 2;
+    float ssum[NCG][4], ssq[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ssum[g][k] = 0.f; ssq[g][k] = 0.f; }
+
+    float* outn = a.out + (long)n * a.out_stride_n;
+    const float* resn = (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) ? a.res + (long)n * a.out_stride_n : nullptr;
+
+#pragma unroll
+    for (int j = 0; j < kQG; ++j) {
+        const int q = q0 + (wave * kQG + j) * 32 + lo;
+        const int y = q / Wp, x = q - y * Wp;
+        const bool valid = (x < Wout) && (y < Hout);
+        float gate = 1.0f;
+        if (EPI == EPI_SSE) {
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot += aux[(r & 3) + 8 * (r >> 2) + 4 * hi] * acc[0][j][r];
+            dot += __shfl_xor(dot, 32);
+            gate = sigmoidf_(dot);
+        }
+        float ratio = 1.0f;
+        if (EPI == EPI_SWISH && a.same_pad) {
+            const bool ey = (y == 0) || (y == Hout - 1), ex = (x == 0) || (x == Wout - 1);
+            ratio = (ey && ex) ? 2.25f : ((ey || ex) ? 1.5f : 1.0f);
+        }
+        const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = acc[g][j][r];
+                if (EPI == EPI_SSE) v *= gate;
+                if (EPI == EPI_SWISH) { v *= ratio; v = v * sigmoidf_(v); }
+                const bool ok = valid && (co < a.Cout);
+                if (EPI >= EPI_BIAS) {
+                    if (co < a.Cout) v += aux[co];
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    if (EPI == EPI_BIAS_RES && ok) v = resn[(long)co * a.out_plane + opix] + 0.1f * v;
+                    if (EPI == EPI_BIAS_TANH_ADD && ok) v = resn[(long)co * a.out_plane + opix] + tanhf(v);
+                }
+                if (ok) outn[(long)co * a.out_plane + opix] = v;
+                if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
+            }
+        }
+    }
+
+    if (EPI <= EPI_SWISH && a.stats) {
+        // reduce over the 32 pixel-lanes of each half, then over the 4 waves through LDS
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = ssum[g][k], s2 = ssq[g][k];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
+                ssum[g][k] = s; ssq[g][k] = s2;
+            }
+        __syncthreads();
+        float* red = smem;                    // [kWaves][NCG*8][2]
+        if (lo == 0) {
+#pragma unroll
+            for (int g = 0; g < NCG; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int quad = g * 8 + 2 * k + hi;
+                    red[(wave * (NCG * 8) + quad) * 2 + 0] = ssum[g][k];
+                    red[(wave * (NCG * 8) + quad) * 2 + 1] = ssq[g][k];
+                }
+        }
+        __syncthreads();
+        if (tid < NCG * 8) {
+            float s = 0.f, s2 = 0.f;
+            for (int w = 0; w < kWaves; ++w) { s += red[(w * (NCG * 8) + tid) * 2]; s2 += red[(w * (NCG * 8) + tid) * 2 + 1]; }
+            const int quad = cb * (BN / 4) + tid;
+            if (quad * 4 < a.Cout) {
+                float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * nblk_q + bq) * 2;
+                dst[0] = s; dst[1] = s2;
+            }
+        }
+    }
+}
+
+template <int CK, int NCG, int EPI>
+hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t s) {
+    constexpr int BN = NCG * 32;
+    const int TL = kBQ + 2 * a.Wp + 2;
+    const int TLp = (TL + 3) & ~3;
+    const size_t lds = (size_t)(CK * TLp + 9 * CK * BN) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32<CK, NCG, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
+    dim3 grid(nblk_q, pw.ncb, n);
+    hipLaunchKernelGGL((conv3x3_f32<CK, NCG, EPI>), grid, dim3(kThreads), lds, s, a, pw.nchunk, nblk_q);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int conv_q_blocks(int Hp, int Wp) { return ((Hp - 2) * Wp + kBQ - 1) / kBQ; }
+
+int conv_pick_ck(int Cin) {
+    // smallest K padding: 49 -> 5 x 10, 17 -> 3 x 6, 10 -> 1 x 10, multiples of 8 -> 8
+    if (Cin % 8 == 0) return 8;
+    const int p8 = ((Cin + 7) / 8) * 8, p10 = ((Cin + 9) / 10) * 10, p6 = ((Cin + 5) / 6) * 6;
+    if (p6 <= p8 && p6 <= p10) return 6;
+    return p10 <= p8 ? 10 : 8;
+}
+
+int conv_pick_bn(int Cout) { return Cout >= 64 ? 64 : 32; }
+
+long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, int BN, std::vector<float>& out) {
+    const int nchunk = (Cin + CK - 1) / CK, ncb = (Cout + BN - 1) / BN;
+    const long per_set = (long)ncb * nchunk * 9 * CK * BN;
+    out.assign((size_t)per_set * nsets, 0.0f);
+    for (int s = 0; s < nsets; ++s)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int c = 0; c < nchunk; ++c)
+                for (int t = 0; t < 9; ++t)
+                    for (int lc = 0; lc < CK; ++lc)
+                        for (int co = 0; co < BN; ++co) {
+                            const int ci = c * CK + lc, o = cb * BN + co;
+                            if (ci >= Cin || o >= Cout) continue;
+                            // HWIO: [(t/3)][(t%3)][ci][o]
+                            out[(size_t)s * per_set + ((((long)cb * nchunk + c) * 9 + t) * CK + lc) * BN + co] =
+                                hwio[s][(((t / 3) * 3 + (t % 3)) * Cin + ci) * (long)Cout + o];
+                        }
+    return per_set;
+}
+
+hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
+    // only the (CK, BN, epilogue) combinations the two graphs need are instantiated
+#define TTC_CONV_CASE(ck, ncg, e) \
+    if (pw.CK == ck && pw.BN == ncg * 32 && epi == e) return launch_t<ck, ncg, e>(a, pw, n, s);
+    TTC_CONV_CASE(10, 2, EPI_RAW)            // ConvGRU gates        49 -> 64
+    TTC_CONV_CASE(10, 1, EPI_SSE)            // ConvGRU candidate    49 -> 32
+    TTC_CONV_CASE(6, 2, EPI_SWISH)           // conv_median          17 -> 64
+    TTC_CONV_CASE(8, 2, EPI_SWISH)           // U-Net blocks         {64,128,256} -> {64,128,256}
+    TTC_CONV_CASE(10, 1, EPI_BIAS_RELU)      // DSen2 in_conv        10 -> 32
+    TTC_CONV_CASE(8, 1, EPI_BIAS_RELU)       // DSen2 x1_conv        32 -> 32
+    TTC_CONV_CASE(8, 1, EPI_BIAS_RES)        // DSen2 x2_conv        32 -> 32 (+ residual)
+    TTC_CONV_CASE(8, 1, EPI_BIAS_TANH_ADD)   // DSen2 out_conv       32 -> 6  (+ bilinear)
+#undef TTC_CONV_CASE
+    return hipErrorInvalidValue;
+}

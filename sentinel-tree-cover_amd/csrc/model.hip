@@ -1,0 +1,492 @@
+// ConvGRU + U-Net forward over a batch of windows: elementwise / normalisation kernels and
+// the launch sequence around the MFMA conv engine (conv3x3_mfma.hip).
+//
+// Reference semantics: src/train/src/model.py (group_norm :100-121, ConvGRUCell :240-290,
+// ZoneoutWrapper :556-579, conv_swish_gn :448-538, sse_block :45-61) assembled as in
+// src/train/train-model.py:140-231.  The reference runs batch 1 per Session.run
+// (job.py:353-357); here all windows of one or more tiles are one batch, and the fw / bw
+// ConvGRU directions are a second batch axis (sequence n' = dir*N + n).
+//
+// Activation layout: planar fp32, [n][C][H][W]; every tensor that feeds a 3x3 conv is
+// stored already padded (reflect for the ConvGRU, zero for SAME blocks) so the conv is a
+// pure linear-offset implicit GEMM.  GroupNorm needs whole-window statistics (SURVEY.md
+// F7): the conv epilogue emits per-workgroup partial sums, k_gn_finalize reduces them in
+// double, and the NEXT elementwise kernel applies the affine while it gathers
+// (pad / pool / upsample / crop / concat are index math, never separate passes).
+#include "ttc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// ---------------------------------------------------------------------------------------
+// [n][L+1][W][W][C] (reference feed layout) -> padded planar frames [n][L+1][C][W+2][W+2];
+// frames < L reflect-padded (ConvGRU, model.py:250), frame L zero-padded (SAME conv).
+__global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict__ frames, int L1, int W, int C) {
+    const int Wp = W + 2;
+    const int f = blockIdx.y, n = blockIdx.z;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Wp * Wp) return;
+    const int py = p / Wp, px = p - py * Wp;
+    const bool last = (f == L1 - 1);
+    int sy = py - 1, sx = px - 1;
+    const bool border = sy < 0 || sy >= W || sx < 0 || sx >= W;
+    sy = reflect_idx(sy, W); sx = reflect_idx(sx, W);
+    const float* src = in + ((((long)n * L1 + f) * W + sy) * W + sx) * C;
+    float* dst = frames + (((long)n * L1 + f) * C) * (Wp * Wp) + p;
+    for (int c = 0; c < C; ++c) dst[(long)c * Wp * Wp] = (last && border) ? 0.0f : src[c];
+}
+
+// ---------------------------------------------------------------------------------------
+// GN partial sums -> (mean, rstd).  stats: [n][Cout/4][nblk][2]; groups of `qpg` quads.
+__global__ void k_gn_finalize(const float* __restrict__ stats, float* __restrict__ gn, int nquads, int nblk,
+                              int qpg, double count, float eps) {
+    const int g = blockIdx.x, n = blockIdx.y, G = gridDim.x;
+    const float* src = stats + (((long)n * nquads + (long)g * qpg) * nblk) * 2;
+    double s = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < qpg * nblk; i += 64) { s += src[2 * i]; s2 += src[2 * i + 1]; }
+    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
+    if (threadIdx.x == 0) {
+        const double mean = s / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0) var = 0;
+        gn[((long)n * G + g) * 2 + 0] = (float)mean;
+        gn[((long)n * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// ConvGRU, after the gates conv (model.py:259-270):
+//   r = sigmoid(GN(y[:32])), u = sigmoid(GN(y[32:])); writes r*h (reflect-padded) and u.
+struct GruParams { const float* base; long dir_stride; };   // per-direction parameter block
+// parameter block layout (floats): gr[32] br[32] gu[32] bu[32] k1[32] gy[32] by[32]
+constexpr int kGruParamFloats = 7 * 32;
+
+__global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm,
+                             const float* __restrict__ hcur, float* __restrict__ rh, float* __restrict__ u,
+                             int W, int N) {
+    const int Wp = W + 2, PP = Wp * Wp, P = W * W;
+    const int n = blockIdx.y, dir = n / N;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= PP) return;
+    const int py = p / Wp, px = p - py * Wp;
+    const int sy0 = py - 1, sx0 = px - 1;
+    const bool interior = sy0 >= 0 && sy0 < W && sx0 >= 0 && sx0 < W;
+    const int s = reflect_idx(sy0, W) * W + reflect_idx(sx0, W);
+    const float* pr = prm.base + dir * prm.dir_stride;
+    const float* y = yg + (long)n * 64 * P + s;
+    const float* g = gn + (long)n * 32;      // 16 groups x (mean, rstd): 0-7 r, 8-15 u
+    const float* h = hcur + (long)n * 32 * PP + p;
+    float* o = rh + (long)n * 32 * PP + p;
+    float* uo = u + (long)n * 32 * P + s;
+#pragma unroll 4
+    for (int c = 0; c < 32; ++c) {
+        const int gi = c >> 2;
+        const float r = sigm((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[c] + pr[32 + c]);
+        o[(long)c * PP] = r * h[(long)c * PP];
+        if (interior) {
+            const float uu = sigm((y[(long)(32 + c) * P] - g[16 + 2 * gi]) * g[16 + 2 * gi + 1] * pr[64 + c] + pr[96 + c]);
+            uo[(long)c * P] = uu;
+        }
+    }
+}
+
+// after the candidate conv (its epilogue already applied the in-cell sSE, model.py:278-282):
+//   cand = tanh(GN(y)); h' = u*h + (1-u)*cand (model.py:288); carried state = z*h + (1-z)*h'
+//   (ZoneoutWrapper inference branch, model.py:571-574).  On the last step also writes the
+//   final state zero-padded into gru_out[n][dir*32 + c] (train-model.py:165 concat order).
+__global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
+                             const float* __restrict__ u, const float* __restrict__ hcur, float* __restrict__ hnext,
+                             float* __restrict__ gru_out, int W, int N, float z) {
+    const int Wp = W + 2, PP = Wp * Wp, P = W * W;
+    const int n = blockIdx.y, dir = n / N;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= PP) return;
+    const int py = p / Wp, px = p - py * Wp;
+    const int sy0 = py - 1, sx0 = px - 1;
+    const bool interior = sy0 >= 0 && sy0 < W && sx0 >= 0 && sx0 < W;
+    const int s = reflect_idx(sy0, W) * W + reflect_idx(sx0, W);
+    const float* pr = prm.base + dir * prm.dir_stride;
+    const float* y = yc + (long)n * 32 * P + s;
+    const float* g = gn + (long)n * 16;      // 8 groups x (mean, rstd)
+    const float* uu = u + (long)n * 32 * P + s;
+    const float* h = hcur + (long)n * 32 * PP + p;
+    float* hn = hnext + (long)n * 32 * PP + p;
+    float* go = gru_out ? gru_out + ((long)(n - dir * N) * 64 + dir * 32) * PP + p : nullptr;
+#pragma unroll 4
+    for (int c = 0; c < 32; ++c) {
+        const int gi = c >> 2;
+        const float cand = tanhf((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
+        const float hv = h[(long)c * PP], uv = uu[(long)c * P];
+        const float hnew = uv * hv + (1.0f - uv) * cand;
+        const float hz = hv * z + hnew * (1.0f - z);
+        hn[(long)c * PP] = hz;
+        if (go) go[(long)c * PP] = interior ? hz : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// conv_swish_gn tail (model.py:519-531): GN(8 groups) affine -> sSE gate x * sigmoid(w.x + b),
+// fused with the gather that builds the next conv's input.
+enum GatherMode : int { G_COPY = 0, G_POOL = 1, G_UP = 2 };
+// block parameter layout (floats): gamma[C] beta[C] ssew[C] sseb[1]
+struct FinArgs {
+    const float* y; const float* gn; const float* prm;
+    float* dst;
+    int C, Hs, Ws;        // source (raw conv output) dims
+    int Hd, Wd;           // destination dims INCLUDING pad
+    int pad, crop, mode;
+    long dst_stride_n;    // floats per n in dst (lets two producers share a concat buffer)
+    int dst_coff;         // channel offset inside dst
+};
+
+template <int MODE>
+__global__ void k_block_finalize(FinArgs a) {
+    extern __shared__ float sm[];            // scale[C] shift[C] ssew[C]
+    const int C = a.C, n = blockIdx.y;
+    const int cpg = C / 8;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mean = a.gn[((long)n * 8 + c / cpg) * 2], rstd = a.gn[((long)n * 8 + c / cpg) * 2 + 1];
+        const float sc = rstd * a.prm[c];
+        sm[c] = sc; sm[C + c] = a.prm[C + c] - mean * sc; sm[2 * C + c] = a.prm[2 * C + c];
+    }
+    __syncthreads();
+    const float sseb = a.prm[3 * C];
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.Hd * a.Wd) return;
+    const int dy = d / a.Wd, dx = d - dy * a.Wd;
+    const long PS = (long)a.Hs * a.Ws, PD = (long)a.Hd * a.Wd;
+    float* dst = a.dst + (long)n * a.dst_stride_n + (long)a.dst_coff * PD + d;
+    const int iy = dy - a.pad, ix = dx - a.pad;
+    if (iy < 0 || ix < 0 || iy >= a.Hd - 2 * a.pad || ix >= a.Wd - 2 * a.pad) {
+        for (int c = 0; c < C; ++c) dst[(long)c * PD] = 0.0f;
+        return;
+    }
+    constexpr int NS = (MODE == G_POOL) ? 4 : 1;
+    int src[NS];
+    if (MODE == G_COPY) src[0] = (iy + a.crop) * a.Ws + ix + a.crop;
+    if (MODE == G_UP) src[0] = (iy >> 1) * a.Ws + (ix >> 1);
+    if (MODE == G_POOL) {
+        src[0] = (2 * iy) * a.Ws + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + a.Ws; src[3] = src[2] + 1;
+    }
+    const float* y = a.y + (long)n * C * PS;
+    float gate[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) gate[k] = sseb;
+    for (int c = 0; c < C; ++c) {
+        const float sc = sm[c], sh = sm[C + c], w = sm[2 * C + c];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) gate[k] += w * (y[(long)c * PS + src[k]] * sc + sh);
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) gate[k] = sigm(gate[k]);
+    for (int c = 0; c < C; ++c) {
+        const float sc = sm[c], sh = sm[C + c];
+        float v = (y[(long)c * PS + src[0]] * sc + sh) * gate[0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) v = fmaxf(v, (y[(long)c * PS + src[k]] * sc + sh) * gate[k]);
+        dst[(long)c * PD] = v;
+    }
+}
+
+// final block tail + 1x1 head (train-model.py:226-231): sigmoid(sum_c hw[c] * z[c] + hb)
+__global__ void k_head(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
+                       const float* __restrict__ headp, float* __restrict__ out, int C, int P) {
+    extern __shared__ float sm[];            // scale shift ssew headw
+    const int n = blockIdx.y, cpg = C / 8;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mean = gn[((long)n * 8 + c / cpg) * 2], rstd = gn[((long)n * 8 + c / cpg) * 2 + 1];
+        const float sc = rstd * prm[c];
+        sm[c] = sc; sm[C + c] = prm[C + c] - mean * sc; sm[2 * C + c] = prm[2 * C + c]; sm[3 * C + c] = headp[c];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* y = yraw + (long)n * C * P + p;
+    float gate = prm[3 * C];
+    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * P] * sm[c] + sm[C + c]);
+    gate = sigm(gate);
+    float logit = headp[C];
+    for (int c = 0; c < C; ++c) logit += sm[3 * C + c] * ((y[(long)c * P] * sm[c] + sm[C + c]) * gate);
+    out[(long)n * P + p] = sigm(logit);
+}
+
+struct Geo {
+    int W, Wp, L, c1, c2, u2, u3, o;
+    explicit Geo(const ttc_config& c) : W(c.win_in), Wp(c.win_in + 2), L(c.length) {
+        c1 = W / 2 - 2; c2 = c1 / 2 - 2; u2 = 2 * c2; u3 = 2 * u2; o = u3 - 2;
+    }
+};
+
+const char* kBlockNames[8] = {"conv_median", "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out"};
+const int kBlockCin[8] = {17, 128, 64, 128, 256, 256, 128, 128};
+const int kBlockCout[8] = {64, 64, 128, 256, 128, 128, 64, 64};
+
+}  // namespace
+
+float* ttc_ctx::alloc_f(size_t n, const char* name) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) return nullptr;
+    allocs.push_back(p);
+    dev_bytes += n * sizeof(float);
+    if (name) named[name] = {static_cast<float*>(p), n};
+    return static_cast<float*>(p);
+}
+
+void* ttc_ctx::scratch_buf(const std::string& key, size_t bytes) {
+    auto it = scratch.find(key);
+    if (it != scratch.end() && it->second.second >= bytes) return it->second.first;
+    if (it != scratch.end()) { hipFree(it->second.first); dev_bytes -= it->second.second; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { scratch.erase(key); return nullptr; }
+    scratch[key] = {p, bytes};
+    dev_bytes += bytes;
+    return p;
+}
+
+ttc_status model_alloc(ttc_ctx* c) {
+    const Geo g(c->cfg);
+    const size_t N = c->cfg.max_windows, N2 = 2 * N;
+    const size_t PP = (size_t)g.Wp * g.Wp, P = (size_t)g.W * g.W;
+    const int F = c->cfg.base_filters, Hd = c->cfg.hidden, C = c->cfg.n_bands;
+    if (g.W % 4 != 0 || g.W < 28) return c->fail(TTC_ERR_ARG, "win_in must be a multiple of 4 and >= 28");
+    if (F != 64 || Hd != 32 || C != 17) return c->fail(TTC_ERR_ARG, "only base_filters=64, hidden=32, n_bands=17 are built");
+#define A(field, count, name)                                                        \
+    if (!(c->field = c->alloc_f((count), name))) return c->fail(TTC_ERR_NOMEM, "hipMalloc " name)
+    A(frames, N * (g.L + 1) * C * PP, "frames");
+    A(h[0], N2 * Hd * PP, "h0"); A(h[1], N2 * Hd * PP, "h1"); A(rh, N2 * Hd * PP, "rh");
+    A(yg, N2 * 2 * Hd * P, "yg"); A(ug, N2 * Hd * P, "u"); A(yc, N2 * Hd * P, "yc");
+    A(gru_out, N * F * PP, "gru_out");
+    A(y_med, N * F * P, "y_med"); A(z_med, N * F * PP, "z_med"); A(y_cat, N * F * P, "y_cat");
+    A(p1, N * F * (P / 4), "p1"); A(y_c1, N * 2 * F * g.c1 * g.c1, "y_c1");
+    A(p2, N * 2 * F * (g.c1 / 2) * (g.c1 / 2), "p2"); A(y_c2, N * 4 * F * g.c2 * g.c2, "y_c2");
+    A(u2in, N * 4 * F * (g.u2 + 2) * (g.u2 + 2), "u2in"); A(y_u2, N * 2 * F * g.u2 * g.u2, "y_u2");
+    A(u2a, N * 4 * F * (g.u2 + 2) * (g.u2 + 2), "u2cat");     // [up2 | crop(conv1)] concat buffer
+    A(y_u2o, N * 2 * F * g.u2 * g.u2, "y_u2o");
+    A(u3in, N * 2 * F * (g.u3 + 2) * (g.u3 + 2), "u3in"); A(y_u3, N * F * g.u3 * g.u3, "y_u3");
+    A(oa, N * 2 * F * g.u3 * g.u3, "ocat");                    // [up3 | crop(concat)] concat buffer
+    A(y_out, N * F * g.o * g.o, "y_out");
+    c->stats_floats = N2 * 16 * (size_t)conv_q_blocks(g.Wp, g.Wp) * 2 + 1024;
+    A(stats, c->stats_floats, "stats");
+    A(gn, 10 * N2 * 32, "gn");
+#undef A
+    return TTC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+static const ttc_tensor* find_t(const ttc_tensor* t, int n, const std::string& name) {
+    for (int i = 0; i < n; ++i) if (name == t[i].name) return &t[i];
+    return nullptr;
+}
+
+static ttc_status upload_conv(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout) {
+    pc.Cin = Cin; pc.Cout = Cout; pc.nsets = nsets;
+    pc.CK = conv_pick_ck(Cin); pc.BN = conv_pick_bn(Cout);
+    pc.nchunk = (Cin + pc.CK - 1) / pc.CK; pc.ncb = (Cout + pc.BN - 1) / pc.BN;
+    std::vector<float> packed;
+    pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);
+    if (!pc.d_w) {
+        pc.d_w = c->alloc_f(packed.size());
+        if (!pc.d_w) return c->fail(TTC_ERR_NOMEM, "hipMalloc weights");
+    }
+    TTC_HIP(c, hipMemcpy(pc.d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    return TTC_OK;
+}
+
+ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
+    const int Hd = c->cfg.hidden, Cx = c->cfg.n_bands;
+    auto need = [&](const std::string& name, int64_t numel) -> const ttc_tensor* {
+        const ttc_tensor* p = find_t(t, n, name);
+        if (!p) { c->fail(TTC_ERR_ARG, "missing weight tensor: " + name); return nullptr; }
+        int64_t e = 1;
+        for (int i = 0; i < p->ndim; ++i) e *= p->shape[i];
+        if (e != numel) { c->fail(TTC_ERR_ARG, "wrong element count for " + name); return nullptr; }
+        return p;
+    };
+    const char* dirs[2] = {"fw", "bw"};
+    const float* gk[2]; const float* ck[2];
+    std::vector<float> small;
+    c->small_off.clear();
+    for (int d = 0; d < 2; ++d) {
+        const std::string p = std::string("gru/") + dirs[d] + "/";
+        const ttc_tensor* a = need(p + "gates/kernel", 9LL * (Cx + Hd) * 2 * Hd);
+        const ttc_tensor* b = need(p + "candidate/kernel", 9LL * (Cx + Hd) * Hd);
+        if (!a || !b) return TTC_ERR_ARG;
+        gk[d] = a->data; ck[d] = b->data;
+        c->small_off[p] = (long)small.size();
+        const char* vecs[7] = {"gates_r/gamma", "gates_r/beta", "gates_u/gamma", "gates_u/beta",
+                               "candidate/kernel_1", "candidate_y/gamma", "candidate_y/beta"};
+        for (const char* v : vecs) {
+            const ttc_tensor* q = need(p + v, Hd);
+            if (!q) return TTC_ERR_ARG;
+            small.insert(small.end(), q->data, q->data + Hd);
+        }
+    }
+    TTC_CHECK(upload_conv(c, c->w_gates, gk, 2, Cx + Hd, 2 * Hd));
+    TTC_CHECK(upload_conv(c, c->w_cand, ck, 2, Cx + Hd, Hd));
+    for (int b = 0; b < 8; ++b) {
+        const std::string p = std::string(kBlockNames[b]) + "/";
+        const int Ci = kBlockCin[b], Co = kBlockCout[b];
+        const ttc_tensor* k = need(p + "kernel", 9LL * Ci * Co);
+        const ttc_tensor* ga = need(p + "gamma", Co);
+        const ttc_tensor* be = need(p + "beta", Co);
+        const ttc_tensor* sw = need(p + "sse_kernel", Co);
+        const ttc_tensor* sb = need(p + "sse_bias", 1);
+        if (!k || !ga || !be || !sw || !sb) return TTC_ERR_ARG;
+        const float* kk[1] = {k->data};
+        TTC_CHECK(upload_conv(c, c->w_block[b], kk, 1, Ci, Co));
+        c->small_off[p] = (long)small.size();
+        small.insert(small.end(), ga->data, ga->data + Co);
+        small.insert(small.end(), be->data, be->data + Co);
+        small.insert(small.end(), sw->data, sw->data + Co);
+        small.push_back(sb->data[0]);
+    }
+    const ttc_tensor* hk = need("head/kernel", 64);
+    const ttc_tensor* hb = need("head/bias", 1);
+    if (!hk || !hb) return TTC_ERR_ARG;
+    c->small_off["head/"] = (long)small.size();
+    small.insert(small.end(), hk->data, hk->data + 64);
+    small.push_back(hb->data[0]);
+    if (!c->d_small) {
+        c->d_small = c->alloc_f(small.size() + 64);
+        if (!c->d_small) return c->fail(TTC_ERR_NOMEM, "hipMalloc small params");
+    }
+    TTC_HIP(c, hipMemcpy(c->d_small, small.data(), small.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->have_model = true;
+    return TTC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStream_t s) {
+    const Geo g(c->cfg);
+    KTimer kt(c, "frames_from_nhwc", s);
+    dim3 grid((g.Wp * g.Wp + 255) / 256, g.L + 1, n);
+    hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.W, c->cfg.n_bands);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+static ttc_status gn_fin(ttc_ctx* c, float* gn, int nseq, int Cout, int groups, int nblk, double count, hipStream_t s) {
+    KTimer kt(c, "gn_finalize", s);
+    const int nquads = Cout / 4;
+    hipLaunchKernelGGL(k_gn_finalize, dim3(groups, nseq), dim3(64), 0, s, c->stats, gn, nquads, nblk, nquads / groups,
+                       count, 1e-5f);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+static ttc_status finalize(ttc_ctx* c, int mode, const FinArgs& a, int n, hipStream_t s) {
+    KTimer kt(c, "block_finalize", s);
+    dim3 grid((a.Hd * a.Wd + 255) / 256, n);
+    const size_t lds = 3 * a.C * sizeof(float);
+    if (mode == G_COPY) hipLaunchKernelGGL(k_block_finalize<G_COPY>, grid, dim3(256), lds, s, a);
+    else if (mode == G_POOL) hipLaunchKernelGGL(k_block_finalize<G_POOL>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(k_block_finalize<G_UP>, grid, dim3(256), lds, s, a);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
+    if (!c->have_model) return c->fail(TTC_ERR_STATE, "ttc_load_weights has not been called");
+    if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
+    const Geo g(c->cfg);
+    const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
+    const long PP = (long)g.Wp * g.Wp, P = (long)g.W * g.W;
+    const float* sm = c->d_small;
+    float* gn_slot[10];
+    for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
+    const int nblk_full = conv_q_blocks(g.Wp, g.Wp);
+
+    // ---------------- bi-directional ConvGRU ----------------
+    TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
+    const GruParams gp{sm + c->small_off["gru/fw/"], c->small_off["gru/bw/"] - c->small_off["gru/fw/"]};
+    int cur = 0;
+    for (int st = 0; st < g.L; ++st) {
+        ConvArgs a{};
+        a.seg[0] = {c->frames, (long)(g.L + 1) * Cx * PP, {(long)st * Cx * PP, (long)(g.L - 1 - st) * Cx * PP}, Cx};
+        a.seg[1] = {c->h[cur], (long)Hd * PP, {0, (long)N * Hd * PP}, Hd};
+        a.Cin = Cx + Hd; a.Hp = g.Wp; a.Wp = g.Wp; a.Cout = 2 * Hd;
+        a.w = c->w_gates.d_w; a.w_set_stride = c->w_gates.set_stride; a.n_per_set = N;
+        a.out = c->yg; a.out_stride_n = 2L * Hd * P; a.out_plane = P; a.out_pitch = g.W; a.oy = a.ox = 0;
+        a.stats = c->stats;
+        { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
+        TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
+        {
+            KTimer kt(c, "gru_apply1", s);
+            hipLaunchKernelGGL(k_gru_apply1, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
+                               c->h[cur], c->rh, c->ug, g.W, N);
+            TTC_HIP(c, hipGetLastError());
+        }
+        a.seg[1].base = c->rh;
+        a.Cout = Hd; a.w = c->w_cand.d_w; a.w_set_stride = c->w_cand.set_stride;
+        a.out = c->yc; a.out_stride_n = (long)Hd * P;
+        a.aux = gp.base + 4 * 32; a.aux_set_stride = gp.dir_stride;
+        { KTimer kt(c, "conv_cand", s); TTC_HIP(c, conv_launch(a, c->w_cand, EPI_SSE, N2, s)); }
+        TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
+        {
+            KTimer kt(c, "gru_apply2", s);
+            hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
+                               c->ug, c->h[cur], c->h[cur ^ 1], st == g.L - 1 ? c->gru_out : nullptr, g.W, N,
+                               c->cfg.zoneout);
+            TTC_HIP(c, hipGetLastError());
+        }
+        cur ^= 1;
+    }
+
+    // ---------------- U-Net ----------------
+    auto block_conv = [&](int b, ConvSeg s0, ConvSeg s1, int Hp, int Wp, int same, float* out, const char* tname) -> ttc_status {
+        ConvArgs a{};
+        a.seg[0] = s0; a.seg[1] = s1; a.Cin = s0.C + s1.C; a.Hp = Hp; a.Wp = Wp; a.Cout = kBlockCout[b];
+        a.w = c->w_block[b].d_w; a.w_set_stride = 0; a.n_per_set = N;
+        const long Po = (long)(Hp - 2) * (Wp - 2);
+        a.out = out; a.out_stride_n = (long)a.Cout * Po; a.out_plane = Po; a.out_pitch = Wp - 2; a.oy = a.ox = 0;
+        a.stats = c->stats; a.same_pad = same;
+        { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
+        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_q_blocks(Hp, Wp), (double)(a.Cout / 8) * Po, s);
+    };
+    auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
+    auto fin = [&](int b, int mode, const float* y, int Hs, float* dst, int Hd_, int pad, int crop, long dst_stride_n,
+                   int coff) -> ttc_status {
+        FinArgs f{y, gn_slot[b], prm(b), dst, kBlockCout[b], Hs, Hs, Hd_, Hd_, pad, crop, mode, dst_stride_n, coff};
+        return finalize(c, mode, f, N, s);
+    };
+    const ConvSeg none{nullptr, 0, {0, 0}, 0};
+    // conv_median on the median frame (zero-padded SAME)
+    TTC_CHECK(block_conv(0, {c->frames + (long)g.L * Cx * PP, (long)(g.L + 1) * Cx * PP, {0, 0}, Cx}, none, g.Wp, g.Wp, 1,
+                         c->y_med, "conv_median"));
+    TTC_CHECK(fin(0, G_COPY, c->y_med, g.W, c->z_med, g.Wp, 1, 0, (long)F * PP, 0));
+    // conv_concat([gru, median_conv])
+    TTC_CHECK(block_conv(1, {c->gru_out, (long)F * PP, {0, 0}, F}, {c->z_med, (long)F * PP, {0, 0}, F}, g.Wp, g.Wp, 1,
+                         c->y_cat, "conv_concat"));
+    TTC_CHECK(fin(1, G_POOL, c->y_cat, g.W, c->p1, g.W / 2, 0, 0, (long)F * (P / 4), 0));
+    // conv1 (VALID) on pool1
+    TTC_CHECK(block_conv(2, {c->p1, (long)F * (P / 4), {0, 0}, F}, none, g.W / 2, g.W / 2, 0, c->y_c1, "conv1"));
+    const int h2 = g.c1 / 2;
+    TTC_CHECK(fin(2, G_POOL, c->y_c1, g.c1, c->p2, h2, 0, 0, 2L * F * h2 * h2, 0));
+    // conv2 (VALID) on pool2
+    TTC_CHECK(block_conv(3, {c->p2, 2L * F * h2 * h2, {0, 0}, 2 * F}, none, h2, h2, 0, c->y_c2, "conv2"));
+    const int u2p = g.u2 + 2;
+    TTC_CHECK(fin(3, G_UP, c->y_c2, g.c2, c->u2in, u2p, 1, 0, 4L * F * u2p * u2p, 0));
+    // up2 (SAME) on nearest x2
+    TTC_CHECK(block_conv(4, {c->u2in, 4L * F * u2p * u2p, {0, 0}, 4 * F}, none, u2p, u2p, 1, c->y_u2, "up2"));
+    TTC_CHECK(fin(4, G_COPY, c->y_u2, g.u2, c->u2a, u2p, 1, 0, 4L * F * u2p * u2p, 0));
+    TTC_CHECK(fin(2, G_COPY, c->y_c1, g.c1, c->u2a, u2p, 1, 2, 4L * F * u2p * u2p, 2 * F));   // crop(conv1, 2)
+    TTC_CHECK(block_conv(5, {c->u2a, 4L * F * u2p * u2p, {0, 0}, 4 * F}, none, u2p, u2p, 1, c->y_u2o, "up2_out"));
+    const int u3p = g.u3 + 2;
+    TTC_CHECK(fin(5, G_UP, c->y_u2o, g.u2, c->u3in, u3p, 1, 0, 2L * F * u3p * u3p, 0));
+    // up3 (SAME)
+    TTC_CHECK(block_conv(6, {c->u3in, 2L * F * u3p * u3p, {0, 0}, 2 * F}, none, u3p, u3p, 1, c->y_u3, "up3"));
+    TTC_CHECK(fin(6, G_COPY, c->y_u3, g.u3, c->oa, g.u3, 0, 0, 2L * F * g.u3 * g.u3, 0));
+    TTC_CHECK(fin(1, G_COPY, c->y_cat, g.W, c->oa, g.u3, 0, 6, 2L * F * g.u3 * g.u3, F));     // crop(concat, 6)
+    // out (VALID)
+    TTC_CHECK(block_conv(7, {c->oa, 2L * F * g.u3 * g.u3, {0, 0}, 2 * F}, none, g.u3, g.u3, 0, c->y_out, "out_conv"));
+    {
+        KTimer kt(c, "head", s);
+        const int Po = g.o * g.o;
+        hipLaunchKernelGGL(k_head, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
+                           prm(7), sm + c->small_off["head/"], d_out, F, Po);
+        TTC_HIP(c, hipGetLastError());
+    }
+    return TTC_OK;
+}

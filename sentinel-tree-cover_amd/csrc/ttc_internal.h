@@ -1,0 +1,144 @@
+// Internal declarations shared by the HIP translation units of libttc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ttc.h"
+
+#define TTC_HIP(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (ctx)->fail(TTC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+            return TTC_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define TTC_CHECK(expr)                         \
+    do {                                        \
+        ttc_status s_ = (expr);                 \
+        if (s_ != TTC_OK) return s_;            \
+    } while (0)
+
+// ----------------------------------------------------------------------------- conv engine
+// Implicit-GEMM 3x3 convolution on fp32 MFMA over "flattened padded planes":
+//   in  : [n][Cin][Hp*Wp]  planar, already padded (reflect / zero / none) by the producer
+//   out : out[n][co][(y+oy)*out_pitch + (x+ox)]  for y < Hp-2, x < Wp-2
+//   out[q] = sum_{ci,dy,dx} w[co][ci][dy][dx] * in[ci][q + dy*Wp + dx],  q = y*Wp + x
+// so a tap is a pure linear offset and a block owns a contiguous run of q.
+enum ConvEpilogue : int {
+    EPI_RAW = 0,        // y (ConvGRU gates)                                   + GN quad stats
+    EPI_SSE = 1,        // y * sigmoid(sum_co k1[co] y[co]) (ConvGRU candidate) + GN quad stats
+    EPI_SWISH = 2,      // partial-conv ratio, swish                            + GN quad stats
+    EPI_BIAS = 3,       // y + b                      (DSen2)
+    EPI_BIAS_RELU = 4,  // relu(y + b)                (DSen2)
+    EPI_BIAS_RES = 5,   // res + 0.1 * (y + b)        (DSen2 residual blocks)
+    EPI_BIAS_TANH_ADD = 6  // res + tanh(y + b)       (DSen2 head; res = bilinear bands)
+};
+
+struct ConvSeg {
+    const float* base;   // segment tensor
+    long stride_n;       // floats between consecutive n (within a weight set)
+    long set_off[2];     // extra offset for weight-set 0 / 1 (ConvGRU fw / bw frame choice)
+    int C;               // channels in this segment
+};
+
+struct ConvArgs {
+    ConvSeg seg[2];
+    int Cin;             // seg[0].C + seg[1].C
+    int Hp, Wp;          // padded input plane
+    int Cout;            // real output channels
+    const float* w;      // packed: [set][cout_block][chunk][tap][CK][BN]
+    long w_set_stride;   // floats between weight sets
+    int n_per_set;       // n / n_per_set selects the weight set (and seg.set_off)
+    float* out;
+    long out_stride_n, out_plane;
+    int out_pitch, oy, ox;
+    float* stats;        // [n][Cout/4][nblk_q] float2 (sum, sumsq) or nullptr
+    const float* aux;    // EPI_SSE: k1[Cout]; EPI_BIAS*: bias[Cout]
+    long aux_set_stride; // floats between the aux vectors of weight sets
+    const float* res;    // EPI_BIAS_RES / _TANH_ADD: residual, same indexing as out
+    int same_pad;        // EPI_SWISH: 1 -> multiply by the partial-conv ratio (zero-padded SAME conv)
+};
+
+struct PackedConv {      // device copy of one layer's packed weights
+    float* d_w = nullptr;
+    int Cin = 0, Cout = 0, CK = 0, BN = 0, nsets = 1;
+    int nchunk = 0, ncb = 0;
+    long set_stride = 0;
+};
+
+int conv_pick_ck(int Cin);
+int conv_pick_bn(int Cout);
+// packs HWIO host kernels (one per weight set) into the layout above; returns floats per set
+long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, int BN, std::vector<float>& out);
+int conv_q_blocks(int Hp, int Wp);   // grid.x for a plane
+hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+
+// ----------------------------------------------------------------------------- context
+struct Timing {
+    bool enabled = false;
+    struct Rec { double ms = 0; int64_t n = 0; };
+    std::map<std::string, Rec> recs;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+};
+
+struct ttc_ctx {
+    ttc_config cfg{};
+    int device = 0;
+    std::string err;
+    size_t dev_bytes = 0;
+    std::vector<void*> allocs;
+    std::map<std::string, std::pair<float*, size_t>> named;   // debug-visible activations
+
+    // model weights
+    bool have_model = false, have_dsen2 = false;
+    PackedConv w_gates, w_cand;                 // 2 sets (fw, bw)
+    PackedConv w_block[8];                      // conv_median, conv_concat, conv1, conv2, up2, up2_out, up3, out
+    float* d_small = nullptr;                   // small per-channel vectors (gamma/beta/sse/head ...)
+    std::map<std::string, long> small_off;      // name -> offset (floats) into d_small
+    PackedConv w_ds[6];
+    float* d_ds_bias = nullptr;
+
+    // workspace (model)
+    float *frames = nullptr, *h[2] = {nullptr, nullptr}, *rh = nullptr, *yg = nullptr, *ug = nullptr,
+          *yc = nullptr, *gru_out = nullptr;
+    float *y_med = nullptr, *z_med = nullptr, *y_cat = nullptr, *p1 = nullptr, *y_c1 = nullptr, *p2 = nullptr,
+          *y_c2 = nullptr, *u2in = nullptr, *y_u2 = nullptr, *u2a = nullptr, *y_u2o = nullptr,
+          *u3in = nullptr, *y_u3 = nullptr, *oa = nullptr, *y_out = nullptr;
+    float *stats = nullptr, *gn = nullptr;      // GN partial sums / (mean, rstd)
+    size_t stats_floats = 0;
+    // workspace (tile-level), grown on demand
+    std::map<std::string, std::pair<void*, size_t>> scratch;
+
+    Timing timing;
+
+    ttc_status fail(ttc_status s, const std::string& m) { err = m; return s; }
+    float* alloc_f(size_t n, const char* name = nullptr);
+    void* scratch_buf(const std::string& key, size_t bytes);
+};
+
+// model.hip
+ttc_status model_alloc(ttc_ctx* c);
+ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n);
+ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s);
+ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStream_t s);
+// dsen2.hip
+ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n);
+
+// timing helper: wraps a launch in HIP events on stream s when enabled
+struct KTimer {
+    ttc_ctx* c; const char* name; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    KTimer(ttc_ctx* c_, const char* n_, hipStream_t s_) : c(c_), name(n_), s(s_) {
+        if (c->timing.enabled) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~KTimer() {
+        if (a) { hipEventRecord(b, s); c->timing.pending.push_back({name, {a, b}}); }
+    }
+};

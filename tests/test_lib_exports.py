@@ -1,0 +1,64 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ttc.h declares; host-side
+weight handling.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests.helpers import ROOT
+import ttc
+from ttc import _lib, weights as W
+
+
+def _ensure_built():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_header_symbols_exported():
+    _ensure_built()
+    hdr = open(os.path.join(ROOT, "include", "ttc.h")).read()
+    declared = set(re.findall(r"\b(ttc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ttc_status"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ttc_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.ttc_version()
+
+
+def test_loader_prototypes():
+    _ensure_built()
+    lib = _lib.load()
+    assert lib.ttc_create.argtypes is not None
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        _lib.Context(win_in=44, length=1, max_windows=1)
+
+
+def test_weights_match_oracle_generator_and_validate():
+    from oracle import restate_model as M
+    a, b = W.synth_weights(3), M.synth_weights(3)
+    assert a.keys() == b.keys()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    W.validate(a)
+    bad = dict(a)
+    bad.pop("head/bias")
+    with pytest.raises(ValueError):
+        W.validate(bad)
+    # round trip through the TF variable names
+    tf_named = {W.TF_NAME_MAP[k]: v for k, v in a.items()}
+    back = W.from_tf_checkpoint_npz(tf_named)
+    for k in a:
+        np.testing.assert_array_equal(a[k], back[k])
+    assert sum(v.size for v in W.load_dsen2().values()) == 41638

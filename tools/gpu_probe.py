@@ -1,0 +1,38 @@
+"""GPU-box probe: per-kernel device time of one batched forward (HIP events inside the library)."""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+import ttc
+from ttc import _lib, synth, weights
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 172
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 36
+ctx = _lib.Context(win_in=W, length=L, max_windows=N)
+ctx.load_weights(weights.synth_weights(0))
+x = torch.from_numpy(synth.synth_windows(seed=1, N=N, L=L, W=W)).cuda()
+print("device bytes", ctx.device_bytes / 1e9, "GB")
+for _ in range(2):
+    ctx.forward_windows(x)
+torch.cuda.synchronize()
+t = time.time()
+K = 5
+for _ in range(K):
+    ctx.forward_windows(x)
+torch.cuda.synchronize()
+dt = (time.time() - t) / K
+from oracle.restate_model import model_flops
+fl = model_flops(W, L) * N
+print(f"forward {N} windows W={W} L={L}: {dt*1e3:.2f} ms  -> {fl/dt/1e12:.1f} TFLOP/s (algorithmic), {N/36*618*618/dt/1e6:.1f} Mpx/s")
+ctx.timing(True)
+for _ in range(3):
+    ctx.forward_windows(x)
+tot = 0
+for k in ["frames_from_nhwc", "conv_gates", "conv_cand", "gn_finalize", "gru_apply1", "gru_apply2", "conv_median",
+          "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out_conv", "block_finalize", "head"]:
+    ms, n = ctx.kernel_ms(k)
+    per_fwd = ms * n / 3
+    tot += per_fwd
+    print(f"  {k:18s} avg {ms:8.3f} ms x {n/3:5.1f}/fwd = {per_fwd:8.3f} ms")
+print("  sum", tot)
