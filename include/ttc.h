@@ -94,10 +94,14 @@ ttc_status ttc_forward_windows(ttc_ctx* ctx, const float* d_in, int32_t n, float
  * h_wmat   [12, T]        float32 host: temporal operator = Whittaker(lambda=100, 24->12)
  *                         o date-regrid (src/preprocessing/whittaker_smoother.py:25-67,
  *                         src/downloading/utils.py:176-347), built by the host mirror
+ * h_keep   [T] int32 host  1 = date survives deal_w_missing_px's screening (job.py:1032-1037);
+ *                         NULL = all.  Medians (job.py:1152-1160) use ALL dates, smoothing and
+ *                         the clear-image count only the kept ones, as in the reference.
  * d_interp [T, X, Y]      interpolated-area weights from the gap-fill
  * d_s1     [12, X, Y, 2]  monthly Sentinel-1 (dB-scaled)
  * d_dem    [X, Y]
- * h_min/h_max [17]        normalisation vectors (job.py:1829-1842)
+ * h_min/h_max [17] double normalisation vectors (job.py:1829-1842; Python floats in the reference:
+ *                         midrange / half-range are formed in float64, then used as float32)
  * size                    output window size (W - 14); windows follow job.py:1295-1317
  * n_dates_ok              len(dates) after host screening (job.py:1418: < 2 -> no data)
  * d_windows [36, size, size] float32: what the reference np.save()s per window
@@ -105,9 +109,9 @@ ttc_status ttc_forward_windows(ttc_ctx* ctx, const float* d_in, int32_t n, float
  * d_windows_raw           same before np.around / bright-surface product (may be NULL)
  */
 ttc_status ttc_process_subtiles(ttc_ctx* ctx, const float* d_s2, int32_t T, int32_t X, int32_t Y,
-                                const float* h_wmat, const float* d_interp, const float* d_s1,
-                                const float* d_dem, const float* h_min, const float* h_max,
-                                int32_t size, int32_t n_dates_ok,
+                                const float* h_wmat, const int32_t* h_keep, const float* d_interp,
+                                const float* d_s1, const float* d_dem, const double* h_min,
+                                const double* h_max, int32_t size, int32_t n_dates_ok,
                                 float* d_windows, float* d_windows_raw, void* stream);
 
 /* per-date count of "missing" pixels, id_missing_px (src/preprocessing/interpolation.py:5-23);

@@ -60,7 +60,8 @@ def load():
     lib.ttc_load_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
     lib.ttc_load_dsen2_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
     lib.ttc_forward_windows.argtypes = [P, VP, I32, VP, VP]
-    lib.ttc_process_subtiles.argtypes = [P, VP, I32, I32, I32, F32P, VP, VP, VP, F32P, F32P, I32, I32, VP, VP, VP]
+    lib.ttc_process_subtiles.argtypes = [P, VP, I32, I32, I32, F32P, C.POINTER(C.c_int32), VP, VP, VP,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), I32, I32, VP, VP, VP]
     lib.ttc_tile_missing_counts.argtypes = [P, VP, I32, I32, I32, VP, VP]
     lib.ttc_tile_fix_missing.argtypes = [P, VP, I32, I32, I32, I32, I32, VP]
     lib.ttc_mosaic.argtypes = [P, VP, I32, C.POINTER(C.c_int32), I32, I32, I32, VP, VP, VP]
@@ -171,6 +172,83 @@ class Context:
         self._check(self.lib.ttc_forward_windows(self._h, C.c_void_p(xd.data_ptr()), n,
                                                  C.c_void_p(out.data_ptr()), self._stream()),
                     "ttc_forward_windows")
+        return out
+
+    # -- per-tile core -------------------------------------------------------------------
+    def tile_fix_missing(self, s2d, do_nan=True, do_zero_one=False):
+        """in place on a cuda tensor [T, X, Y, 10]"""
+        T, X, Y = (int(v) for v in s2d.shape[:3])
+        self._check(self.lib.ttc_tile_fix_missing(self._h, C.c_void_p(s2d.data_ptr()), T, X, Y, int(do_nan),
+                                                  int(do_zero_one), self._stream()), "ttc_tile_fix_missing")
+        return s2d
+
+    def tile_missing_counts(self, s2d):
+        t = self.torch
+        T, X, Y = (int(v) for v in s2d.shape[:3])
+        counts = t.zeros(T, dtype=t.int32, device=s2d.device)
+        self._check(self.lib.ttc_tile_missing_counts(self._h, C.c_void_p(s2d.data_ptr()), T, X, Y,
+                                                     C.c_void_p(counts.data_ptr()), self._stream()),
+                    "ttc_tile_missing_counts")
+        return counts.cpu().numpy()
+
+    def process_subtiles(self, s2, wmat, keep, interp, s1, dem, min_all, max_all, size, n_dates_ok, want_raw=False):
+        """-> (windows [n, size, size] cuda float32, raw or None).  Window order = job.py iteration order."""
+        t = self.torch
+        s2d, itp, s1d, demd = (self._dev(a, t.float32) for a in (s2, interp, s1, dem))
+        T, X, Y = (int(v) for v in s2d.shape[:3])
+        assert tuple(itp.shape) == (T, X, Y) and tuple(s1d.shape) == (12, X, Y, 2) and tuple(demd.shape) == (X, Y)
+        w = np.ascontiguousarray(wmat, dtype=np.float32)
+        assert w.shape == (12, T)
+        k = np.ascontiguousarray(keep, dtype=np.int32)
+        mn = np.ascontiguousarray(min_all, dtype=np.float64)
+        mx = np.ascontiguousarray(max_all, dtype=np.float64)
+        nwin = 36
+        out = t.empty((nwin, size, size), dtype=t.float32, device=s2d.device)
+        raw = t.empty((nwin, size, size), dtype=t.float32, device=s2d.device) if want_raw else None
+        self._check(self.lib.ttc_process_subtiles(
+            self._h, C.c_void_p(s2d.data_ptr()), T, X, Y, w.ctypes.data_as(C.POINTER(C.c_float)),
+            k.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(itp.data_ptr()), C.c_void_p(s1d.data_ptr()),
+            C.c_void_p(demd.data_ptr()), mn.ctypes.data_as(C.POINTER(C.c_double)),
+            mx.ctypes.data_as(C.POINTER(C.c_double)), size, n_dates_ok, C.c_void_p(out.data_ptr()),
+            C.c_void_p(raw.data_ptr()) if want_raw else None, self._stream()), "ttc_process_subtiles")
+        return out, raw
+
+    def mosaic(self, windows, xy, size, rows, cols, want_float=False):
+        """windows [n, size, size] (numpy / cuda), xy [n, 2] int32 (folder_x, folder_y) -> (u8 [rows, cols], f32 | None)"""
+        t = self.torch
+        wd = self._dev(windows, t.float32)
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        u8 = t.empty((rows, cols), dtype=t.uint8, device=wd.device)
+        f32 = t.empty((rows, cols), dtype=t.float32, device=wd.device) if want_float else None
+        self._check(self.lib.ttc_mosaic(self._h, C.c_void_p(wd.data_ptr()), int(wd.shape[0]),
+                                        xy.ctypes.data_as(C.POINTER(C.c_int32)), size, rows, cols,
+                                        C.c_void_p(u8.data_ptr()), C.c_void_p(f32.data_ptr()) if want_float else None,
+                                        self._stream()), "ttc_mosaic")
+        return u8, f32
+
+    # -- 20 m -> 10 m ---------------------------------------------------------------------
+    def dsen2_forward(self, x, bilinear):
+        t = self.torch
+        xd, bd = self._dev(x, t.float32), self._dev(bilinear, t.float32)
+        n, H, W = (int(v) for v in xd.shape[:3])
+        out = t.empty((n, H, W, 6), dtype=t.float32, device=xd.device)
+        self._check(self.lib.ttc_dsen2_forward(self._h, C.c_void_p(xd.data_ptr()), C.c_void_p(bd.data_ptr()), n, H, W,
+                                               C.c_void_p(out.data_ptr()), self._stream()), "ttc_dsen2_forward")
+        return out
+
+    def superresolve_tile(self, s2d, quirks=True):
+        T, X, Y = (int(v) for v in s2d.shape[:3])
+        self._check(self.lib.ttc_superresolve_tile(self._h, C.c_void_p(s2d.data_ptr()), T, X, Y, int(quirks),
+                                                   self._stream()), "ttc_superresolve_tile")
+        return s2d
+
+    def upsample_20m(self, s2_10, s2_20):
+        t = self.torch
+        a, b = self._dev(s2_10, t.float32), self._dev(s2_20, t.float32)
+        T, h, w = (int(v) for v in b.shape[:3])
+        out = t.empty((T, 2 * h, 2 * w, 10), dtype=t.float32, device=a.device)
+        self._check(self.lib.ttc_upsample_20m(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), T, h, w,
+                                              C.c_void_p(out.data_ptr()), self._stream()), "ttc_upsample_20m")
         return out
 
     # -- debug ----------------------------------------------------------------------------

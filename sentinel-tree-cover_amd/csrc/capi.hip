@@ -3,9 +3,9 @@
 
 // tile.hip / mosaic.hip / dsen2.hip
 ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat,
-                                 const float* d_interp, const float* d_s1, const float* d_dem, const float* h_min,
-                                 const float* h_max, int size, int n_dates_ok, float* d_windows, float* d_windows_raw,
-                                 hipStream_t s);
+                                 const int32_t* h_keep, const float* d_interp, const float* d_s1, const float* d_dem,
+                                 const double* h_min, const double* h_max, int size, int n_dates_ok, float* d_windows,
+                                 float* d_windows_raw, hipStream_t s);
 ttc_status tile_missing_counts(ttc_ctx* c, const float* d_s2, int T, int X, int Y, int32_t* d_counts, hipStream_t s);
 ttc_status tile_fix_missing(ttc_ctx* c, float* d_s2, int T, int X, int Y, int do_nan, int do_zero_one, hipStream_t s);
 ttc_status mosaic_run(ttc_ctx* c, const float* d_windows, int n, const int32_t* h_xy, int size, int rows, int cols,
@@ -80,11 +80,11 @@ ttc_status ttc_forward_windows(ttc_ctx* c, const float* d_in, int32_t n, float* 
 }
 
 ttc_status ttc_process_subtiles(ttc_ctx* c, const float* d_s2, int32_t T, int32_t X, int32_t Y, const float* h_wmat,
-                                const float* d_interp, const float* d_s1, const float* d_dem, const float* h_min,
-                                const float* h_max, int32_t size, int32_t n_dates_ok, float* d_windows,
-                                float* d_windows_raw, void* stream) {
+                                const int32_t* h_keep, const float* d_interp, const float* d_s1, const float* d_dem,
+                                const double* h_min, const double* h_max, int32_t size, int32_t n_dates_ok,
+                                float* d_windows, float* d_windows_raw, void* stream) {
     if (!c) return TTC_ERR_ARG;
-    return tile_process_subtiles(c, d_s2, T, X, Y, h_wmat, d_interp, d_s1, d_dem, h_min, h_max, size, n_dates_ok,
+    return tile_process_subtiles(c, d_s2, T, X, Y, h_wmat, h_keep, d_interp, d_s1, d_dem, h_min, h_max, size, n_dates_ok,
                                  d_windows, d_windows_raw, static_cast<hipStream_t>(stream));
 }
 

@@ -1,0 +1,628 @@
+// Per-tile numeric core around the model: everything process_subtiles
+// (src/download_and_predict_job.py:1125-1483) does with numpy, as HBM-streaming HIP kernels.
+//
+//   k_tile_temporal   medians over dates (job.py:1152-1160), 0/1 repair with the running median
+//                     (job.py:1039-1047), spectral indices (src/preprocessing/indices.py), date
+//                     regrid + Whittaker + monthly mean as ONE 12 x T operator
+//                     (src/downloading/utils.py:176-347, src/preprocessing/whittaker_smoother.py),
+//                     quarterly medians (job.py:1274-1278)              -> planar [L][14][X][Y]
+//   k_tile_s1         Sentinel-1 median / quarterly medians (job.py:1174, :1277-1278)
+//   k_assemble        window cut + 7-px reflect pad at tile edges + 17-channel assembly +
+//                     normalisation (job.py:1355-1407, :316-325) straight into the model's padded
+//                     planar frame buffer
+//   k_bright_flags / k_bright_dist   identify_bright_bare_surfaces (job.py:1099-1122)
+//   k_post            clear-image statistics, no-image mask (job.py:1363-1366, :1451-1472), bright
+//                     attenuation and np.around(.,3) (job.py:1480-1482)
+//
+// Tile arrays arrive in the reference's layout ([T, X, Y, C] float32); intermediates are planar
+// [C][X][Y] so that every later access is coalesced along Y.
+#include "ttc_internal.h"
+
+namespace {
+
+constexpr int kMaxWin = 64;
+constexpr int kMaxT = 32;
+
+struct WinDesc {          // one model window, job.py:1295-1317 + tof_downloading.py:498-524
+    int sx, sy;           // start of the input slice in the tile
+    int lx, ly;           // slice length (size+7 at tile edges, size+14 inside)
+    int fx, fy;           // reflect-pad amount in FRONT of the slice (7 on the first row/col, else 0)
+    int qx;               // front pad the reference applies to the clear-count map on axis 0 (job.py:1395 quirk)
+    int ox, oy;           // output (folder) origin
+};
+struct WinTable { int n; WinDesc w[kMaxWin]; };
+struct WMat { float w[12 * kMaxT]; unsigned keep; int T; int Tk; };
+struct Norm { float lo[17], hi[17], mid[17], half[17]; };   // float32-rounded Python-float constants
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// slice-local coordinate (after the 7-px tile-edge reflect pad) -> tile coordinate
+__device__ __forceinline__ int win_to_tile(int l, int start, int len, int front) {
+    return start + reflect_idx(l - front, len);
+}
+
+// ---- float32 formulas evaluated exactly as numpy does (no FMA contraction) -------------------
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+__device__ float idx_evi(float b, float r, float n) {
+#pragma clang fp contract(off)
+    b = clip01(b); r = clip01(r); n = clip01(n);
+    const float den = ((n + (6.0f * r)) - (7.5f * b)) + 1.0f;
+    const float e = 2.5f * ((n - r) / den);
+    return fminf(fmaxf(e, -1.5f), 1.5f);
+}
+__device__ float idx_bi(float b2, float b4, float b8, float b11) {
+#pragma clang fp contract(off)
+    b2 = clip01(b2); b4 = clip01(b4); b8 = clip01(b8); b11 = clip01(b11);
+    const float a = b11 + b4, c = b8 + b2;
+    const float v = (a - c) / ((a + c) + 1e-5f);
+    return fminf(fmaxf(v, -1.0f), 1.0f);
+}
+__device__ float idx_msavi2(float r, float n) {
+#pragma clang fp contract(off)
+    r = clip01(r); n = clip01(n);
+    const float t = 2.0f * n + 1.0f;
+    float s = t * t - 8.0f * (n - r);
+    if (s < 0.0f) s = 0.0f;
+    const float v = (t - sqrtf(s)) / 2.0f;
+    return fminf(fmaxf(v, -1.0f), 1.0f);
+}
+__device__ float idx_grndvi(float g, float r, float n) {
+#pragma clang fp contract(off)
+    g = clip01(g); r = clip01(r); n = clip01(n);
+    const float gr = g + r;
+    return (n - gr) / ((n + gr) + 1e-5f);
+}
+
+// ---- median of the first `cnt` members of a TM-array whose non-members are +inf ---------------
+template <int TM>
+__device__ __forceinline__ void bitonic_sort(float (&a)[TM]) {
+#pragma unroll
+    for (int k = 2; k <= TM; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float lo = fminf(a[i], a[l]), hi = fmaxf(a[i], a[l]);
+                    if ((i & k) == 0) { a[i] = lo; a[l] = hi; } else { a[i] = hi; a[l] = lo; }
+                }
+            }
+        }
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ float median_masked(const float (&v)[TM], unsigned mask, int cnt) {
+    float a[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a[t] = ((mask >> t) & 1u) ? v[t] : INFINITY;
+    bitonic_sort<TM>(a);
+    const int i0 = (cnt - 1) >> 1, i1 = cnt >> 1;
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { if (t == i0) lo = a[t]; if (t == i1) hi = a[t]; }
+    return (lo + hi) * 0.5f;      // == numpy's mean of the two middle values in float32
+}
+
+__device__ __forceinline__ float med3(float a, float b, float c) {
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+}
+
+// deal_w_missing_px value repair (job.py:1039-1047): sequentially, each 0 (then each 1) of a kept
+// date becomes the median of the CURRENT kept series.
+template <int TM>
+__device__ __forceinline__ void fix_zero_one(float (&v)[TM], unsigned keep, int Tk) {
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const float bad = pass == 0 ? 0.0f : 1.0f;
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) any |= ((keep >> t) & 1u) && v[t] == bad;
+        if (!any) continue;
+#pragma unroll 1
+        for (int t = 0; t < TM; ++t) {              // rolled: one inlined sort per pass, taken rarely
+            float vt = 0.f;
+#pragma unroll
+            for (int u = 0; u < TM; ++u) if (u == t) vt = v[u];
+            if (((keep >> t) & 1u) && vt == bad) {
+                const float m = median_masked<TM>(v, keep, Tk);
+#pragma unroll
+                for (int u = 0; u < TM; ++u) if (u == t) v[u] = m;
+            }
+        }
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void smooth_store(const float (&v)[TM], const WMat& wm, int L, float* dst, long cstride_L) {
+    // dst -> sm[0][ch][p]; frame stride cstride_L
+    float m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) if (t < wm.T) acc = fmaf(wm.w[k * kMaxT + t], v[t], acc);
+        m[k] = acc;
+    }
+    if (L == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q * cstride_L] = med3(m[3 * q], m[3 * q + 1], m[3 * q + 2]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dst[k * cstride_L] = m[k];
+    }
+}
+
+template <int TM>
+__global__ __launch_bounds__(256) void k_tile_temporal(const float* __restrict__ s2, WMat wm, int npix, int L,
+                                                       float* __restrict__ sm, float* __restrict__ med) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int T = wm.T;
+    const unsigned all = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
+    const long fstride = 14L * npix;     // sm frame stride
+    const float2* px = reinterpret_cast<const float2*>(s2) + (long)p * 5;
+    const long tstride = (long)npix * 5;  // float2 per date
+
+    // ---- bands 0,1,2,3,8,9 (the index inputs + the last band) ----
+    float b0[TM], b1[TM], b2[TM], b3[TM], b8[TM], b9[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        if (t < T) {
+            const float2 q0 = px[t * tstride], q1 = px[t * tstride + 1], q4 = px[t * tstride + 4];
+            b0[t] = q0.x; b1[t] = q0.y; b2[t] = q1.x; b3[t] = q1.y; b8[t] = q4.x; b9[t] = q4.y;
+        } else { b0[t] = b1[t] = b2[t] = b3[t] = b8[t] = b9[t] = 0.f; }
+    }
+    // medians over ALL dates of the raw bands and of the raw per-date indices (job.py:1152-1160)
+    med[0L * npix + p] = median_masked<TM>(b0, all, T);
+    med[1L * npix + p] = median_masked<TM>(b1, all, T);
+    med[2L * npix + p] = median_masked<TM>(b2, all, T);
+    med[3L * npix + p] = median_masked<TM>(b3, all, T);
+    med[8L * npix + p] = median_masked<TM>(b8, all, T);
+    med[9L * npix + p] = median_masked<TM>(b9, all, T);
+    {
+        float ix[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_evi(b0[t], b2[t], b3[t]);
+        med[10L * npix + p] = median_masked<TM>(ix, all, T);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_bi(b0[t], b2[t], b3[t], b8[t]);
+        med[11L * npix + p] = median_masked<TM>(ix, all, T);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_msavi2(b2[t], b3[t]);
+        med[12L * npix + p] = median_masked<TM>(ix, all, T);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_grndvi(b1[t], b2[t], b3[t]);
+        med[13L * npix + p] = median_masked<TM>(ix, all, T);
+    }
+    // repair, then smooth bands and the indices of the REPAIRED bands (job.py:1067-1082)
+    fix_zero_one<TM>(b0, wm.keep, wm.Tk); fix_zero_one<TM>(b1, wm.keep, wm.Tk); fix_zero_one<TM>(b2, wm.keep, wm.Tk);
+    fix_zero_one<TM>(b3, wm.keep, wm.Tk); fix_zero_one<TM>(b8, wm.keep, wm.Tk); fix_zero_one<TM>(b9, wm.keep, wm.Tk);
+    smooth_store<TM>(b0, wm, L, sm + 0L * npix + p, fstride);
+    smooth_store<TM>(b1, wm, L, sm + 1L * npix + p, fstride);
+    smooth_store<TM>(b2, wm, L, sm + 2L * npix + p, fstride);
+    smooth_store<TM>(b3, wm, L, sm + 3L * npix + p, fstride);
+    smooth_store<TM>(b8, wm, L, sm + 8L * npix + p, fstride);
+    smooth_store<TM>(b9, wm, L, sm + 9L * npix + p, fstride);
+    {
+        float ix[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_evi(b0[t], b2[t], b3[t]);
+        smooth_store<TM>(ix, wm, L, sm + 10L * npix + p, fstride);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_bi(b0[t], b2[t], b3[t], b8[t]);
+        smooth_store<TM>(ix, wm, L, sm + 11L * npix + p, fstride);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_msavi2(b2[t], b3[t]);
+        smooth_store<TM>(ix, wm, L, sm + 12L * npix + p, fstride);
+#pragma unroll
+        for (int t = 0; t < TM; ++t) ix[t] = idx_grndvi(b1[t], b2[t], b3[t]);
+        smooth_store<TM>(ix, wm, L, sm + 13L * npix + p, fstride);
+    }
+    // ---- bands 4,5,6,7 ----
+    {
+        float c4[TM], c5[TM], c6[TM], c7[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if (t < T) {
+                const float2 q2 = px[t * tstride + 2], q3 = px[t * tstride + 3];
+                c4[t] = q2.x; c5[t] = q2.y; c6[t] = q3.x; c7[t] = q3.y;
+            } else { c4[t] = c5[t] = c6[t] = c7[t] = 0.f; }
+        }
+        med[4L * npix + p] = median_masked<TM>(c4, all, T);
+        med[5L * npix + p] = median_masked<TM>(c5, all, T);
+        med[6L * npix + p] = median_masked<TM>(c6, all, T);
+        med[7L * npix + p] = median_masked<TM>(c7, all, T);
+        fix_zero_one<TM>(c4, wm.keep, wm.Tk); fix_zero_one<TM>(c5, wm.keep, wm.Tk);
+        fix_zero_one<TM>(c6, wm.keep, wm.Tk); fix_zero_one<TM>(c7, wm.keep, wm.Tk);
+        smooth_store<TM>(c4, wm, L, sm + 4L * npix + p, fstride);
+        smooth_store<TM>(c5, wm, L, sm + 5L * npix + p, fstride);
+        smooth_store<TM>(c6, wm, L, sm + 6L * npix + p, fstride);
+        smooth_store<TM>(c7, wm, L, sm + 7L * npix + p, fstride);
+    }
+}
+
+// Sentinel-1: [12][X][Y][2] -> median over 12 (job.py:1174) and L-step series (job.py:1277-1278)
+__global__ void k_tile_s1(const float* __restrict__ s1, int npix, int L, float* __restrict__ s1q,
+                          float* __restrict__ s1med) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (t < 12) {
+            const float2 q = reinterpret_cast<const float2*>(s1)[(long)t * npix + p];
+            a[t] = q.x; b[t] = q.y;
+        } else { a[t] = b[t] = 0.f; }
+    }
+    s1med[p] = median_masked<16>(a, 0xfffu, 12);
+    s1med[npix + p] = median_masked<16>(b, 0xfffu, 12);
+    if (L == 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s1q[(2L * q) * npix + p] = med3(a[3 * q], a[3 * q + 1], a[3 * q + 2]);
+            s1q[(2L * q + 1) * npix + p] = med3(b[3 * q], b[3 * q + 1], b[3 * q + 2]);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) { s1q[(2L * t) * npix + p] = a[t]; s1q[(2L * t + 1) * npix + p] = b[t]; }
+    }
+}
+
+// window assembly straight into the padded planar frame buffer of the model
+__global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ sm, const float* __restrict__ med,
+                                                  const float* __restrict__ s1q, const float* __restrict__ s1med,
+                                                  const float* __restrict__ dem, WinTable wt, Norm nm, int X, int Y,
+                                                  int W, int L, float* __restrict__ frames) {
+#pragma clang fp contract(off)
+    const int Wp = W + 2, PP = Wp * Wp;
+    const int f = blockIdx.y, wi = blockIdx.z;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= PP) return;
+    const int py = p / Wp, pxx = p - py * Wp;
+    int lx = py - 1, ly = pxx - 1;
+    const bool border = lx < 0 || lx >= W || ly < 0 || ly >= W;
+    const bool last = (f == L);
+    float* dst = frames + (((long)wi * (L + 1) + f) * 17) * PP + p;
+    if (last && border) {
+        for (int c = 0; c < 17; ++c) dst[(long)c * PP] = 0.0f;
+        return;
+    }
+    lx = reflect_idx(lx, W); ly = reflect_idx(ly, W);        // ConvGRU reflect pad (model.py:250)
+    const WinDesc& w = wt.w[wi];
+    const int tx = win_to_tile(lx, w.sx, w.lx, w.fx), ty = win_to_tile(ly, w.sy, w.ly, w.fy);
+    const long npix = (long)X * Y, tp = (long)tx * Y + ty;
+    for (int c = 0; c < 17; ++c) {
+        float v;
+        if (c == 10) v = dem[tp];
+        else if (c == 11 || c == 12) v = last ? s1med[(c - 11) * npix + tp] : s1q[(2L * f + (c - 11)) * npix + tp];
+        else {
+            const int ch = c < 10 ? c : c - 3;               // 13..16 -> smoothed / median index 10..13
+            v = last ? med[ch * npix + tp] : sm[((long)f * 14 + ch) * npix + tp];
+        }
+        v = fminf(fmaxf(v, nm.lo[c]), nm.hi[c]);             // normalize_subtile, job.py:316-325 (float32)
+        dst[(long)c * PP] = (v - nm.mid[c]) / nm.half[c];
+    }
+}
+
+// identify_bright_bare_surfaces, part 1 (job.py:1110-1114): per window pixel, more than one frame
+// with NIR/(SWIR+0.01) < 0.9, mean(B,G,R) > 0.2 and EVI < 0.3 (on the un-normalised window)
+__global__ void k_bright_flags(const float* __restrict__ sm, const float* __restrict__ med, WinTable wt, int X, int Y,
+                               int W, int L, unsigned char* __restrict__ flags) {
+#pragma clang fp contract(off)
+    const int wi = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= W * W) return;
+    const int lx = p / W, ly = p - lx * W;
+    const WinDesc& w = wt.w[wi];
+    const int tx = win_to_tile(lx, w.sx, w.lx, w.fx), ty = win_to_tile(ly, w.sy, w.ly, w.fy);
+    const long npix = (long)X * Y, tp = (long)tx * Y + ty;
+    int cnt = 0;
+    for (int f = 0; f <= L; ++f) {
+        const float* src = f == L ? med : sm + (long)f * 14 * npix;
+        const float b = src[0 * npix + tp], g = src[1 * npix + tp], r = src[2 * npix + tp], n = src[3 * npix + tp],
+                    sw = src[8 * npix + tp];
+        const bool c1 = (n / (sw + 0.01f)) < 0.9f;
+        const bool c2 = (((b + g) + r) / 3.0f) > 0.2f;
+        const bool c3 = idx_evi(b, r, n) < 0.3f;
+        cnt += (c1 && c2 && c3) ? 1 : 0;
+    }
+    flags[(long)wi * W * W + p] = cnt > 1 ? 1 : 0;
+}
+
+// part 2 (job.py:1115-1122): erode(diamond 2) -> dilate(diamond 1) -> squared distance to the nearest
+// remaining bright pixel, capped at 9, on the [7:-7] crop.  One workgroup per window, bitmaps in LDS.
+__global__ __launch_bounds__(1024) void k_bright_dist(const unsigned char* __restrict__ flags, int W, int size,
+                                                      unsigned char* __restrict__ d2out) {
+    extern __shared__ unsigned char lds[];
+    unsigned char* A = lds; unsigned char* E = lds + W * W; unsigned char* B = lds + 2 * W * W;
+    const int wi = blockIdx.x, P = W * W;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) A[p] = flags[(long)wi * P + p];
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        const int x = p / W, y = p - x * W;
+        bool all = true;
+        for (int dx = -2; dx <= 2; ++dx)
+            for (int dy = -(2 - abs(dx)); dy <= 2 - abs(dx); ++dy) {
+                const int xx = x + dx, yy = y + dy;
+                if (xx >= 0 && xx < W && yy >= 0 && yy < W) all &= A[xx * W + yy] != 0;
+            }
+        E[p] = all;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        const int x = p / W, y = p - x * W;
+        bool any = E[p];
+        if (x > 0) any |= E[p - W] != 0;
+        if (x < W - 1) any |= E[p + W] != 0;
+        if (y > 0) any |= E[p - 1] != 0;
+        if (y < W - 1) any |= E[p + 1] != 0;
+        B[p] = any;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < size * size; o += blockDim.x) {
+        const int x = o / size + 7, y = o % size + 7;
+        int best = 9;
+        for (int dx = -3; dx <= 3; ++dx)
+            for (int dy = -3; dy <= 3; ++dy) {
+                const int xx = x + dx, yy = y + dy, d = dx * dx + dy * dy;
+                if (d < best && xx >= 0 && xx < W && yy >= 0 && yy < W && B[xx * W + yy]) best = d;
+            }
+        d2out[(long)wi * size * size + o] = (unsigned char)best;
+    }
+}
+
+// post-masks + rounding; one workgroup per window
+struct PostArgs {
+    const float* probs; const float* interp; const unsigned char* d2;
+    float* out; float* out_raw;
+    WinTable wt; unsigned keep; int T, X, Y, size, n_dates_ok;
+};
+
+__device__ __forceinline__ int clear_count(const PostArgs& a, int tx, int ty) {
+    int c = 0;
+    for (int t = 0; t < a.T; ++t)
+        if ((a.keep >> t) & 1u) c += a.interp[((long)t * a.X + tx) * a.Y + ty] < 0.33f ? 1 : 0;
+    return c;
+}
+
+__global__ __launch_bounds__(1024) void k_post(PostArgs a) {
+    extern __shared__ unsigned char lds[];
+    __shared__ int s_z, s_z1, s_blk[81];
+    const int wi = blockIdx.x, size = a.size, m = size + 2;
+    const WinDesc& w = a.wt.w[wi];
+    unsigned char* M0 = lds; unsigned char* M1 = lds + m * m;
+    if (threadIdx.x == 0) { s_z = 0; s_z1 = 0; }
+    if (threadIdx.x < 81) s_blk[threadIdx.x] = 0;
+    __syncthreads();
+    // window-level "no clear image" test: np.percentile(min_clear, 50) < 1 on the unpadded slice (job.py:1363-1366)
+    {
+        int z = 0, z1 = 0;
+        for (int i = threadIdx.x; i < w.lx * w.ly; i += blockDim.x) {
+            const int c = clear_count(a, w.sx + i / w.ly, w.sy + i % w.ly);
+            z += c == 0; z1 += c <= 1;
+        }
+        for (int k = 32; k >= 1; k >>= 1) { z += __shfl_xor(z, k); z1 += __shfl_xor(z1, k); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&s_z, z); atomicAdd(&s_z1, z1); }
+    }
+    const bool has_mask = (size == 158 || size == 142);
+    const int nb = size == 158 ? 4 : 9, bs = size == 158 ? 40 : 16;
+    if (has_mask) {
+        // clear map on the [6:-6] crop of the (size+14)^2 padded count map, with the reference's pad sides
+        for (int i = threadIdx.x; i < m * m; i += blockDim.x) {
+            const int lx = i / m + 6, ly = i % m + 6;
+            const int tx = win_to_tile(lx, w.sx, w.lx, w.lx == size + 7 ? w.qx : 0);
+            const int ty = win_to_tile(ly, w.sy, w.ly, w.fy);
+            M0[i] = clear_count(a, tx, ty) >= 1;
+        }
+        __syncthreads();
+        // 8-connected dilation x6 == 13x13 max, separable; twice (clear -> !dilated -> dilated again)
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = threadIdx.x; i < m * m; i += blockDim.x) {
+                const int x = i / m, y = i % m;
+                bool v = false;
+                for (int d = -6; d <= 6; ++d) { const int yy = y + d; if (yy >= 0 && yy < m) v |= M0[x * m + yy] != 0; }
+                M1[i] = v;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < m * m; i += blockDim.x) {
+                const int x = i / m, y = i % m;
+                bool v = false;
+                for (int d = -6; d <= 6; ++d) { const int xx = x + d; if (xx >= 0 && xx < m) v |= M1[xx * m + y] != 0; }
+                M0[i] = rep == 0 ? !v : v;
+            }
+            __syncthreads();
+        }
+        // block vote (job.py:1459-1463 / :1467-1471)
+        for (int i = threadIdx.x; i < m * m; i += blockDim.x)
+            if (M0[i]) atomicAdd(&s_blk[(i / m / bs) * nb + (i % m) / bs], 1);
+    }
+    __syncthreads();
+    const int n = w.lx * w.ly, k = n / 2;
+    bool no_images = (n & 1) ? (s_z >= k + 1) : (s_z >= k && s_z1 >= k + 1);
+    if (a.n_dates_ok < 2) no_images = true;
+    const int thr = size == 158 ? 400 : 192;
+    for (int o = threadIdx.x; o < size * size; o += blockDim.x) {
+        const long gi = (long)wi * size * size + o;
+        float p = no_images ? 255.0f : a.probs[gi];
+        if (a.out_raw) a.out_raw[gi] = p;
+        if (has_mask) {
+            const int li = o / size + 1, lj = o % size + 1;
+            if (s_blk[(li / bs) * nb + lj / bs] > thr) p = 255.0f;
+        }
+        // preds * bright_surface in float64, np.around(., 3), astype(float32)  (job.py:1480-1482)
+        const double blur = sqrt((double)a.d2[gi]) / 3.0;
+        a.out[gi] = (float)(rint(((double)p * blur) * 1000.0) / 1000.0);
+    }
+}
+
+// id_missing_px (src/preprocessing/interpolation.py:5-23): per date, pixels with more than one band == 0 or >= 1
+__global__ void k_missing_counts(const float* __restrict__ s2, int npix, int* __restrict__ counts) {
+    const int t = blockIdx.y;
+    int c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const float* v = s2 + ((long)t * npix + p) * 10;
+        int bad = 0;
+#pragma unroll
+        for (int b = 0; b < 10; ++b) bad += (v[b] == 0.0f) + (v[b] >= 1.0f);
+        c += bad > 1;
+    }
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[t], c);
+}
+
+// interpolate_na_vals (interpolation.py:42-56): any NaN in a pixel-band series makes bn.median NaN -> 0,
+// so every NaN of that series becomes 0;  optional 0/1 repair (job.py:1039-1047) in place.
+template <int TM>
+__global__ void k_fix_missing(float* __restrict__ s2, int T, int npix, int do_nan, int do_zero_one) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // pixel*10 + band
+    if (i >= (long)npix * 10) return;
+    float v[TM];
+    bool anynan = false;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { v[t] = t < T ? s2[(long)t * npix * 10 + i] : 0.f; anynan |= (t < T) && isnan(v[t]); }
+    bool changed = false;
+    if (do_nan && anynan) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) if (t < T && isnan(v[t])) v[t] = 0.0f;
+        changed = true;
+    }
+    if (do_zero_one) {
+        const unsigned all = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) any |= t < T && (v[t] == 0.0f || v[t] == 1.0f);
+        if (any) { fix_zero_one<TM>(v, all, T); changed = true; }
+    }
+    if (changed)
+#pragma unroll
+        for (int t = 0; t < TM; ++t) if (t < T) s2[(long)t * npix * 10 + i] = v[t];
+}
+
+// window table: job.py:1295-1317 + make_overlapping_windows (src/tof/tof_downloading.py:498-524)
+bool build_windows(int X, int Y, int size, WinTable& wt) {
+    const int n_rows = 6, diff = 7;
+    if (X < size + 2 * diff || Y < size + 2 * diff) return false;
+    const int gx = (X - size + n_rows - 2) / (n_rows - 1), gy = (Y - size + n_rows - 2) / (n_rows - 1);
+    std::vector<int> xs, ys;
+    for (int v = 0; v < X - size; v += gx) xs.push_back(v);
+    xs.push_back(X - size);
+    for (int v = 0; v < Y - size; v += gy) ys.push_back(v);
+    ys.push_back(Y - size);
+    if (xs.size() * ys.size() > kMaxWin) return false;
+    wt.n = 0;
+    for (size_t ix = 0; ix < xs.size(); ++ix)
+        for (size_t iy = 0; iy < ys.size(); ++iy) {
+            WinDesc d{};
+            const bool fx0 = ix == 0, fxl = ix + 1 == xs.size(), fy0 = iy == 0, fyl = iy + 1 == ys.size();
+            d.ox = xs[ix]; d.oy = ys[iy];
+            d.sx = fx0 ? 0 : xs[ix] - diff; d.sy = std::max(0, ys[iy] - diff);
+            d.lx = size + ((fx0 || fxl) ? diff : 2 * diff);
+            d.ly = size + ((fy0 || fyl) ? diff : 2 * diff);
+            d.fx = fx0 ? diff : 0; d.fy = fy0 ? diff : 0;
+            d.qx = fyl ? 0 : diff;          // job.py:1395 pads axis 0 with the (stale) y-axis amounts
+            wt.w[wt.n++] = d;
+        }
+    return true;
+}
+
+}  // namespace
+
+#define LAUNCH_T(kern, T, ...)                                                        \
+    do {                                                                              \
+        if ((T) <= 8) hipLaunchKernelGGL((kern<8>), __VA_ARGS__);                     \
+        else if ((T) <= 16) hipLaunchKernelGGL((kern<16>), __VA_ARGS__);              \
+        else hipLaunchKernelGGL((kern<32>), __VA_ARGS__);                             \
+    } while (0)
+
+ttc_status tile_missing_counts(ttc_ctx* c, const float* d_s2, int T, int X, int Y, int32_t* d_counts, hipStream_t s) {
+    if (!d_s2 || !d_counts || T < 1) return c->fail(TTC_ERR_ARG, "tile_missing_counts: bad argument");
+    TTC_HIP(c, hipMemsetAsync(d_counts, 0, sizeof(int32_t) * T, s));
+    KTimer kt(c, "missing_counts", s);
+    hipLaunchKernelGGL(k_missing_counts, dim3(128, T), dim3(256), 0, s, d_s2, X * Y, d_counts);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+ttc_status tile_fix_missing(ttc_ctx* c, float* d_s2, int T, int X, int Y, int do_nan, int do_zero_one, hipStream_t s) {
+    if (!d_s2 || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "tile_fix_missing: T must be in [1, 32]");
+    KTimer kt(c, "fix_missing", s);
+    const long n = (long)X * Y * 10;
+    LAUNCH_T(k_fix_missing, T, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_s2, T, X * Y, do_nan, do_zero_one);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat,
+                                 const int32_t* h_keep, const float* d_interp, const float* d_s1, const float* d_dem,
+                                 const double* h_min, const double* h_max, int size, int n_dates_ok, float* d_windows,
+                                 float* d_windows_raw, hipStream_t s) {
+    if (!d_s2 || !h_wmat || !d_interp || !d_s1 || !d_dem || !h_min || !h_max || !d_windows)
+        return c->fail(TTC_ERR_ARG, "process_subtiles: null argument");
+    if (T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "process_subtiles: T must be in [1, 32]");
+    const int W = c->cfg.win_in, L = c->cfg.length;
+    if (size != W - 14) return c->fail(TTC_ERR_ARG, "process_subtiles: size must equal win_in - 14");
+    if (L != 4 && L != 12) return c->fail(TTC_ERR_ARG, "process_subtiles: length must be 4 or 12");
+    WinTable wt{};
+    if (!build_windows(X, Y, size, wt)) return c->fail(TTC_ERR_ARG, "process_subtiles: tile too small for a 6x6 window grid");
+    if (wt.n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "process_subtiles: max_windows < windows per tile");
+    const long npix = (long)X * Y;
+    float* sm = static_cast<float*>(c->scratch_buf("sm", sizeof(float) * L * 14 * npix));
+    float* med = static_cast<float*>(c->scratch_buf("med", sizeof(float) * 14 * npix));
+    float* s1q = static_cast<float*>(c->scratch_buf("s1q", sizeof(float) * L * 2 * npix));
+    float* s1med = static_cast<float*>(c->scratch_buf("s1med", sizeof(float) * 2 * npix));
+    unsigned char* flags = static_cast<unsigned char*>(c->scratch_buf("flags", (size_t)wt.n * W * W));
+    unsigned char* d2 = static_cast<unsigned char*>(c->scratch_buf("d2", (size_t)wt.n * size * size));
+    float* probs = static_cast<float*>(c->scratch_buf("probs", sizeof(float) * wt.n * size * size));
+    if (!sm || !med || !s1q || !s1med || !flags || !d2 || !probs) return c->fail(TTC_ERR_NOMEM, "tile scratch");
+    c->named["tile_sm"] = {sm, (size_t)L * 14 * npix};
+    c->named["tile_med"] = {med, (size_t)14 * npix};
+    c->named["tile_s1q"] = {s1q, (size_t)L * 2 * npix};
+    c->named["tile_s1med"] = {s1med, (size_t)2 * npix};
+    c->named["tile_probs"] = {probs, (size_t)wt.n * size * size};
+
+    WMat wm{};
+    wm.T = T; wm.keep = 0; wm.Tk = 0;
+    for (int t = 0; t < T; ++t) if (!h_keep || h_keep[t]) { wm.keep |= 1u << t; wm.Tk++; }
+    for (int k = 0; k < 12; ++k)
+        for (int t = 0; t < T; ++t) wm.w[k * kMaxT + t] = ((wm.keep >> t) & 1u) ? h_wmat[k * T + t] : 0.0f;
+    Norm nm{};
+    for (int i = 0; i < 17; ++i) {
+        nm.lo[i] = (float)h_min[i]; nm.hi[i] = (float)h_max[i];
+        nm.mid[i] = (float)((h_max[i] + h_min[i]) / 2.0);
+        nm.half[i] = (float)((h_max[i] - h_min[i]) / 2.0);
+    }
+    const unsigned gp = (unsigned)((npix + 255) / 256);
+    { KTimer kt(c, "tile_temporal", s);
+      LAUNCH_T(k_tile_temporal, T, dim3(gp), dim3(256), 0, s, d_s2, wm, (int)npix, L, sm, med);
+      TTC_HIP(c, hipGetLastError()); }
+    { KTimer kt(c, "tile_s1", s);
+      hipLaunchKernelGGL(k_tile_s1, dim3(gp), dim3(256), 0, s, d_s1, (int)npix, L, s1q, s1med);
+      TTC_HIP(c, hipGetLastError()); }
+    const int PP = (W + 2) * (W + 2);
+    { KTimer kt(c, "assemble", s);
+      hipLaunchKernelGGL(k_assemble, dim3((PP + 255) / 256, L + 1, wt.n), dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm,
+                         X, Y, W, L, c->frames);
+      TTC_HIP(c, hipGetLastError()); }
+    { KTimer kt(c, "bright", s);
+      hipLaunchKernelGGL(k_bright_flags, dim3((W * W + 255) / 256, wt.n), dim3(256), 0, s, sm, med, wt, X, Y, W, L, flags);
+      TTC_HIP(c, hipGetLastError());
+      const size_t lds = 3 * (size_t)W * W;
+      static size_t cfg_lds = 0;
+      if (lds > cfg_lds) {
+          TTC_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bright_dist),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          cfg_lds = lds;
+      }
+      hipLaunchKernelGGL(k_bright_dist, dim3(wt.n), dim3(1024), lds, s, flags, W, size, d2);
+      TTC_HIP(c, hipGetLastError()); }
+    TTC_CHECK(model_forward_frames(c, wt.n, probs, s));
+    { KTimer kt(c, "post", s);
+      PostArgs pa{probs, d_interp, d2, d_windows, d_windows_raw, wt, wm.keep, T, X, Y, size, n_dates_ok};
+      const size_t lds = 2 * (size_t)(size + 2) * (size + 2);
+      hipLaunchKernelGGL(k_post, dim3(wt.n), dim3(1024), lds, s, pa);
+      TTC_HIP(c, hipGetLastError()); }
+    return TTC_OK;
+}

@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's per-tile functions (src/download_and_predict_job.py).
+
+Same names, argument meaning and numpy-in / numpy-out contracts as the reference, so the
+download / mosaic notebooks and the job script can swap them in; the
+arithmetic runs in libttc_hip.so on an MI355X.  There is no CPU fallback.
+
+  TTCSession.run(fetch, feed_dict)          <->  tf.Session.run on the frozen graphs (job.py:1788-1824)
+  normalize_subtile(subtile)                <->  job.py:316-325
+  predict_subtile(subtile, sess, op, size)  <->  job.py:328-369
+  process_subtiles(...)                     <->  job.py:1125-1483 (returns the windows instead of np.save)
+  load_mosaic_predictions(windows, depth=1) <->  job.py:1515-1641 (takes the windows instead of a folder)
+  predict_tile(...)                         ==   process_subtiles + load_mosaic_predictions in one call
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, temporal, weights as _weights
+
+SIZE = 172 - 14          # job.py:60
+LEN = 4                  # job.py:61 / args.length default (job.py:1715)
+
+# job.py:1829-1842
+min_all = [0.006576638437476157, 0.0162050812542916, 0.010040436408026246, 0.013351644159609368,
+           0.01965362020294499, 0.014229037918669413, 0.015289539940489814, 0.011993591210803388,
+           0.008239871824216068, 0.006546120393682765, 0.0, 0.0, 0.0, -0.1409399364817101,
+           -0.4973397113668104, -0.09731556326714398, -0.7193834232943873]
+max_all = [0.2691233691920348, 0.3740291447318227, 0.5171435111009385, 0.6027466239414053,
+           0.5650263218127718, 0.5747005416952773, 0.5933928435187305, 0.6034943160143434,
+           0.7472037842374304, 0.7000076295109483, 0.4, 0.948334642387533, 0.6729257769285485,
+           0.8177635298774327, 0.35768999002433816, 0.7545951919107605, 0.7602693339366691]
+
+# tensor names of the reference graphs (job.py:1794-1796, :1807-1824)
+PREDICT_INP = "predict/Placeholder:0"
+PREDICT_LENGTH = "predict/PlaceholderWithDefault:0"
+PREDICT_LOGITS = ("predict/conv2d/Sigmoid:0", "predict/conv2d_13/Sigmoid:0")
+SUPERRESOLVE_INP = "superresolve/Placeholder:0"
+SUPERRESOLVE_INP_BILINEAR = "superresolve/Placeholder_1:0"
+SUPERRESOLVE_LOGITS = "superresolve/Add_2:0"
+
+
+def _name(t):
+    return t if isinstance(t, str) else getattr(t, "name", str(t))
+
+
+class TTCSession:
+    """Stands in for the `tf.Session` objects of the job script.  One session serves both graphs:
+
+        sess.run(predict_logits, feed_dict={predict_inp: x[1,L+1,W,W,17], predict_length: [L]})
+        sess.run([superresolve_logits], feed_dict={superresolve_inp: a, superresolve_inp_bilinear: b})
+
+    Feeds are matched by tensor NAME (strings or objects with a `.name`), as Session.run does.
+    """
+
+    def __init__(self, weights=None, win_in=SIZE + 14, length=LEN, max_windows=36, device=0, zoneout=0.75,
+                 dsen2_weights="package"):
+        self.ctx = _lib.Context(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout)
+        self.win_in, self.length = win_in, length
+        if weights is not None:
+            self.ctx.load_weights(_weights.validate(dict(weights)))
+        if dsen2_weights == "package":
+            dsen2_weights = _weights.load_dsen2()
+        if dsen2_weights is not None:
+            self.ctx.load_dsen2_weights(dict(dsen2_weights))
+
+    # -- tf.Session.run look-alike ---------------------------------------------------------
+    def run(self, fetches, feed_dict=None):
+        feeds = {_name(k): v for k, v in (feed_dict or {}).items()}
+        single = not isinstance(fetches, (list, tuple))
+        outs = []
+        for f in ([fetches] if single else fetches):
+            n = _name(f)
+            if n in PREDICT_LOGITS or n.endswith("Sigmoid:0"):
+                x = np.asarray(feeds[PREDICT_INP], dtype=np.float32)
+                if PREDICT_LENGTH in feeds and int(np.asarray(feeds[PREDICT_LENGTH]).ravel()[0]) != self.length:
+                    raise ValueError("predict_length does not match the session's ConvGRU length")
+                outs.append(self.ctx.forward_windows(x).cpu().numpy()[..., np.newaxis])
+            elif n == SUPERRESOLVE_LOGITS or n.endswith("Add_2:0"):
+                outs.append(self.ctx.dsen2_forward(feeds[SUPERRESOLVE_INP], feeds[SUPERRESOLVE_INP_BILINEAR]).cpu().numpy())
+            else:
+                raise KeyError(f"TTCSession cannot fetch {n!r}")
+        return outs[0] if single else outs
+
+    def close(self):
+        self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------
+def normalize_subtile(subtile, ctx=None):
+    """job.py:316-325, in place on [..., 17].  (Pure float32 numpy: used only on the
+    predict_subtile drop-in path where the caller normalises itself; the per-tile path
+    normalises inside k_assemble.)"""
+    for band in range(subtile.shape[-1]):
+        mins, maxs = min_all[band], max_all[band]
+        subtile[..., band] = np.clip(subtile[..., band], mins, maxs)
+        subtile[..., band] = (subtile[..., band] - (maxs + mins) / 2) / ((maxs - mins) / 2)
+    return subtile
+
+
+def predict_subtile(subtile, sess, op=PREDICT_LOGITS[0], size=SIZE):
+    """job.py:328-369: [L+1, W, W, 17] normalised window -> [size, size] float32 (255 = all-zero input)."""
+    subtile = np.asarray(subtile)
+    if np.sum(subtile) != 0:
+        if not isinstance(subtile.flat[0], np.floating):
+            assert np.max(subtile) > 1
+            subtile = subtile / 65535.
+        batch_x = subtile[np.newaxis].astype(np.float32)
+        lengths = np.full((batch_x.shape[0]), sess.length)
+        preds = sess.run(op, feed_dict={PREDICT_INP: batch_x, PREDICT_LENGTH: lengths})
+        preds = preds.squeeze()
+        clip = (preds.shape[0] - size) // 2
+        if clip > 0:
+            preds = preds[clip:-clip, clip:-clip]
+        return np.float32(preds)
+    return np.full((size, size), 255)
+
+
+def window_grid(X, Y, size=SIZE, n_rows=6):
+    """Output-window origins (folder_x, folder_y) in iteration order (job.py:1295-1316)."""
+    gx = int(np.ceil((X - size) / (n_rows - 1)))
+    gy = int(np.ceil((Y - size) / (n_rows - 1)))
+    xs = list(range(0, X - size, gx)) + [X - size]
+    ys = list(range(0, Y - size, gy)) + [Y - size]
+    return [(x, y) for x in xs for y in ys]
+
+
+def _process_subtiles_device(s2, dates, interp, s1, dem, sess, size, want_raw=False):
+    """Device-resident core of process_subtiles: -> (windows cuda [n,size,size], raw | None, [(fx, fy)])."""
+    ctx, t = sess.ctx, sess.ctx.torch
+    s2d = ctx._dev(s2, t.float32)
+    if isinstance(s2, t.Tensor) and s2d.data_ptr() == s2.data_ptr():
+        s2d = s2d.clone()                                                  # the NaN repair below is in place
+    T, X, Y = int(s2d.shape[0]), int(s2d.shape[1]), int(s2d.shape[2])
+    dates = np.asarray(dates).copy()
+    ctx.tile_fix_missing(s2d, do_nan=True, do_zero_one=False)              # interpolate_na_vals, job.py:1149
+    counts = ctx.tile_missing_counts(s2d)                                   # id_missing_px(arr, 10), job.py:1032
+    keep = counts < (X ** 2) / 10
+    wmat = np.zeros((12, T), dtype=np.float32)
+    if keep.sum() > 0:
+        wmat[:, keep] = temporal.temporal_operator(dates[keep])
+    windows, raw = ctx.process_subtiles(s2d, wmat, keep.astype(np.int32), interp, s1, dem, min_all, max_all, size,
+                                        n_dates_ok=int(keep.sum()), want_raw=want_raw)
+    return windows, raw, window_grid(X, Y, size)
+
+
+def process_subtiles(x, y, s2, dates, interp, s1, dem, sess, bbx=None, size=SIZE, train_bbx=None,
+                     return_raw=False):
+    """job.py:1125-1483 numeric core on the GPU.
+
+    s2 [T,X,Y,10] f32, dates [T], interp [T,X,Y] f32, s1 [12,X,Y,2] f32, dem [X,Y] f32 (numpy or
+    cuda tensors), `sess` a TTCSession.  Returns {(folder_y, folder_x): preds[size,size] float32}
+    -- exactly the arrays the reference writes to processed/{folder_y}/{folder_x}.npy.
+    x, y, bbx, train_bbx are accepted for signature compatibility (file naming / GeoTIFF only).
+    """
+    windows, raw, grid = _process_subtiles_device(s2, dates, interp, s1, dem, sess, size, return_raw)
+    wins = windows.cpu().numpy()
+    out = {(fy, fx): wins[i] for i, (fx, fy) in enumerate(grid)}
+    if return_raw:
+        rw = raw.cpu().numpy()
+        return out, {(fy, fx): rw[i] for i, (fx, fy) in enumerate(grid)}
+    return out
+
+
+def load_mosaic_predictions(windows, depth=1, sess=None, size=SIZE, return_float=False):
+    """job.py:1515-1641 for depth == 1, from the dict returned by process_subtiles.
+    Returns uint8 [max_y + size, max_x + size] -- transposed like the reference (job.py:1578)."""
+    if depth != 1:
+        raise NotImplementedError("feature mosaics (depth > 1) are outside the built path (SURVEY.md 8f-4)")
+    if sess is None:
+        raise ValueError("load_mosaic_predictions needs the TTCSession whose GPU holds the windows")
+    keys = sorted(windows.keys())
+    stack = np.stack([np.asarray(windows[k], dtype=np.float32) for k in keys])
+    xy = np.array([[fx, fy] for (fy, fx) in keys], dtype=np.int32)
+    rows = int(max(k[0] for k in keys) + size)
+    cols = int(max(k[1] for k in keys) + size)
+    u8, f32 = sess.ctx.mosaic(stack, xy, size, rows, cols, want_float=return_float)
+    if return_float:
+        return u8.cpu().numpy(), f32.cpu().numpy()
+    return u8.cpu().numpy()
+
+
+def predict_tile(s2, dates, interp, s1, dem, sess, size=SIZE, to_host=True):
+    """One call, device-resident between the stages: cloud-free tile stack ->
+    (float32 percent raster with NaN no-data, uint8 product), both [Y, X] like load_mosaic_predictions."""
+    windows, _, grid = _process_subtiles_device(s2, dates, interp, s1, dem, sess, size)
+    xy = np.array(grid, dtype=np.int32)
+    rows, cols = int(xy[:, 1].max() + size), int(xy[:, 0].max() + size)
+    u8, f32 = sess.ctx.mosaic(windows, xy, size, rows, cols, want_float=True)
+    if to_host:
+        return f32.cpu().numpy(), u8.cpu().numpy()
+    return f32, u8
