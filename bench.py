@@ -1,0 +1,166 @@
+"""Benchmark of the MI355X tree-cover inference hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--win 172] [--length 4] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the built hot path over one synthetic 618x618 tile that is already
+resident in HBM (config.stages lists exactly what runs inside the timed region):
+
+    bilinear 20 m->10 m  ->  DSen2 super-resolution (31 windows x T dates, reference tiling)
+    ->  repair / indices / 12xT temporal operator / medians  ->  36 overlapping windows
+    ->  bi-ConvGRU + U-Net forward (fp32 MFMA)  ->  post-masks  ->  Gaussian overlap mosaic
+    [-> RCCL gather of the uint8 raster to rank 0 when N > 1]
+
+Tiles shard embarrassingly (one process per GPU, static assignment, weak scaling); the only
+collective is the gather of finished rasters.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TILE = 618
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3        # v_mfma_f32_32x32x2_f32, dense
+
+
+def conv_gates_flops(W, n_windows):
+    """algorithmic FLOPs of ONE conv_gates launch: 3x3, 49 -> 64, W^2 px, both directions"""
+    return 2.0 * 9 * 49 * 64 * W * W * (2 * n_windows)
+
+
+def cpu_baseline(args, tile):
+    """The oracle (CPU restatement of the reference; kind = "port") on ONE whole tile, host cores."""
+    import torch
+    from oracle import restate_model as M, restate_numpy as O
+    from ttc import weights as Wt
+    s2_10, s2_20, dates, interp, s1, dem = tile
+    w = Wt.synth_weights(0)
+    net = M.TreeCoverNet(w, dtype=torch.float32)
+    ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    size = args.win - 14
+    t0 = time.time()
+    s2 = O.upsample_20m(s2_10, s2_20)
+    s2 = O.superresolve_large_tile(s2, ds)
+    wins = O.process_subtiles(s2, dates.copy(), interp.copy(), s1.copy(), dem.copy(),
+                              lambda x: O.predict_subtile(x, net, size), size=size, length=args.length)
+    O.mosaic_predictions(wins, size=size)
+    dt = time.time() - t0
+    return {"value": TILE * TILE / dt, "unit": "px/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"1 tile (618x618, T={args.dates}) through oracle/: numpy preprocessing + torch-CPU DSen2 and "
+                      f"ConvGRU/U-Net (36 windows) + mosaic, {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--win", type=int, default=172, help="model input window (172 = reference default; 168 also legal)")
+    ap.add_argument("--length", type=int, default=4, help="ConvGRU steps (reference default 4; 12 = monthly)")
+    ap.add_argument("--dates", type=int, default=12, help="raw acquisition dates T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ttc  # noqa: F401
+    from ttc import job, synth, weights as Wt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+
+    size = args.win - 14
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=args.win, length=args.length, max_windows=36, device=local)
+    ctx = sess.ctx
+
+    # synthetic tile, seed 1234 + tile_id (tile_id = rank): 10 m bands, 20 m bands, interp, S1, DEM -> HBM
+    s2, dates, interp, s1, dem = synth.synth_tile(seed=1234 + rank, T=args.dates, H=TILE, W=TILE, cloud_frac=0.1)
+    s2_10 = np.ascontiguousarray(s2[..., :4])
+    s2_20 = np.ascontiguousarray(s2[:, ::2, ::2, 4:])
+    host_tile = (s2_10, s2_20, dates, interp, s1, dem)
+    dev = f"cuda:{local}"
+    d10, d20 = torch.from_numpy(s2_10).to(dev), torch.from_numpy(s2_20).to(dev)
+    dint, ds1, ddem = torch.from_numpy(interp).to(dev), torch.from_numpy(s1).to(dev), torch.from_numpy(dem).to(dev)
+    gather_buf = [torch.empty((TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        s2d = ctx.upsample_20m(d10, d20)                              # job.py:734-782
+        ctx.superresolve_tile(s2d, quirks=True)                       # job.py:95-147
+        f32, u8 = job.predict_tile(s2d, dates, dint, ds1, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
+        if world > 1:
+            dist.gather(u8, gather_buf, dst=0)                        # final-mosaic gather (RCCL over xGMI)
+        return u8
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing(2)                     # HIP events around the conv-engine launches only (on the launch stream)
+    ctx.kernel_ms(None)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    gates_ms, gates_n = ctx.kernel_ms("conv_gates")
+    ctx.timing(0)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        ach = conv_gates_flops(args.win, 36) / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
+        out = {
+            "metric": "10m pixels/s tree-cover inference", "value": world * TILE * TILE * args.steps / dt, "unit": "px/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"one 618x618 tile per GPU per step, T={args.dates} dates, 36 overlapping {args.win}x{args.win} "
+                            f"windows (out {size}), L={args.length}, fp32 (BASELINE.json configs[1])",
+                "stages": ["bilinear_20m", "dsen2_superresolve(31 windows x T)", "temporal_operator+indices+medians",
+                           "window_assembly+normalise", "biConvGRU+UNet forward", "post_masks", "gaussian_mosaic"]
+                          + (["rccl_gather_u8"] if world > 1 else []),
+                "not_in_timed_region": ["cloud gap-fill (remove_cloud_and_shadows): not built yet",
+                                        "H2D of the raw tile (inputs resident in HBM)"],
+                "weights": "synthetic seed 0 (ConvGRU/U-Net weights absent from the reference checkout); DSen2 real",
+                "tiles_per_step_per_gpu": 1, "win_in": args.win, "length": args.length, "dates": args.dates,
+            },
+            "roofline": {
+                "kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
+                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None,
+                "launch_ms": gates_ms, "launches_timed": gates_n,
+                "flops_per_launch": conv_gates_flops(args.win, 36),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, host_tile)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

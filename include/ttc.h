@@ -155,8 +155,9 @@ ttc_status ttc_upsample_20m(ttc_ctx* ctx, const float* d_s2_10, const float* d_s
 ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t cap_floats,
                            size_t* n_floats);
 /* average device time (ms) of the named kernel family over the launches since the last
- * reset, measured with HIP events on the launch stream; name == NULL resets.  Only
- * collected after ttc_debug_timing(ctx, 1). */
+ * reset, measured with HIP events on the launch stream; name == NULL resets.  Collected after
+ * ttc_debug_timing(ctx, level): 0 = off, 1 = every kernel family, 2 = conv-engine launches only
+ * (cheap enough to leave on inside a timed benchmark region). */
 ttc_status ttc_debug_timing(ttc_ctx* ctx, int32_t enable);
 ttc_status ttc_debug_kernel_ms(ttc_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 

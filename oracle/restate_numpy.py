@@ -529,19 +529,29 @@ def resize_bilinear(img, shape):
 
 
 def upsample_20m(s2_10, s2_20):
-    """job.py:734-782 for even-sized 20 m grids: [T,2h,2w,4] + [T,h,w,6] -> [T,2h,2w,10]."""
+    """job.py:734-782: [T,2h,2w,4] + [T,h,w,6] -> [T,2h,2w,10].  The 40 m bands (20 m indices 4, 5)
+    are 2x2-averaged first; on odd 20 m grids (309 for a 618 tile!) the first row / column is set
+    aside and written back nearest-replicated (:760-782)."""
     T, w, h = s2_10.shape[0], s2_20.shape[1] * 2, s2_20.shape[2] * 2
     out = np.zeros((T, w, h, 10), np.float32)
     out[..., :4] = s2_10
     for band in range(4):
         for t in range(T):
             out[t, ..., band + 4] = resize_bilinear(s2_20[t, ..., band], (w, h))
+
+    def mean4(m):
+        return np.mean(m.reshape(m.shape[0] // 2, 2, m.shape[1] // 2, 2), axis=(1, 3))
+
     for band in range(4, 6):
         for t in range(T):
             mid = s2_20[t, ..., band]
-            assert mid.shape[0] % 2 == 0 and mid.shape[1] % 2 == 0, "odd 40 m grids: see job.py:760-782"
-            mid = np.mean(mid.reshape(mid.shape[0] // 2, 2, mid.shape[1] // 2, 2), axis=(1, 3))
-            out[t, ..., band + 4] = resize_bilinear(mid, (w, h))
+            ox, oy = mid.shape[0] % 2, mid.shape[1] % 2
+            row0, col0 = mid[0, :], mid[:, 0]
+            out[t, ox:, oy:, band + 4] = resize_bilinear(mean4(mid[ox:, oy:]), (w - ox, h - oy))
+            if ox:
+                out[t, 0, :, band + 4] = row0.repeat(2)
+            if oy:
+                out[t, :, 0, band + 4] = col0.repeat(2)
     return out
 
 

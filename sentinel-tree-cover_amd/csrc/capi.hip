@@ -141,7 +141,7 @@ ttc_status ttc_debug_timing(ttc_ctx* c, int32_t enable) {
     if (!c) return TTC_ERR_ARG;
     TTC_HIP(c, hipDeviceSynchronize());
     flush_timing(c);
-    c->timing.enabled = enable != 0;
+    c->timing.level = enable;
     return TTC_OK;
 }
 

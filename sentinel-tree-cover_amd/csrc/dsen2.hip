@@ -115,14 +115,16 @@ __global__ void k_upsample_20m(const float* __restrict__ s10, const float* __res
     for (int c = 0; c < 4; ++c) dst[4 + c] = (float)bil_sample(b + c, (long)w * 6, 6, h, w, sy, sx);
 }
 
-// 40 m bands (indices 4, 5 of the 20 m stack): 2x2 mean (float32) then bilinear x4 (job.py:754-759)
-__global__ void k_mean2x2(const float* __restrict__ s20, int h, int w, float* __restrict__ m) {
+// 40 m bands (indices 4, 5 of the 20 m stack): 2x2 mean (float32) then bilinear (job.py:754-782).  On odd
+// 20 m grids (309 for a 618 tile) the reference sets the first row / column aside (oy / ox = 1), averages
+// the rest, resizes it to (2h - oy, 2w - ox) and writes the set-aside row / column back nearest-replicated.
+__global__ void k_mean2x2(const float* __restrict__ s20, int h, int w, int oy, int ox, float* __restrict__ m) {
 #pragma clang fp contract(off)
-    const int t = blockIdx.y, hh = h / 2, ww = w / 2;
+    const int t = blockIdx.y, hh = (h - oy) / 2, ww = (w - ox) / 2;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hh * ww) return;
     const int y = p / ww, x = p % ww;
-    const float* b = s20 + ((long)t * h * w + (long)(2 * y) * w + 2 * x) * 6;
+    const float* b = s20 + ((long)t * h * w + (long)(2 * y + oy) * w + 2 * x + ox) * 6;
     for (int c = 0; c < 2; ++c) {
         const float v00 = b[4 + c], v01 = b[6 + 4 + c], v10 = b[(long)w * 6 + 4 + c], v11 = b[(long)w * 6 + 6 + 4 + c];
         // np.mean over axes (1, 3) of the [h/2, 2, w/2, 2] view: float32 accumulate, divide by 4
@@ -130,15 +132,24 @@ __global__ void k_mean2x2(const float* __restrict__ s20, int h, int w, float* __
     }
 }
 
-__global__ void k_upsample_40m(const float* __restrict__ m, int h, int w, float* __restrict__ out) {
-    const int t = blockIdx.y, H = 2 * h, W = 2 * w, hh = h / 2, ww = w / 2;
+__global__ void k_upsample_40m(const float* __restrict__ m, const float* __restrict__ s20, int h, int w, int oy, int ox,
+                               float* __restrict__ out) {
+    const int t = blockIdx.y, H = 2 * h, W = 2 * w, hh = (h - oy) / 2, ww = (w - ox) / 2;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W) return;
     const int y = p / W, x = p % W;
-    const double sy = (y + 0.5) * 0.25 - 0.5, sx = (x + 0.5) * 0.25 - 0.5;
     float* dst = out + ((long)t * H * W + p) * 10;
-    for (int c = 0; c < 2; ++c)
-        dst[8 + c] = (float)bil_sample(m + ((long)t * 2 + c) * hh * ww, ww, 1, hh, ww, sy, sx);
+    const float* b = s20 + (long)t * h * w * 6;
+    for (int c = 0; c < 2; ++c) {
+        float v;
+        if (ox && x == 0) v = b[((long)(y / 2) * w) * 6 + 4 + c];            // first column, written last (job.py:769)
+        else if (oy && y == 0) v = b[(long)(x / 2) * 6 + 4 + c];             // first row
+        else {
+            const double sy = (y - oy + 0.5) * ((double)hh / (H - oy)) - 0.5, sx = (x - ox + 0.5) * ((double)ww / (W - ox)) - 0.5;
+            v = (float)bil_sample(m + ((long)t * 2 + c) * hh * ww, ww, 1, hh, ww, sy, sx);
+        }
+        dst[8 + c] = v;
+    }
 }
 
 const char* kDsNames[6] = {"in_conv", "01_conv", "02_conv", "11_conv", "12_conv", "out_conv"};
@@ -293,14 +304,14 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
 
 ttc_status upsample_20m(ttc_ctx* c, const float* d10, const float* d20, int T, int h, int w, float* d_out, hipStream_t s) {
     if (!d10 || !d20 || !d_out || T < 1) return c->fail(TTC_ERR_ARG, "upsample_20m: bad argument");
-    if ((h % 2) || (w % 2)) return c->fail(TTC_ERR_ARG, "upsample_20m: odd 20 m grids (job.py:760-782) are not built");
-    float* m = static_cast<float*>(c->scratch_buf("up_mean", sizeof(float) * (size_t)T * 2 * (h / 2) * (w / 2)));
+    const int oy = h % 2, ox = w % 2, hh = (h - oy) / 2, ww = (w - ox) / 2;
+    float* m = static_cast<float*>(c->scratch_buf("up_mean", sizeof(float) * (size_t)T * 2 * hh * ww));
     if (!m) return c->fail(TTC_ERR_NOMEM, "upsample scratch");
     KTimer kt(c, "upsample_20m", s);
     const int P = 4 * h * w;
     hipLaunchKernelGGL(k_upsample_20m, dim3((P + 255) / 256, T), dim3(256), 0, s, d10, d20, h, w, d_out);
-    hipLaunchKernelGGL(k_mean2x2, dim3(((h / 2) * (w / 2) + 255) / 256, T), dim3(256), 0, s, d20, h, w, m);
-    hipLaunchKernelGGL(k_upsample_40m, dim3((P + 255) / 256, T), dim3(256), 0, s, m, h, w, d_out);
+    hipLaunchKernelGGL(k_mean2x2, dim3((hh * ww + 255) / 256, T), dim3(256), 0, s, d20, h, w, oy, ox, m);
+    hipLaunchKernelGGL(k_upsample_40m, dim3((P + 255) / 256, T), dim3(256), 0, s, m, d20, h, w, oy, ox, d_out);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }

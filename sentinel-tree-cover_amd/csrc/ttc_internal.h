@@ -83,7 +83,7 @@ hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, 
 
 // ----------------------------------------------------------------------------- context
 struct Timing {
-    bool enabled = false;
+    int level = 0;
     struct Rec { double ms = 0; int64_t n = 0; };
     std::map<std::string, Rec> recs;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -136,7 +136,10 @@ ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n);
 struct KTimer {
     ttc_ctx* c; const char* name; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     KTimer(ttc_ctx* c_, const char* n_, hipStream_t s_) : c(c_), name(n_), s(s_) {
-        if (c->timing.enabled) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+        // level 1: every kernel family; level 2: only the conv engine launches (names "conv_*", "dsen2_conv")
+        if (c->timing.level == 1 || (c->timing.level == 2 && strstr(name, "conv") != nullptr)) {
+            hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s);
+        }
     }
     ~KTimer() {
         if (a) { hipEventRecord(b, s); c->timing.pending.push_back({name, {a, b}}); }

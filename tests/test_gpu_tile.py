@@ -183,11 +183,13 @@ def test_dsen2_and_superresolve_tile():
     assert not np.array_equal(d2.cpu().numpy()[:, :508, 550:, 4:], arr[:, :508, 550:, 4:])
 
 
-def test_upsample_20m():
+@pytest.mark.parametrize("h,w", [(20, 18), (21, 19), (21, 18), (20, 19)])
+def test_upsample_20m(h, w):
+    """even grids and the three odd-grid branches of job.py:760-782 (309 x 309 is the production case)"""
     from oracle import restate_numpy as O
     sess, _ = _session(172, 4)
     rng = np.random.default_rng(8)
-    s10 = rng.random((2, 40, 36, 4)).astype(np.float32)
-    s20 = rng.random((2, 20, 18, 6)).astype(np.float32)
+    s10 = rng.random((2, 2 * h, 2 * w, 4)).astype(np.float32)
+    s20 = rng.random((2, h, w, 6)).astype(np.float32)
     got = sess.ctx.upsample_20m(s10, s20).cpu().numpy()
-    _report("bilinear 20m->10m", got, O.upsample_20m(s10, s20), 1e-6)
+    _report(f"bilinear 20m->10m {h}x{w}", got, O.upsample_20m(s10, s20), 1e-6)
