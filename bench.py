@@ -70,7 +70,7 @@ def main():
 
     import torch
     import ttc  # noqa: F401
-    from ttc import job, synth, weights as Wt
+    from ttc import job, shard, synth, weights as Wt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,7 +103,7 @@ def main():
         ctx.superresolve_tile(s2d, quirks=True)                       # job.py:95-147
         f32, u8 = job.predict_tile(s2d, dates, dint, ds1, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
         if world > 1:
-            dist.gather(u8, gather_buf, dst=0)                        # final-mosaic gather (RCCL over xGMI)
+            shard.gather_rasters(u8, rank, world, 0, gather_buf)     # final-mosaic gather (RCCL over xGMI)
         return u8
 
     def sync():
@@ -123,10 +123,7 @@ def main():
     dt = time.perf_counter() - t0
     gates_ms, gates_n = ctx.kernel_ms("conv_gates")
     ctx.timing(0)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(dt, dev, world)
 
     if rank == 0:
         ms = dt / args.steps * 1e3

@@ -65,26 +65,82 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchun
 #pragma unroll
     for (int t = 0; t < 9; ++t) toff[t] = (t / 3) * Wp + (t % 3);
 
+    // staging geometry: wave w stages input planes lc = w, w+4, ... of the chunk; a lane moves up to NJ float4
+    // of a plane row.  All global loads of a stage are issued before the first LDS write so that a stage costs
+    // ONE memory round trip (a rolled scalar copy loop costs one per element and was 60 % of this kernel).
+    constexpr int RCI = (CK + kWaves - 1) / kWaves;
+    constexpr int NJ = 4;                          // 4 * 64 float4 = 1024 floats >= BQ + 2*Wp + 2 up to Wp = 255
+    constexpr int NWV = (9 * CK * BN / 4 + kThreads - 1) / kThreads;
+    const int TL4 = TLp >> 2;
+    const bool vec_ok = ((plane & 3) == 0) && (Wp <= 255);
+
     for (int c = 0; c < nchunk; ++c) {
-        __syncthreads();
-        // ---- stage inputs: CK planes x TL contiguous floats (coalesced) ----
-        for (int lc = 0; lc < CK; ++lc) {
-            const int ci = c * CK + lc;
-            const float* src = nullptr;
-            if (ci < C0) src = seg0 + (long)ci * plane;
-            else if (ci < a.Cin) src = seg1 + (long)(ci - C0) * plane;
-            float* dst = in_tile + lc * TLp;
-            if (src) {
+        if (vec_ok) {
+            float4 iv[RCI][NJ];
+            float4 wv[NWV];
+#pragma unroll
+            for (int r = 0; r < RCI; ++r) {
+                const int lc = wave + r * kWaves;
+                const int ci = c * CK + lc;
+                const float* src = nullptr;
+                if (lc < CK) {
+                    if (ci < C0) src = seg0 + (long)ci * plane;
+                    else if (ci < a.Cin) src = seg1 + (long)(ci - C0) * plane;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int i4 = lane + 64 * j;
+                    const int q = q0 + 4 * i4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (src && i4 < TL4) {
+                        if (q + 3 < plane) v = *reinterpret_cast<const float4*>(src + q);
+                        else {
+                            if (q < plane) v.x = src[q];
+                            if (q + 1 < plane) v.y = src[q + 1];
+                            if (q + 2 < plane) v.z = src[q + 2];
+                        }
+                    }
+                    iv[r][j] = v;
+                }
+            }
+            const float4* ws = reinterpret_cast<const float4*>(wsrc + (long)c * (9 * CK * BN));
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) {
+                const int i = tid + k * kThreads;
+                wv[k] = i < 9 * CK * BN / 4 ? ws[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __syncthreads();                       // previous chunk's MFMA reads are done
+#pragma unroll
+            for (int r = 0; r < RCI; ++r) {
+                const int lc = wave + r * kWaves;
+                if (lc < CK) {
+                    float4* dst = reinterpret_cast<float4*>(in_tile + lc * TLp);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int i4 = lane + 64 * j;
+                        if (i4 < TL4) dst[i4] = iv[r][j];
+                    }
+                }
+            }
+            float4* wd = reinterpret_cast<float4*>(w_tile);
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) {
+                const int i = tid + k * kThreads;
+                if (i < 9 * CK * BN / 4) wd[i] = wv[k];
+            }
+        } else {
+            __syncthreads();
+            for (int lc = 0; lc < CK; ++lc) {      // generic (unaligned plane) fallback
+                const int ci = c * CK + lc;
+                const float* src = nullptr;
+                if (ci < C0) src = seg0 + (long)ci * plane;
+                else if (ci < a.Cin) src = seg1 + (long)(ci - C0) * plane;
+                float* dst = in_tile + lc * TLp;
                 for (int i = tid; i < TL; i += kThreads) {
                     const int q = q0 + i;
-                    dst[i] = q < plane ? src[q] : 0.0f;
+                    dst[i] = (src && q < plane) ? src[q] : 0.0f;
                 }
-            } else {
-                for (int i = tid; i < TL; i += kThreads) dst[i] = 0.0f;
             }
-        }
-        // ---- stage weights: 9*CK*BN contiguous floats ----
-        {
             const float4* ws = reinterpret_cast<const float4*>(wsrc + (long)c * (9 * CK * BN));
             float4* wd = reinterpret_cast<float4*>(w_tile);
             for (int i = tid; i < 9 * CK * BN / 4; i += kThreads) wd[i] = ws[i];

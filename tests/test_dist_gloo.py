@@ -1,0 +1,60 @@
+"""CPU, world_size 2, gloo: the N > 1 path of bench.py (static tile sharding + raster gather + max-over-ranks)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ttc  # noqa: F401
+from ttc import shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = shard.tiles_for_rank(7, rank, world)
+        last = None
+        for tile_id in mine[:7 // world]:      # every rank runs the same number of collective steps (as bench.py does)
+            raster = torch.full((6, 5), tile_id, dtype=torch.uint8)
+            got = shard.gather_rasters(raster, rank, world)
+            if rank == 0:
+                last = [int(g[0, 0]) for g in got]
+        t = shard.max_over_ranks(1.0 + rank, "cpu", world)
+        out.put((rank, mine, last, t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_gather_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, tiles0, last0, t0), (r1, tiles1, last1, t1) = res
+    assert tiles0 == [0, 2, 4, 6] and tiles1 == [1, 3, 5]
+    assert sorted(tiles0 + tiles1) == list(range(7))
+    assert last0 == [4, 5]                   # third joint step: rank 0 holds tile 4, rank 1 tile 5
+    assert t0 == t1 == 2.0                   # max over ranks
+
+
+def test_single_rank_is_passthrough():
+    r = torch.zeros((3, 3), dtype=torch.uint8)
+    assert shard.gather_rasters(r, 0, 1)[0] is r
+    assert shard.tiles_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert shard.max_over_ranks(0.5, "cpu", 1) == 0.5
