@@ -96,3 +96,31 @@ def synth_bright_window(seed=21, L=4, W=172):
         img[:, a:b, c:d, :3] = 0.3      # bright visible
         img[:, a:b, c:d, 3] = 0.31      # NIR/SWIR < 0.9
     return img
+
+
+def synth_gapfill_scene(seed=31, T=6, H=224, W=224):
+    """Cloudy Sentinel-2 stack for the gap-fill stage (cloud_removal.py:888-973 input):
+    tiles [T,H,W,10] f32 with per-date gain/offset drift, a lake (NDWI > 0), bright cloud blobs and
+    darker shadow blobs; probs [T,H,W] f32 binary cloud+shadow mask; pfcps [H,W] bool (none)."""
+    s2, dates, _, _, _ = synth_tile(seed=seed, T=T, H=H, W=W)
+    rng = np.random.default_rng(seed + 1)
+    gain = (1.0 + 0.15 * (rng.random((T, 1, 1, 10), dtype=np.float32) - 0.5)).astype(np.float32)
+    off = (0.02 * (rng.random((T, 1, 1, 10), dtype=np.float32) - 0.5)).astype(np.float32)
+    tiles = (s2 * gain + off).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    lake = ((yy - 0.7 * H) / (0.12 * H)) ** 2 + ((xx - 0.25 * W) / (0.18 * W)) ** 2 < 1.0
+    tiles[:, lake, 3] = 0.03                     # NIR dark over water -> NDWI > 0
+    tiles[:, lake, 1] = 0.08
+    probs = np.zeros((T, H, W), dtype=np.float32)
+    for t in range(T):
+        nblob = [2, 0, 1, 3, 1, 2][t % 6]
+        for b in range(nblob):
+            cy, cx = rng.integers(0, H), rng.integers(0, W)
+            ry, rx = rng.integers(H // 12, H // 4), rng.integers(W // 12, W // 4)
+            m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
+            probs[t][m] = 1.0
+            tiles[t][m] += (0.35 if b % 2 == 0 else -0.04)          # cloud / shadow
+    probs[3, : (6 * H) // 10, :] = 1.0            # one date mostly covered (< 40 000 clear px -> multi-date fit)
+    tiles[3, : (6 * H) // 10, :, :] += 0.3
+    tiles = np.clip(tiles, 0.001, 0.98).astype(np.float32)
+    return tiles, dates, probs, np.zeros((H, W), dtype=bool)

@@ -199,6 +199,17 @@ def main():
                         windows_permille=np.round(np.stack([mw[tuple(k)] for k in mk]) * 1000).astype(np.int32),
                         mosaic=J.load_mosaic_predictions(proc, depth=1))
 
+    # ---- cloud gap-fill (stdlib RNG pinned: the reference samples with random.shuffle) -----
+    tiles, gdates, probs, pf = synth.synth_gapfill_scene(31, 6, 224, 224)
+    ia = CR.id_areas_to_interp(tiles.copy(), probs.copy(), probs.copy(), gdates, pfcps=pf)
+    random.seed(7)
+    rt, ri, rr = CR.remove_cloud_and_shadows(tiles.copy(), probs.copy(), probs.copy(), gdates, pfcps=pf, sentinel1=None)
+    np.savez_compressed(os.path.join(OUT, "gapfill.npz"), seed=31, T=6, H=224, W=224, rng_seed=7,
+                        id_areas=ia.astype(np.float32), interp=ri.astype(np.float32),
+                        tiles_sub=rt[:, ::3, ::3, :].astype(np.float32), mosaic_sub=np.load("mosaic.npy")[::2, ::2],
+                        to_remove=np.array(rr, dtype=np.int64),
+                        tiles_sum=np.float64(rt.astype(np.float64).sum()))
+
     # ---- DSen2 tiling driver with a fake session ------------------------------------
     J.superresolve_logits, J.superresolve_inp, J.superresolve_inp_bilinear = "l", "i", "b"
 
