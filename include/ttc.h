@@ -124,6 +124,34 @@ ttc_status ttc_tile_missing_counts(ttc_ctx* ctx, const float* d_s2, int32_t T, i
 ttc_status ttc_tile_fix_missing(ttc_ctx* ctx, float* d_s2, int32_t T, int32_t X, int32_t Y,
                                 int32_t do_nan, int32_t do_zero_one, void* stream);
 
+/* ---- cloud / shadow gap-fill (src/preprocessing/cloud_removal.py) --------------------
+ * Feather weights == id_areas_to_interp (cloud_removal.py:774-798; closing 15, clip 1) or the
+ * identical block inside remove_cloud_and_shadows (:910-923; closing 20, clip 0).
+ * d_mask [T, X, Y] float32 (binary cloud+shadow mask) -> d_w [T, X, Y] float32 in [0, 1]. */
+ttc_status ttc_feather(ttc_ctx* ctx, const float* d_mask, int32_t T, int32_t X, int32_t Y, int32_t closing,
+                       int32_t clip, float* d_w, void* stream);
+/* == make_aligned_mosaic (cloud_removal.py:578-699).  d_tiles [T, X, Y, 10]; d_w [T, X, Y] in/out
+ * (dates that cannot be aligned are set to 1, :679-680); d_mosaic [X, Y, 10] out.  Synchronises the
+ * stream once per date (selection ranks depend on a device count). */
+ttc_status ttc_aligned_mosaic(ttc_ctx* ctx, const float* d_tiles, float* d_w, int32_t T, int32_t X, int32_t Y,
+                              float* d_mosaic, void* stream);
+/* Row sampler for the per-date fit (align_interp_array_randomforest, cloud_removal.py:453-505):
+ * given the unclipped EVI of the n_rows candidate training rows (host memory), write the chosen row
+ * indices (repeats allowed) to out_idx (capacity cap) and return their number.  The Python mirror
+ * replays the reference's stdlib random.shuffle sequence through this hook. */
+typedef int64_t (*ttc_sampler_fn)(const float* h_evi, int64_t n_rows, int64_t* out_idx, int64_t cap, void* user);
+/* == remove_cloud_and_shadows (cloud_removal.py:888-973): feather (closing 20) -> aligned mosaic ->
+ * per date: non-negative least-squares map [mosaic(10), snow] -> band (10 fits), predict, blend ->
+ * residual clouds in the mosaic (calculate_clouds_in_mosaic, :703-732).
+ * d_tiles [T, X, Y, 10] is modified in place; d_probs [T, X, Y] binary mask; d_pfcps [X, Y] uint8 or NULL;
+ * sampler NULL = deterministic expected-multiplicity weighting on the device (no RNG);
+ * d_interp [T, X, Y] out (areas_interpolated); d_mosaic [X, Y, 10] out or NULL;
+ * h_to_remove [T] / n_to_remove: dates that are interpolated everywhere (:958-959). */
+ttc_status ttc_remove_cloud_and_shadows(ttc_ctx* ctx, float* d_tiles, const float* d_probs, const uint8_t* d_pfcps,
+                                        int32_t T, int32_t X, int32_t Y, ttc_sampler_fn sampler, void* user,
+                                        float* d_interp, float* d_mosaic, int32_t* h_to_remove,
+                                        int32_t* n_to_remove, void* stream);
+
 /* ---- Gaussian overlap mosaic --------------------------------------------------------
  * == load_mosaic_predictions(out_folder, depth=1), job.py:1515-1641, from the 36 window
  * arrays (not from .npy files).

@@ -20,8 +20,10 @@ EXPORTS = [
     "ttc_load_weights", "ttc_load_dsen2_weights", "ttc_forward_windows", "ttc_process_subtiles",
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
-    "ttc_debug_kernel_ms",
+    "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
 ]
+
+SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
 
 
 class TTCConfig(C.Structure):
@@ -68,6 +70,10 @@ def load():
     lib.ttc_dsen2_forward.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
     lib.ttc_superresolve_tile.argtypes = [P, VP, I32, I32, I32, I32, VP]
     lib.ttc_upsample_20m.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_feather.argtypes = [P, VP, I32, I32, I32, I32, I32, VP, VP]
+    lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
     lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.ttc_debug_timing.argtypes = [P, I32]
     lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -225,6 +231,59 @@ class Context:
                                         C.c_void_p(u8.data_ptr()), C.c_void_p(f32.data_ptr()) if want_float else None,
                                         self._stream()), "ttc_mosaic")
         return u8, f32
+
+    # -- cloud gap-fill ------------------------------------------------------------------
+    def feather(self, mask, closing=20, clip=False):
+        t = self.torch
+        m = self._dev(mask, t.float32)
+        T, X, Y = (int(v) for v in m.shape)
+        w = t.empty_like(m)
+        self._check(self.lib.ttc_feather(self._h, C.c_void_p(m.data_ptr()), T, X, Y, closing, int(clip),
+                                         C.c_void_p(w.data_ptr()), self._stream()), "ttc_feather")
+        return w
+
+    def aligned_mosaic(self, tiles, w):
+        """tiles [T,X,Y,10], w [T,X,Y] cuda float32 (w is updated in place) -> mosaic [X,Y,10]"""
+        t = self.torch
+        T, X, Y = (int(v) for v in tiles.shape[:3])
+        mosaic = t.empty((X, Y, 10), dtype=t.float32, device=tiles.device)
+        self._check(self.lib.ttc_aligned_mosaic(self._h, C.c_void_p(tiles.data_ptr()), C.c_void_p(w.data_ptr()), T, X, Y,
+                                                C.c_void_p(mosaic.data_ptr()), self._stream()), "ttc_aligned_mosaic")
+        return mosaic
+
+    def remove_cloud_and_shadows(self, tiles, probs, pfcps=None, sampler=None, want_mosaic=False):
+        """tiles [T,X,Y,10] cuda float32 (in place), probs [T,X,Y]; sampler: None (deterministic, on device) or a
+        Python callable (evi float32[n]) -> int64 row indices.  -> (interp cuda [T,X,Y], to_remove list, mosaic | None)"""
+        t = self.torch
+        T, X, Y = (int(v) for v in tiles.shape[:3])
+        pr = self._dev(probs, t.float32)
+        pf = self._dev(np.ascontiguousarray(pfcps).astype(np.uint8), t.uint8) if pfcps is not None else None
+        interp = t.empty((T, X, Y), dtype=t.float32, device=tiles.device)
+        mosaic = t.empty((X, Y, 10), dtype=t.float32, device=tiles.device) if want_mosaic else None
+        rem = (C.c_int32 * T)()
+        nrem = C.c_int32(0)
+        err = []
+
+        def _cb(evi_p, n, out_p, cap, user):
+            try:
+                evi = np.ctypeslib.as_array(evi_p, shape=(n,))
+                idx = np.asarray(sampler(evi), dtype=np.int64)
+                if idx.size > cap:
+                    raise ValueError("sampler returned more rows than the capacity")
+                np.ctypeslib.as_array(out_p, shape=(idx.size,))[:] = idx
+                return int(idx.size)
+            except Exception as e:      # never raise through the C frame
+                err.append(e)
+                return -1
+        cb = SAMPLER_FN(_cb) if sampler is not None else SAMPLER_FN()
+        st = self.lib.ttc_remove_cloud_and_shadows(
+            self._h, C.c_void_p(tiles.data_ptr()), C.c_void_p(pr.data_ptr()), C.c_void_p(pf.data_ptr()) if pf is not None else None,
+            T, X, Y, cb, None, C.c_void_p(interp.data_ptr()), C.c_void_p(mosaic.data_ptr()) if want_mosaic else None,
+            rem, C.byref(nrem), self._stream())
+        if err:
+            raise err[0]
+        self._check(st, "ttc_remove_cloud_and_shadows")
+        return interp, [int(rem[i]) for i in range(nrem.value)], mosaic
 
     # -- 20 m -> 10 m ---------------------------------------------------------------------
     def dsen2_forward(self, x, bilinear):

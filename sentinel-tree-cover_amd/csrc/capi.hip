@@ -15,6 +15,12 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
 ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, hipStream_t s);
 ttc_status upsample_20m(ttc_ctx* c, const float* d10, const float* d20, int T, int h, int w, float* d_out, hipStream_t s);
 
+ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y, int closing, int clip, float* d_w, hipStream_t s);
+ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic, hipStream_t s);
+ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_probs, const uint8_t* d_pfcps, int T, int X, int Y,
+                                 ttc_sampler_fn sampler, void* user, float* d_interp, float* d_mosaic_out, int32_t* h_to_remove,
+                                 int32_t* n_to_remove, hipStream_t s);
+
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
         float ms = 0.f;
@@ -98,6 +104,26 @@ ttc_status ttc_tile_fix_missing(ttc_ctx* c, float* d_s2, int32_t T, int32_t X, i
                                 int32_t do_zero_one, void* stream) {
     if (!c) return TTC_ERR_ARG;
     return tile_fix_missing(c, d_s2, T, X, Y, do_nan, do_zero_one, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_feather(ttc_ctx* c, const float* d_mask, int32_t T, int32_t X, int32_t Y, int32_t closing, int32_t clip,
+                       float* d_w, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return gapfill_feather(c, d_mask, T, X, Y, closing, clip, d_w, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int32_t T, int32_t X, int32_t Y, float* d_mosaic,
+                              void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return gapfill_aligned_mosaic(c, d_tiles, d_w, T, X, Y, d_mosaic, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_remove_cloud_and_shadows(ttc_ctx* c, float* d_tiles, const float* d_probs, const uint8_t* d_pfcps, int32_t T,
+                                        int32_t X, int32_t Y, ttc_sampler_fn sampler, void* user, float* d_interp,
+                                        float* d_mosaic, int32_t* h_to_remove, int32_t* n_to_remove, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return gapfill_remove_clouds(c, d_tiles, d_probs, d_pfcps, T, X, Y, sampler, user, d_interp, d_mosaic, h_to_remove,
+                                 n_to_remove, static_cast<hipStream_t>(stream));
 }
 
 ttc_status ttc_mosaic(ttc_ctx* c, const float* d_windows, int32_t n, const int32_t* h_xy, int32_t size,

@@ -18,6 +18,7 @@
 // summation-order rounding.
 #include "ttc_internal.h"
 
+// (types shared with ttc.h)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {

@@ -1,0 +1,878 @@
+// Cloud / shadow gap-fill: src/preprocessing/cloud_removal.py (CR.py)
+//   a6  feather weights           id_areas_to_interp CR.py:774-798, remove_cloud_and_shadows CR.py:910-923
+//   a7  aligned cloud-free mosaic make_aligned_mosaic CR.py:578-699
+//   a8  per-date NNLS radiometric alignment + blend  align_interp_array_randomforest CR.py:316-575, :943-959
+//   a9  clouds left in the mosaic calculate_clouds_in_mosaic CR.py:703-732
+//
+// All of it is HBM-streaming / small-reduction work: exact EDT by two separable lower-envelope passes
+// (only distances <= 12 matter), 20x20 grey closing as separable max / min with scipy's even-size window
+// offsets, masked medians by an 8-bit-per-pass radix select, the 11-unknown non-negative least squares
+// from Gram matrices (Z'Z with Z = [clipped x | raw x | y], accumulated in double) solved by
+// Lawson-Hanson on the host side of the library (microseconds).
+//
+// Sampling: the reference draws an EVI-stratified sample with the stdlib global RNG.
+//   sampler callback != NULL : the library hands the training rows' EVI to the callback and uses the row
+//                              indices it returns (the Python mirror replays random.shuffle exactly);
+//   sampler callback == NULL : every training row is used with its EXPECTED multiplicity under the
+//                              reference's scheme (equal mass per EVI quintile, x10 on the 2 % tails) -- the
+//                              deterministic, device-only limit of the reference's estimator.
+#include "ttc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxT = 32;
+
+__device__ __forceinline__ int reflect_edge(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }  // scipy 'reflect'
+
+// ------------------------------------------------------------------------------------------------ a6
+// pass 1: along Y (contiguous): squared distance to the nearest masked pixel in the row, capped (13^2)
+__global__ void k_edt_rows(const float* __restrict__ mask, int X, int Y, int clip, unsigned short* __restrict__ g2) {
+    const int t = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= X * Y) return;
+    const int x = p / Y, y = p % Y;
+    const float* row = mask + ((long)t * X + x) * Y;
+    int best = 13;
+    for (int d = 0; d <= 12; ++d) {
+        bool hit = false;
+        if (y - d >= 0) { float v = row[y - d]; if (clip) v = fminf(fmaxf(v, 0.f), 1.f); hit |= (1.0f - v) == 0.0f; }
+        if (y + d < Y) { float v = row[y + d]; if (clip) v = fminf(fmaxf(v, 0.f), 1.f); hit |= (1.0f - v) == 0.0f; }
+        if (hit) { best = d; break; }
+    }
+    g2[(long)t * X * Y + p] = (unsigned short)(best * best);
+}
+// pass 2: along X: d2 = min_dx g2(x+dx)^2 + dx^2; b = 1 - min(sqrt(d2), 12)/12, < 0.2 -> 0 (float64 like scipy)
+__global__ void k_edt_cols(const unsigned short* __restrict__ g2, int X, int Y, double* __restrict__ b) {
+    const int t = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= X * Y) return;
+    const int x = p / Y, y = p % Y;
+    const unsigned short* pl = g2 + (long)t * X * Y;
+    int best = 169;
+    for (int dx = -12; dx <= 12; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= X) continue;
+        const int v = (int)pl[xx * Y + y] + dx * dx;
+        best = v < best ? v : best;
+    }
+    double d = sqrt((double)best);
+    if (d > 12.0) d = 12.0;
+    double v = 1.0 - d / 12.0;
+    if (v < 0.2) v = 0.0;
+    b[(long)t * X * Y + p] = v;
+}
+// separable flat max / min filter with window [lo, hi] and scipy 'reflect' borders
+template <bool MAXF, bool ALONG_Y>
+__global__ void k_minmax(const double* __restrict__ in, int X, int Y, int lo, int hi, double* __restrict__ out) {
+    const int t = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= X * Y) return;
+    const int x = p / Y, y = p % Y;
+    const double* pl = in + (long)t * X * Y;
+    double acc = MAXF ? -1e300 : 1e300;
+    for (int k = lo; k <= hi; ++k) {
+        const double v = ALONG_Y ? pl[x * Y + reflect_edge(y + k, Y)] : pl[reflect_edge(x + k, X) * Y + y];
+        acc = MAXF ? fmax(acc, v) : fmin(acc, v);
+    }
+    out[(long)t * X * Y + p] = acc;
+}
+// dates whose mask is empty keep the (clipped) mask itself (CR.py:786 / :914 `if np.sum(...) > 0`)
+__global__ void k_feather_store(const double* __restrict__ closed, const float* __restrict__ mask, const int* __restrict__ nz,
+                                int npix, int clip, float* __restrict__ w) {
+    const int t = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float m = mask[(long)t * npix + p];
+    if (clip) m = fminf(fmaxf(m, 0.f), 1.f);
+    w[(long)t * npix + p] = nz[t] > 0 ? (float)closed[(long)t * npix + p] : m;
+}
+__global__ void k_mask_positive(const float* __restrict__ mask, int npix, int clip, int* __restrict__ nz) {
+    const int t = blockIdx.y;
+    int c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        float m = mask[(long)t * npix + p];
+        if (clip) m = fminf(fmaxf(m, 0.f), 1.f);
+        c += m > 0.f;
+    }
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&nz[t], c);
+}
+
+// ------------------------------------------------------------------------------------------------ a7
+template <int TM>
+__device__ __forceinline__ void bitonic_sort(float (&a)[TM]) {
+#pragma unroll
+    for (int k = 2; k <= TM; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float lo = fminf(a[i], a[l]), hi = fmaxf(a[i], a[l]);
+                    if ((i & k) == 0) { a[i] = lo; a[l] = hi; } else { a[i] = hi; a[l] = lo; }
+                }
+            }
+}
+template <int TM>
+__device__ __forceinline__ float median_T(float (&a)[TM], int T) {     // a[t >= T] must be +inf
+    bitonic_sort<TM>(a);
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) { if (t == (T - 1) / 2) lo = a[t]; if (t == T / 2) hi = a[t]; }
+    return (lo + hi) * 0.5f;
+}
+
+// water = median_t NDWI > 0 (any NaN -> not water), NDWI = (G - N) / (G + N)   (CR.py:580-584)
+template <int TM, bool OF_MEDIAN>
+__global__ void k_water(const float* __restrict__ tiles, int T, int npix, unsigned char* __restrict__ water) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    if (OF_MEDIAN) {     // NDWI of the per-band temporal median (CR.py:936-939)
+        float g[TM], n[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            g[t] = t < T ? tiles[((long)t * npix + p) * 10 + 1] : INFINITY;
+            n[t] = t < T ? tiles[((long)t * npix + p) * 10 + 3] : INFINITY;
+        }
+        const float gm = median_T<TM>(g, T), nm = median_T<TM>(n, T);
+        water[p] = ((gm - nm) / (gm + nm)) > 0.0f;
+    } else {
+        float v[TM];
+        bool nan = false;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            if (t < T) {
+                const float g = tiles[((long)t * npix + p) * 10 + 1], n = tiles[((long)t * npix + p) * 10 + 3];
+                v[t] = (g - n) / (g + n);
+                nan |= isnan(v[t]);
+            } else v[t] = INFINITY;
+        }
+        water[p] = nan ? 0 : (median_T<TM>(v, T) > 0.0f);
+    }
+}
+// binary dilation with the cross structuring element iterated r times == L1 ball of radius r; `invert` applies
+// it to the complement (the reference dilates `1 - x`)
+__global__ void k_dilate_diamond(const unsigned char* __restrict__ in, int X, int Y, int r, int invert,
+                                 unsigned char* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= X * Y) return;
+    const int x = p / Y, y = p % Y;
+    bool any = false;
+    for (int dx = -r; dx <= r && !any; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= X) continue;
+        const int ry = r - abs(dx);
+        for (int dy = -ry; dy <= ry; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= Y) continue;
+            if ((in[xx * Y + yy] != 0) != (invert != 0)) { any = true; break; }
+        }
+    }
+    out[p] = any;
+}
+
+// per date i: valid = (w_i < 0.25) & land & (some other date b with w_b < 1); ref = mean of those dates
+__global__ void k_mosaic_ref(const float* __restrict__ tiles, const float* __restrict__ w, const unsigned char* __restrict__ water,
+                             int T, int npix, int i, float* __restrict__ ref, unsigned char* __restrict__ valid,
+                             int* __restrict__ count) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int ok = 0;
+    if (p < npix) {
+        if (w[(long)i * npix + p] < 0.25f && !water[p]) {
+            float s[10];
+#pragma unroll
+            for (int c = 0; c < 10; ++c) s[c] = 0.f;
+            int n = 0;
+            for (int b = 0; b < T; ++b) {
+                if (b == i || !(w[(long)b * npix + p] < 1.0f)) continue;
+                const float* v = tiles + ((long)b * npix + p) * 10;
+#pragma unroll
+                for (int c = 0; c < 10; ++c) s[c] += v[c];
+                ++n;
+            }
+            if (n > 0) {
+                ok = 1;
+#pragma unroll
+                for (int c = 0; c < 10; ++c) ref[(long)p * 10 + c] = s[c] / (float)n;
+            }
+        }
+        valid[p] = ok;
+    }
+    int c = ok;
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+// ---- radix select: k-th smallest of the valid elements, 8 bits per pass, batched over problems -------------
+__device__ __forceinline__ unsigned fkey(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+struct SelState { unsigned prefix, mask; long long k; };
+// value of problem q at pixel p: q = (band, which, rank); which 0 -> ref[p][band], 1 -> src[p][band]
+struct SelSrc { const float* a; const float* b; const unsigned char* valid; int npix; int stride; };
+
+__global__ void k_sel_hist(SelSrc s, const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[256];
+    const int q = blockIdx.y, band = q >> 2, which = (q >> 1) & 1;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const SelState ss = st[q];
+    const float* src = which ? s.b : s.a;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npix; p += gridDim.x * blockDim.x) {
+        if (!s.valid[p]) continue;
+        const unsigned k = fkey(src[(long)p * s.stride + band]);
+        if ((k & ss.mask) == ss.prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[q * 256 + threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_sel_pick(SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        SelState ss = st[q];
+        long long k = ss.k;
+        int b = 0;
+        for (; b < 255; ++b) { const unsigned c = hist[q * 256 + b]; if (k < (long long)c) break; k -= c; }
+        ss.prefix |= (unsigned)b << shift; ss.mask |= 255u << shift; ss.k = k;
+        st[q] = ss;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[q * 256 + i] = 0;
+}
+
+// mean / variance of the valid elements (two passes in double), 20 problems = (band, which)
+__global__ void k_stat_sum(SelSrc s, const double* __restrict__ mean, double* __restrict__ out) {
+    const int q = blockIdx.y, band = q >> 1, which = q & 1;
+    const float* src = which ? s.b : s.a;
+    const double m = mean ? mean[q] : 0.0;
+    double acc = 0.0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npix; p += gridDim.x * blockDim.x) {
+        if (!s.valid[p]) continue;
+        const double v = (double)src[(long)p * s.stride + band] - m;
+        acc += mean ? v * v : v;
+    }
+    for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[q], acc);
+}
+
+// gain / offset per band from (median, std) of ref and src; ok flag (CR.py:624-641)
+struct AlignPar { float k[10], add[10]; int ok; int any_land; };
+__global__ void k_align_params(const SelState* __restrict__ st, const double* __restrict__ var, const int* __restrict__ count,
+                               const int* __restrict__ n_land, AlignPar* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const int n = *count;
+    AlignPar ap;
+    ap.ok = n > 1000;
+    ap.any_land = *n_land > 0;
+    for (int b = 0; b < 10; ++b) {
+        // problems q = band*4 + which*2 + rank ; median = mean of the two middle order statistics
+        const float mr = 0.5f * (fkey_inv(st[b * 4 + 0].prefix) + fkey_inv(st[b * 4 + 1].prefix));
+        const float ms = 0.5f * (fkey_inv(st[b * 4 + 2].prefix) + fkey_inv(st[b * 4 + 3].prefix));
+        const float sr = (float)sqrt(var[b * 2 + 0] / (double)n), ss = (float)sqrt(var[b * 2 + 1] / (double)n);
+        const float k = sr / ss;
+        ap.k[b] = k; ap.add[b] = mr - ms * k;
+    }
+    *out = ap;
+}
+__global__ void k_mosaic_accum(const float* __restrict__ tiles, float* __restrict__ w, const unsigned char* __restrict__ water,
+                               const AlignPar* __restrict__ app, int npix, int i, float* __restrict__ mosaic) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const AlignPar& ap = *app;
+    if (ap.ok) {
+        const float wi = 1.0f - w[(long)i * npix + p];
+        const float* v = tiles + ((long)i * npix + p) * 10;
+        const bool land = !water[p];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const float a = land ? v[c] * ap.k[c] + ap.add[c] : v[c];
+            mosaic[(long)p * 10 + c] = mosaic[(long)p * 10 + c] + wi * a;
+        }
+    } else if (ap.any_land) {
+        w[(long)i * npix + p] = 1.0f;                          // CR.py:679-680
+    }
+}
+// mosaic / divisor, NaN -> 10th percentile over dates, clamp to [min_t, max_t] (CR.py:683-689)
+template <int TM>
+__global__ void k_mosaic_final(const float* __restrict__ tiles, const float* __restrict__ divisor, int T, int npix,
+                               float* __restrict__ mosaic) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float d = divisor[p];
+    if (d < 0.f) d = 0.f;
+    for (int c = 0; c < 10; ++c) {
+        float v[TM];
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            v[t] = t < T ? tiles[((long)t * npix + p) * 10 + c] : INFINITY;
+            if (t < T) { mn = fminf(mn, v[t]); mx = fmaxf(mx, v[t]); }
+        }
+        float m = mosaic[(long)p * 10 + c] / d;
+        if (isnan(m)) {
+            bitonic_sort<TM>(v);
+            const double pos = 0.1 * (T - 1);
+            const int lo = (int)floor(pos);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) { if (t == lo) a = v[t]; if (t == lo + 1 && lo + 1 < T) b = v[t]; }
+            if (lo + 1 >= T) b = a;
+            m = (float)((double)a + ((double)b - (double)a) * (pos - lo));
+        }
+        m = fmaxf(m, mn);
+        m = fminf(m, mx);
+        mosaic[(long)p * 10 + c] = m;
+    }
+}
+__global__ void k_divisor(const float* __restrict__ w, int T, int npix, float* __restrict__ divisor) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += 1.0f - w[(long)t * npix + p];
+    divisor[p] = s;
+}
+__global__ void k_count_land(const unsigned char* __restrict__ water, int npix, int* __restrict__ n_land) {
+    int c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) c += !water[p];
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_land, c);
+}
+
+// ------------------------------------------------------------------------------------------------ a8
+__device__ __forceinline__ float snow_prob_px(const float* v) {           // CR.py:348-370
+#pragma clang fp contract(off)
+    float ndsi = (v[1] - v[8]) / (v[1] + v[8]);
+    if (ndsi < 0.10f) ndsi = 0.f;                      // NaN compares false: stays NaN, like numpy
+    if (ndsi > 0.42f) ndsi = 0.42f;
+    float p = (ndsi - 0.1f) / 0.32f;
+    if (v[3] < 0.10f) p = 0.f;
+    if (v[3] > 0.35f && p > 0.f) p = 1.f;
+    if (v[0] < 0.10f) p = 0.f;
+    if (v[0] > 0.22f && p > 0.f) p = 1.f;
+    if ((v[0] / v[2]) < 0.75f) p = 0.f;
+    return p;
+}
+__global__ void k_snow_mean(const float* __restrict__ tiles, int T, int npix, float* __restrict__ snow) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += snow_prob_px(tiles + ((long)t * npix + p) * 10);
+    snow[p] = s / (float)T;
+}
+__device__ __forceinline__ float evi_unclipped(const float* v) {          // CR.py:332-345
+#pragma clang fp contract(off)
+    const float e = 2.5f * ((v[3] - v[2]) / (((v[3] + (6.0f * v[2])) - (7.5f * v[0])) + 1.0f));
+    return fminf(fmaxf(e, -1.5f), 1.5f);
+}
+// per-date clear statistics: n(w > 0), n(w == 0), n(w < 1)
+__global__ void k_date_counts(const float* __restrict__ w, int npix, int date, int* __restrict__ out) {
+    int a = 0, b = 0, c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const float v = w[(long)date * npix + p];
+        a += v > 0.f; b += v == 0.f; c += v < 1.f;
+    }
+    for (int k = 32; k >= 1; k >>= 1) { a += __shfl_xor(a, k); b += __shfl_xor(b, k); c += __shfl_xor(c, k); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicAdd(&out[1], b); atomicAdd(&out[2], c); }
+}
+// training rows of dates [t0, t1): pixels with w_t == 0 and not water, in (t, pixel) order -- 2-level scan compaction
+__global__ void k_rows_count(const float* __restrict__ w, const unsigned char* __restrict__ water, int npix, int t0, int nt,
+                             int* __restrict__ blk) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int f = 0;
+    if (i < (long)nt * npix) { const int t = t0 + (int)(i / npix), p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
+}
+__global__ void k_rows_scan(int* __restrict__ blk, int nblk, int* __restrict__ total) {     // single block exclusive scan
+    __shared__ int carry;
+    __shared__ int tmp[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblk ? blk[i] : 0;
+        tmp[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int a = threadIdx.x >= off ? tmp[threadIdx.x - off] : 0;
+            __syncthreads();
+            tmp[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (i < nblk) blk[i] = carry + tmp[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += tmp[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_rows_fill(const float* __restrict__ w, const unsigned char* __restrict__ water, const float* __restrict__ tiles,
+                            int npix, int t0, int nt, const int* __restrict__ blk, int* __restrict__ rows,
+                            float* __restrict__ evi) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int f = 0, t = 0, p = 0;
+    if (i < (long)nt * npix) { t = t0 + (int)(i / npix); p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
+    __shared__ int wbase[4];
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wbase[wv] = __popcll(m);
+    __syncthreads();
+    int off = blk[blockIdx.x];
+    for (int k = 0; k < wv; ++k) off += wbase[k];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (f) { rows[off] = (int)((long)(t - t0) * npix + p); evi[off] = evi_unclipped(tiles + ((long)t * npix + p) * 10); }
+}
+
+// Z'Z for Z = [clip(x,0.005,1)(10) snow | x(10) snow | y(10)] (32 columns), rows given by an index list with
+// optional per-row weights; double accumulation; one 32x32 partial per block, reduced by k_gram_reduce.
+struct GramArgs {
+    const float* tiles; const float* mosaic; const float* snow; const int* rows; const int* sample; const float* weight;
+    long nsample; int npix; int t0;
+};
+__global__ __launch_bounds__(256) void k_gram(GramArgs a, double* __restrict__ partial) {
+    __shared__ float zs[64][33];
+    __shared__ float ws[64];
+    double acc[4] = {0, 0, 0, 0};
+    const int tid = threadIdx.x;
+    const int r0 = tid >> 3, c0 = (tid & 7) * 4;          // thread owns Z'Z[r0][c0..c0+3]
+    for (long base = (long)blockIdx.x * 64; base < a.nsample; base += (long)gridDim.x * 64) {
+        __syncthreads();
+        if (tid < 64) {
+            const long s = base + tid;
+            float wgt = 0.f;
+            if (s < a.nsample) {
+                const int row = a.sample ? a.sample[s] : (int)s;
+                const int rr = a.rows[row];
+                const int t = a.t0 + rr / a.npix, p = rr % a.npix;
+                const float* x = a.mosaic + (long)p * 10;
+                const float* y = a.tiles + ((long)t * a.npix + p) * 10;
+                const float sn = a.snow[p];
+                for (int c = 0; c < 10; ++c) { zs[tid][c] = fminf(fmaxf(x[c], 0.005f), 1.0f); zs[tid][11 + c] = x[c]; zs[tid][22 + c] = y[c]; }
+                zs[tid][10] = sn; zs[tid][21] = sn;
+                wgt = a.weight ? a.weight[row] : 1.0f;
+            } else {
+                for (int c = 0; c < 32; ++c) zs[tid][c] = 0.f;
+            }
+            ws[tid] = wgt;
+        }
+        __syncthreads();
+        for (int s = 0; s < 64; ++s) {
+            const double zr = (double)zs[s][r0] * (double)ws[s];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += zr * (double)zs[s][c0 + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) partial[(long)blockIdx.x * 1024 + r0 * 32 + c0 + k] = acc[k];
+}
+__global__ void k_gram_reduce(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 1024) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 1024 + i];
+    out[i] = s;
+}
+// expected multiplicity of a row under the reference's stratified sampling (CR.py:453-496), from EVI thresholds
+struct Strata { float b2, b20, b40, b60, b80, b98; float wq[5]; };
+__global__ void k_row_weights(const float* __restrict__ evi, int n, Strata st, float* __restrict__ weight) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = evi[i];
+    float w = e < st.b20 ? st.wq[0] : (e < st.b40 ? st.wq[1] : (e < st.b60 ? st.wq[2] : (e < st.b80 ? st.wq[3] : st.wq[4])));
+    if (e < st.b2) w += 10.f;
+    if (e >= st.b98) w += 10.f;
+    weight[i] = w;
+}
+
+// prediction + blend (CR.py:561-569, :954-955): pixels with w_d > 0 get [fill, snow] . beta, then
+// tile = tile * (1 - w) + pred * w
+struct Beta { double b[10][11]; int fitted; };
+__global__ void k_predict_blend(float* __restrict__ tiles, const float* __restrict__ w, const float* __restrict__ mosaic,
+                                const float* __restrict__ snow, Beta be, int npix, int date) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float wd = w[(long)date * npix + p];
+    if (!(wd > 0.f)) return;                                   // tile * 1 + 0 * 0: unchanged
+    float* tv = tiles + ((long)date * npix + p) * 10;
+    const float* mv = mosaic + (long)p * 10;
+    const double sn = (double)snow[p];
+    for (int c = 0; c < 10; ++c) {
+        float pred = mv[c];
+        if (be.fitted) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) s += (double)mv[j] * be.b[c][j];
+            s += sn * be.b[c][10];
+            pred = (float)s;
+        }
+        tv[c] = tv[c] * (1.0f - wd) + pred * wd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ a9
+__global__ void k_only1(const float* __restrict__ w, const unsigned char* __restrict__ pf_dil, int T, int npix,
+                        unsigned char* __restrict__ only1, int* __restrict__ n_only) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int o = 0;
+    if (p < npix) {
+        int clear = 0;
+        for (int t = 0; t < T; ++t) clear += !(w[(long)t * npix + p] > 0.f);
+        o = (clear < 2) || pf_dil[p];
+        only1[p] = o;
+    }
+    int c = o;
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_only, c);
+}
+__global__ void k_not(const unsigned char* __restrict__ in, int n, unsigned char* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = !in[p];
+}
+__global__ void k_cloud_flags(const float* __restrict__ mosaic, const unsigned char* __restrict__ only1,
+                              const unsigned char* __restrict__ pf_dil, float ref_blue, float ref_red, int npix,
+                              unsigned char* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float* m = mosaic + (long)p * 10;
+    bool c = (m[0] > ref_blue) && (m[2] > ref_red) && only1[p] && (((m[0] + m[1]) + m[2]) < 1.0f);
+    if (pf_dil[p]) c = false;
+    out[p] = c;
+}
+__global__ void k_add_clouds(float* __restrict__ w, const unsigned char* __restrict__ clouds, int T, int npix) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix || !clouds[p]) return;
+    for (int t = 0; t < T; ++t) { float v = w[(long)t * npix + p] + 1.0f; w[(long)t * npix + p] = v > 1.f ? 1.f : v; }
+}
+__global__ void k_u8_from_bool(const unsigned char* __restrict__ in, int n, unsigned char* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = in[p] != 0;
+}
+
+// ---- host: Lawson-Hanson NNLS on the normal equations (n = 11) ---------------------------------
+void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
+    const int n = 11;
+    bool P[11] = {false};
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    double wv[11];
+    for (int iter = 0; iter < 3 * n; ++iter) {
+        for (int i = 0; i < n; ++i) { double s = g[i]; for (int j = 0; j < n; ++j) s -= G[i][j] * x[j]; wv[i] = s; }
+        int best = -1; double bw = 0.0;
+        const double tol = 1e-12 * std::fabs(g[0] + 1e-300) + 1e-15;
+        for (int i = 0; i < n; ++i) if (!P[i] && wv[i] > tol && wv[i] > bw) { bw = wv[i]; best = i; }
+        if (best < 0) break;
+        P[best] = true;
+        for (int inner = 0; inner < 3 * n; ++inner) {
+            // solve G_PP s_P = g_P (Cholesky-free Gaussian elimination with partial pivoting, tiny system)
+            int idx[11], m = 0;
+            for (int i = 0; i < n; ++i) if (P[i]) idx[m++] = i;
+            double A[11][12];
+            for (int r = 0; r < m; ++r) { for (int c2 = 0; c2 < m; ++c2) A[r][c2] = G[idx[r]][idx[c2]]; A[r][m] = g[idx[r]]; }
+            for (int c2 = 0; c2 < m; ++c2) {
+                int piv = c2;
+                for (int r = c2 + 1; r < m; ++r) if (std::fabs(A[r][c2]) > std::fabs(A[piv][c2])) piv = r;
+                if (piv != c2) for (int k = 0; k <= m; ++k) std::swap(A[piv][k], A[c2][k]);
+                const double d = A[c2][c2];
+                if (std::fabs(d) < 1e-300) continue;
+                for (int r = 0; r < m; ++r) {
+                    if (r == c2) continue;
+                    const double f = A[r][c2] / d;
+                    if (f != 0.0) for (int k = c2; k <= m; ++k) A[r][k] -= f * A[c2][k];
+                }
+            }
+            double sfull[11] = {0};
+            bool allpos = true;
+            for (int r = 0; r < m; ++r) { const double d = A[r][r]; sfull[idx[r]] = std::fabs(d) < 1e-300 ? 0.0 : A[r][m] / d; if (sfull[idx[r]] <= 0.0) allpos = false; }
+            if (allpos) { for (int i = 0; i < n; ++i) x[i] = P[i] ? sfull[i] : 0.0; break; }
+            double alpha = 1.0;
+            for (int r = 0; r < m; ++r) { const int i = idx[r]; if (sfull[i] <= 0.0) { const double a = x[i] / (x[i] - sfull[i]); if (a < alpha) alpha = a; } }
+            for (int i = 0; i < n; ++i) if (P[i]) x[i] += alpha * (sfull[i] - x[i]);
+            for (int i = 0; i < n; ++i) if (P[i] && x[i] <= 1e-15) { x[i] = 0.0; P[i] = false; }
+        }
+    }
+}
+
+float percentile_host(std::vector<float>& v, double q) {        // numpy 'linear' method
+    if (v.empty()) return NAN;
+    const double pos = q / 100.0 * (double)(v.size() - 1);
+    const size_t lo = (size_t)std::floor(pos), hi = std::min(lo + 1, v.size() - 1);
+    std::nth_element(v.begin(), v.begin() + lo, v.end());
+    const float a = v[lo];
+    float b = a;
+    if (hi != lo) b = *std::min_element(v.begin() + lo + 1, v.end());
+    return (float)((double)a + ((double)b - (double)a) * (pos - (double)lo));
+}
+
+}  // namespace
+
+#define GF_T(kern, T, ...)                                                            \
+    do {                                                                              \
+        if ((T) <= 8) hipLaunchKernelGGL((kern<8>), __VA_ARGS__);                     \
+        else if ((T) <= 16) hipLaunchKernelGGL((kern<16>), __VA_ARGS__);              \
+        else hipLaunchKernelGGL((kern<32>), __VA_ARGS__);                             \
+    } while (0)
+#define GF_T2(kern, flag, T, ...)                                                     \
+    do {                                                                              \
+        if ((T) <= 8) hipLaunchKernelGGL((kern<8, flag>), __VA_ARGS__);               \
+        else if ((T) <= 16) hipLaunchKernelGGL((kern<16, flag>), __VA_ARGS__);        \
+        else hipLaunchKernelGGL((kern<32, flag>), __VA_ARGS__);                       \
+    } while (0)
+
+// a6 ------------------------------------------------------------------------------------------------
+ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y, int closing, int clip, float* d_w,
+                           hipStream_t s) {
+    if (!d_mask || !d_w || T < 1) return c->fail(TTC_ERR_ARG, "feather: bad argument");
+    if (closing != 15 && closing != 20) return c->fail(TTC_ERR_ARG, "feather: closing must be 15 or 20");
+    const long npix = (long)X * Y;
+    unsigned short* g2 = static_cast<unsigned short*>(c->scratch_buf("gf_g2", sizeof(unsigned short) * T * npix));
+    double* b0 = static_cast<double*>(c->scratch_buf("gf_b0", sizeof(double) * T * npix));
+    double* b1 = static_cast<double*>(c->scratch_buf("gf_b1", sizeof(double) * T * npix));
+    int* nz = static_cast<int*>(c->scratch_buf("gf_nz", sizeof(int) * kMaxT));
+    if (!g2 || !b0 || !b1 || !nz) return c->fail(TTC_ERR_NOMEM, "feather scratch");
+    KTimer kt(c, "feather", s);
+    const dim3 grid((unsigned)((npix + 255) / 256), T), blk(256);
+    TTC_HIP(c, hipMemsetAsync(nz, 0, sizeof(int) * kMaxT, s));
+    hipLaunchKernelGGL(k_mask_positive, dim3(64, T), blk, 0, s, d_mask, (int)npix, clip, nz);
+    hipLaunchKernelGGL(k_edt_rows, grid, blk, 0, s, d_mask, X, Y, clip, g2);
+    hipLaunchKernelGGL(k_edt_cols, grid, blk, 0, s, g2, X, Y, b0);
+    // scipy grey_closing(size): dilation window [-(size/2 - 1), size/2] for even sizes, then erosion [-size/2, size/2 - 1]
+    const int dlo = closing == 20 ? -9 : -7, dhi = closing == 20 ? 10 : 7, elo = closing == 20 ? -10 : -7, ehi = closing == 20 ? 9 : 7;
+    hipLaunchKernelGGL((k_minmax<true, true>), grid, blk, 0, s, b0, X, Y, dlo, dhi, b1);
+    hipLaunchKernelGGL((k_minmax<true, false>), grid, blk, 0, s, b1, X, Y, dlo, dhi, b0);
+    hipLaunchKernelGGL((k_minmax<false, true>), grid, blk, 0, s, b0, X, Y, elo, ehi, b1);
+    hipLaunchKernelGGL((k_minmax<false, false>), grid, blk, 0, s, b1, X, Y, elo, ehi, b0);
+    hipLaunchKernelGGL(k_feather_store, grid, blk, 0, s, b0, d_mask, nz, (int)npix, clip, d_w);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+// a7 ------------------------------------------------------------------------------------------------
+static ttc_status water_mask(ttc_ctx* c, const float* d_tiles, int T, int X, int Y, bool of_median, bool dilate,
+                             unsigned char* out, hipStream_t s) {
+    const int npix = X * Y;
+    unsigned char* tmp = static_cast<unsigned char*>(c->scratch_buf("gf_wtmp", 2 * (size_t)npix));
+    if (!tmp) return c->fail(TTC_ERR_NOMEM, "water scratch");
+    const dim3 grid((npix + 255) / 256), blk(256);
+    unsigned char* raw = dilate ? tmp : out;
+    if (of_median) GF_T2(k_water, true, T, grid, blk, 0, s, d_tiles, T, npix, raw);
+    else GF_T2(k_water, false, T, grid, blk, 0, s, d_tiles, T, npix, raw);
+    if (dilate) {   // binary_dilation(1 - water, 2) then binary_dilation(1 - that, 5)  (CR.py:585-586)
+        hipLaunchKernelGGL(k_dilate_diamond, grid, blk, 0, s, raw, X, Y, 2, 1, tmp + npix);
+        hipLaunchKernelGGL(k_dilate_diamond, grid, blk, 0, s, tmp + npix, X, Y, 5, 1, out);
+    }
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
+                                  hipStream_t s) {
+    if (!d_tiles || !d_w || !d_mosaic || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "aligned_mosaic: bad argument (T in [1,32])");
+    const int npix = X * Y;
+    unsigned char* water = static_cast<unsigned char*>(c->scratch_buf("gf_water", (size_t)npix));
+    unsigned char* valid = static_cast<unsigned char*>(c->scratch_buf("gf_valid", (size_t)npix));
+    float* ref = static_cast<float*>(c->scratch_buf("gf_ref", sizeof(float) * 10 * (size_t)npix));
+    float* divisor = static_cast<float*>(c->scratch_buf("gf_div", sizeof(float) * (size_t)npix));
+    char* small = static_cast<char*>(c->scratch_buf("gf_small", 65536));
+    if (!water || !valid || !ref || !divisor || !small) return c->fail(TTC_ERR_NOMEM, "aligned_mosaic scratch");
+    SelState* st = reinterpret_cast<SelState*>(small);                   // 40 problems
+    unsigned* hist = reinterpret_cast<unsigned*>(small + 4096);           // 40 * 256 * 4 = 40960
+    double* mean = reinterpret_cast<double*>(small + 4096 + 40960);       // 20
+    double* var = mean + 20;                                              // 20
+    int* count = reinterpret_cast<int*>(var + 20);                        // count, n_land
+    AlignPar* ap = reinterpret_cast<AlignPar*>(count + 4);
+    KTimer kt(c, "aligned_mosaic", s);
+    TTC_CHECK(water_mask(c, d_tiles, T, X, Y, false, true, water, s));
+    const dim3 grid((npix + 255) / 256), blk(256);
+    TTC_HIP(c, hipMemsetAsync(d_mosaic, 0, sizeof(float) * 10 * (size_t)npix, s));
+    TTC_HIP(c, hipMemsetAsync(count, 0, sizeof(int) * 4, s));
+    hipLaunchKernelGGL(k_divisor, grid, blk, 0, s, d_w, T, npix, divisor);
+    hipLaunchKernelGGL(k_count_land, dim3(64), blk, 0, s, water, npix, count + 1);
+    TTC_HIP(c, hipMemsetAsync(hist, 0, 40960, s));
+    for (int i = 0; i < T; ++i) {
+        TTC_HIP(c, hipMemsetAsync(count, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_mosaic_ref, grid, blk, 0, s, d_tiles, d_w, water, T, npix, i, ref, valid, count);
+        // the selection ranks depend on the count -> one small D2H per date
+        int n = 0;
+        TTC_HIP(c, hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, s));
+        TTC_HIP(c, hipStreamSynchronize(s));
+        if (n > 1000) {
+            SelState h[40];
+            for (int q = 0; q < 40; ++q) { h[q].prefix = 0; h[q].mask = 0; h[q].k = (q & 1) ? n / 2 : (n - 1) / 2; }
+            TTC_HIP(c, hipMemcpyAsync(st, h, sizeof(h), hipMemcpyHostToDevice, s));
+            SelSrc src{ref, d_tiles + (long)i * npix * 10, valid, npix, 10};
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                hipLaunchKernelGGL(k_sel_hist, dim3(96, 40), dim3(256), 0, s, src, st, shift, hist);
+                hipLaunchKernelGGL(k_sel_pick, dim3(40), dim3(64), 0, s, st, shift, hist);
+            }
+            TTC_HIP(c, hipMemsetAsync(mean, 0, sizeof(double) * 40, s));
+            hipLaunchKernelGGL(k_stat_sum, dim3(96, 20), dim3(256), 0, s, src, (const double*)nullptr, mean);
+            double hm[20];
+            TTC_HIP(c, hipMemcpyAsync(hm, mean, sizeof(hm), hipMemcpyDeviceToHost, s));
+            TTC_HIP(c, hipStreamSynchronize(s));
+            for (int q = 0; q < 20; ++q) hm[q] /= (double)n;
+            TTC_HIP(c, hipMemcpyAsync(mean, hm, sizeof(hm), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_stat_sum, dim3(96, 20), dim3(256), 0, s, src, (const double*)mean, var);
+        }
+        hipLaunchKernelGGL(k_align_params, dim3(1), dim3(64), 0, s, st, var, count, count + 1, ap);
+        hipLaunchKernelGGL(k_mosaic_accum, grid, blk, 0, s, d_tiles, d_w, water, ap, npix, i, d_mosaic);
+        TTC_HIP(c, hipGetLastError());
+    }
+    GF_T(k_mosaic_final, T, grid, blk, 0, s, d_tiles, divisor, T, npix, d_mosaic);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+// a8 + a9 -------------------------------------------------------------------------------------------
+ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_probs, const uint8_t* d_pfcps, int T, int X, int Y,
+                                 ttc_sampler_fn sampler, void* user, float* d_interp, float* d_mosaic_out, int32_t* h_to_remove,
+                                 int32_t* n_to_remove, hipStream_t s) {
+    if (!d_tiles || !d_probs || !d_interp || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "remove_cloud_and_shadows: bad argument (T in [1,32])");
+    const int npix = X * Y;
+    float* mosaic = d_mosaic_out ? d_mosaic_out : static_cast<float*>(c->scratch_buf("gf_mosaic", sizeof(float) * 10 * (size_t)npix));
+    float* snow = static_cast<float*>(c->scratch_buf("gf_snow", sizeof(float) * (size_t)npix));
+    unsigned char* water2 = static_cast<unsigned char*>(c->scratch_buf("gf_water2", (size_t)npix));
+    unsigned char* bits = static_cast<unsigned char*>(c->scratch_buf("gf_bits", 4 * (size_t)npix));
+    int* rows = static_cast<int*>(c->scratch_buf("gf_rows", sizeof(int) * 3 * (size_t)npix));
+    float* evi = static_cast<float*>(c->scratch_buf("gf_evi", sizeof(float) * 3 * (size_t)npix));
+    float* weight = static_cast<float*>(c->scratch_buf("gf_weight", sizeof(float) * 3 * (size_t)npix));
+    const int nblk_rows = (3 * npix + 255) / 256;
+    int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * (nblk_rows + 16)));
+    const int gram_blocks = 512;
+    double* gpart = static_cast<double*>(c->scratch_buf("gf_gram", sizeof(double) * 1024 * (gram_blocks + 1)));
+    if (!mosaic || !snow || !water2 || !bits || !rows || !evi || !weight || !blk || !gpart) return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
+    int* counters = blk + nblk_rows;                                     // [0..2] date counts, [3] total rows, [4] n_only
+    if (n_to_remove) *n_to_remove = 0;
+    const dim3 grid((npix + 255) / 256), b256(256);
+
+    TTC_CHECK(gapfill_feather(c, d_probs, T, X, Y, 20, 0, d_interp, s));                       // CR.py:910-923
+    TTC_CHECK(gapfill_aligned_mosaic(c, d_tiles, d_interp, T, X, Y, mosaic, s));               // CR.py:925
+    TTC_CHECK(water_mask(c, d_tiles, T, X, Y, true, false, water2, s));                        // CR.py:936-939
+    KTimer kt(c, "gapfill_dates", s);
+    std::vector<float> h_evi;
+    std::vector<int64_t> h_idx;
+    int* d_sample = nullptr;
+    for (int date = 0; date < T; ++date) {
+        hipLaunchKernelGGL(k_snow_mean, grid, b256, 0, s, d_tiles, T, npix, snow);            // CR.py:372 (tiles mutate per date)
+        TTC_HIP(c, hipMemsetAsync(counters, 0, sizeof(int) * 8, s));
+        hipLaunchKernelGGL(k_date_counts, dim3(64), b256, 0, s, d_interp, npix, date, counters);
+        int hc[3];
+        TTC_HIP(c, hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
+        TTC_HIP(c, hipStreamSynchronize(s));
+        Beta be{};
+        be.fitted = 0;
+        const bool proceed = hc[0] > 0 && hc[1] > 0 && ((double)hc[2] / npix) > 0.01;        // CR.py:377-378
+        if (proceed) {
+            int t0, t1;
+            if (hc[1] > 40000) { t0 = date; t1 = date + 1; }                                   // CR.py:394-402
+            else { t0 = std::max(date == T - 1 ? date - 2 : date - 1, 0); t1 = std::min(date + 2, T); }
+            const int nt = t1 - t0;
+            const int nb = (int)(((long)nt * npix + 255) / 256);
+            hipLaunchKernelGGL(k_rows_count, dim3(nb), b256, 0, s, d_interp, water2, npix, t0, nt, blk);
+            hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, blk, nb, counters + 3);
+            hipLaunchKernelGGL(k_rows_fill, dim3(nb), b256, 0, s, d_interp, water2, d_tiles, npix, t0, nt, blk, rows, evi);
+            int nrows = 0;
+            TTC_HIP(c, hipMemcpyAsync(&nrows, counters + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+            TTC_HIP(c, hipStreamSynchronize(s));
+            if (nrows > 0) {
+                h_evi.resize(nrows);
+                TTC_HIP(c, hipMemcpyAsync(h_evi.data(), evi, sizeof(float) * nrows, hipMemcpyDeviceToHost, s));
+                TTC_HIP(c, hipStreamSynchronize(s));
+                GramArgs ga{d_tiles, mosaic, snow, rows, nullptr, nullptr, nrows, npix, t0};
+                if (sampler) {
+                    // reference replay: the callback returns row indices (with repeats), at most 2.5 * nrows of them
+                    h_idx.resize((size_t)nrows * 3 + 16);
+                    const int64_t ns = sampler(h_evi.data(), nrows, h_idx.data(), (int64_t)h_idx.size(), user);
+                    if (ns <= 0 || ns > (int64_t)h_idx.size()) return c->fail(TTC_ERR_ARG, "sampler callback returned a bad count");
+                    std::vector<int> idx32(ns);
+                    for (int64_t i = 0; i < ns; ++i) {
+                        if (h_idx[i] < 0 || h_idx[i] >= nrows) return c->fail(TTC_ERR_ARG, "sampler callback returned an out-of-range row");
+                        idx32[i] = (int)h_idx[i];
+                    }
+                    d_sample = static_cast<int*>(c->scratch_buf("gf_sample", sizeof(int) * (size_t)ns));
+                    if (!d_sample) return c->fail(TTC_ERR_NOMEM, "sample buffer");
+                    TTC_HIP(c, hipMemcpyAsync(d_sample, idx32.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
+                    TTC_HIP(c, hipStreamSynchronize(s));
+                    ga.sample = d_sample; ga.nsample = ns;
+                } else {
+                    // expected multiplicities: strata thresholds from the host copy of EVI (numpy-style percentiles)
+                    std::vector<float> tmp(h_evi);
+                    Strata stt{};
+                    float* bp[6] = {&stt.b2, &stt.b20, &stt.b40, &stt.b60, &stt.b80, &stt.b98};
+                    const double qs[6] = {2, 20, 40, 60, 80, 98};
+                    for (int k = 0; k < 6; ++k) *bp[k] = percentile_host(tmp, qs[k]);
+                    long cnt[5] = {0, 0, 0, 0, 0};
+                    for (float e : h_evi) cnt[e < stt.b20 ? 0 : (e < stt.b40 ? 1 : (e < stt.b60 ? 2 : (e < stt.b80 ? 3 : 4)))]++;
+                    const long n_i = std::min<long>(90000, nrows) / 5;
+                    for (int k = 0; k < 5; ++k) stt.wq[k] = cnt[k] > 0 ? (float)std::min(1.0, (double)n_i / (double)cnt[k]) : 0.f;
+                    hipLaunchKernelGGL(k_row_weights, dim3((nrows + 255) / 256), b256, 0, s, evi, nrows, stt, weight);
+                    ga.weight = weight;
+                }
+                hipLaunchKernelGGL(k_gram, dim3(gram_blocks), b256, 0, s, ga, gpart);
+                hipLaunchKernelGGL(k_gram_reduce, dim3(4), b256, 0, s, gpart, gram_blocks, gpart + 1024L * gram_blocks);
+                double Z[32][32];
+                TTC_HIP(c, hipMemcpyAsync(Z, gpart + 1024L * gram_blocks, sizeof(Z), hipMemcpyDeviceToHost, s));
+                TTC_HIP(c, hipStreamSynchronize(s));
+                for (int band = 0; band < 10; ++band) {
+                    // design column j: clipped copy (Z col j) for j < band, raw (Z col 11 + j) otherwise (CR.py:522, :550)
+                    int col[11];
+                    for (int j = 0; j < 11; ++j) col[j] = (j < band && j < 10) ? j : 11 + j;
+                    double G[11][11], g[11];
+                    for (int i = 0; i < 11; ++i) {
+                        for (int j = 0; j < 11; ++j) G[i][j] = Z[col[i]][col[j]];
+                        g[i] = Z[col[i]][22 + band];
+                    }
+                    nnls_gram(G, g, be.b[band]);
+                }
+                be.fitted = 1;
+            }
+        }
+        hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, be, npix, date);
+        TTC_HIP(c, hipGetLastError());
+        if (hc[2] == 0 && h_to_remove && n_to_remove) h_to_remove[(*n_to_remove)++] = date;   // mean(w == 1) == 1 (CR.py:958-959)
+    }
+    // a9: clouds that survive in the mosaic (CR.py:964-968)
+    unsigned char *only1 = bits, *pfd = bits + npix, *cl = bits + 2 * (size_t)npix, *tmp = bits + 3 * (size_t)npix;
+    if (d_pfcps) hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, d_pfcps, X, Y, 10, 0, pfd);
+    else TTC_HIP(c, hipMemsetAsync(pfd, 0, npix, s));
+    TTC_HIP(c, hipMemsetAsync(counters + 4, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_only1, grid, b256, 0, s, d_interp, pfd, T, npix, only1, counters + 4);
+    int n_only = 0;
+    TTC_HIP(c, hipMemcpyAsync(&n_only, counters + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    TTC_HIP(c, hipStreamSynchronize(s));
+    if (n_only < npix) {
+        std::vector<float> hm((size_t)npix * 10);
+        std::vector<unsigned char> ho(npix);
+        TTC_HIP(c, hipMemcpyAsync(hm.data(), mosaic, sizeof(float) * hm.size(), hipMemcpyDeviceToHost, s));
+        TTC_HIP(c, hipMemcpyAsync(ho.data(), only1, npix, hipMemcpyDeviceToHost, s));
+        TTC_HIP(c, hipStreamSynchronize(s));
+        std::vector<float> blue, red;
+        blue.reserve(npix); red.reserve(npix);
+        for (int p = 0; p < npix; ++p) if (!ho[p]) { blue.push_back(hm[(size_t)p * 10]); red.push_back(hm[(size_t)p * 10 + 2]); }
+        const float rb = percentile_host(blue, 99.0), rr = percentile_host(red, 99.0);
+        hipLaunchKernelGGL(k_cloud_flags, grid, b256, 0, s, mosaic, only1, pfd, rb, rr, npix, cl);
+        hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, cl, X, Y, 3, 1, tmp);     // dilate(1 - c, 3)
+        hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, tmp, X, Y, 8, 1, cl);      // dilate(1 - that, 8)
+        hipLaunchKernelGGL(k_add_clouds, grid, b256, 0, s, d_interp, cl, T, npix);
+    }
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}

@@ -181,6 +181,50 @@ def load_mosaic_predictions(windows, depth=1, sess=None, size=SIZE, return_float
     return u8.cpu().numpy()
 
 
+# ------------------------------------------------------------------------------------------
+# cloud / shadow gap-fill (src/preprocessing/cloud_removal.py)
+def reference_sampler(evi, rng=None):
+    """The reference's EVI-stratified row sample (cloud_removal.py:453-500), replayed with the stdlib global RNG:
+    2 % tails repeated x10, five quintile strata truncated to n//5 after random.shuffle, shuffled again.
+    Pin random.seed() before remove_cloud_and_shadows to reproduce the reference bit for bit."""
+    import random
+    rng = rng or random
+    n_rows = len(evi)
+    n_i = min(90000, n_rows) // 5
+    b2, b20, b40, b60, b80, b98 = (np.percentile(evi, q) for q in (2, 20, 40, 60, 80, 98))
+    strata = [np.flatnonzero(evi < b20), np.flatnonzero((evi >= b20) & (evi < b40)), np.flatnonzero((evi >= b40) & (evi < b60)),
+              np.flatnonzero((evi >= b60) & (evi < b80)), np.flatnonzero(evi >= b80)]
+    p2, p98 = np.repeat(np.flatnonzero(evi < b2), 10), np.repeat(np.flatnonzero(evi >= b98), 10)
+    for p in [p2, p98] + strata:              # the reference's shuffle order: p2, p98, p20, p40, p60, p80, p100
+        rng.shuffle(p)
+    sample = np.concatenate([p2] + [q[:n_i] for q in strata] + [p98])
+    rng.shuffle(sample)
+    return sample[:n_rows]
+
+
+def id_areas_to_interp(tiles, probs, shadows, image_dates, pfcps, sess=None):
+    """cloud_removal.py:774-798 (tiles / shadows / dates / pfcps are unused by the reference too)."""
+    return sess.ctx.feather(probs, closing=15, clip=True).cpu().numpy()
+
+
+def remove_cloud_and_shadows(tiles, probs, shadows, image_dates, pfcps, sentinel1=None, mosaic=None, sess=None,
+                             sampler="reference"):
+    """cloud_removal.py:888-973 on the GPU.  tiles [T,X,Y,10] float32 numpy (modified in place, like the
+    reference) or cuda tensor; returns (tiles, areas_interpolated [T,X,Y], to_remove).
+    sampler = "reference": replay random.shuffle on the host (exact, but Python-speed: ~0.5 s per date);
+              "expected":  deterministic expected-multiplicity weighting, entirely on the device."""
+    if mosaic is not None:
+        raise NotImplementedError("a caller-supplied mosaic is not used anywhere in the reference job")
+    ctx, t = sess.ctx, sess.ctx.torch
+    td = ctx._dev(tiles, t.float32)
+    fn = reference_sampler if sampler == "reference" else None
+    interp, to_remove, _ = ctx.remove_cloud_and_shadows(td, probs, pfcps, fn)
+    if isinstance(tiles, np.ndarray):
+        tiles[...] = td.cpu().numpy()
+        return tiles, interp.cpu().numpy(), to_remove
+    return td, interp, to_remove
+
+
 def predict_tile(s2, dates, interp, s1, dem, sess, size=SIZE, to_host=True):
     """One call, device-resident between the stages: cloud-free tile stack ->
     (float32 percent raster with NaN no-data, uint8 product), both [Y, X] like load_mosaic_predictions."""
