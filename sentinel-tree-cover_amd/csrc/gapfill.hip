@@ -218,19 +218,45 @@ __device__ __forceinline__ float fkey_inv(unsigned k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 struct SelState { unsigned prefix, mask; long long k; };
-// value of problem q at pixel p: q = (band, which, rank); which 0 -> ref[p][band], 1 -> src[p][band]
-struct SelSrc { const float* a; const float* b; const unsigned char* valid; int npix; int stride; };
+struct DatePlan { int proceed, t0, nt, nrows, fitted; };     // device-resident control block of one gap-fill date
 
-__global__ void k_sel_hist(SelSrc s, const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
+// selection sources: value of problem q at element p (false = element not in the set)
+struct SrcMosaic {      // q = band*4 + which*2 + rank ; which 0 -> ref[p][band], 1 -> src[p][band]
+    const float* ref; const float* src; const unsigned char* valid; int npix;
+    __device__ int count() const { return npix; }
+    __device__ bool get(int q, int p, float& v) const {
+        if (!valid[p]) return false;
+        v = (((q >> 1) & 1) ? src : ref)[(long)p * 10 + (q >> 2)];
+        return true;
+    }
+};
+struct SrcEvi {         // every problem selects from the same EVI row list
+    const float* evi; const DatePlan* plan;
+    __device__ int count() const { return plan->nrows; }
+    __device__ bool get(int, int p, float& v) const { v = evi[p]; return true; }
+};
+struct SrcBlueRed {     // q = band2*2 + rank ; band2 0 -> mosaic blue, 1 -> mosaic red ; set = ~only1
+    const float* mosaic; const unsigned char* only1; int npix;
+    __device__ int count() const { return npix; }
+    __device__ bool get(int q, int p, float& v) const {
+        if (only1[p]) return false;
+        v = mosaic[(long)p * 10 + ((q >> 1) ? 2 : 0)];
+        return true;
+    }
+};
+
+template <class SRC>
+__global__ void k_sel_hist(SRC s, const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
     __shared__ unsigned h[256];
-    const int q = blockIdx.y, band = q >> 2, which = (q >> 1) & 1;
+    const int q = blockIdx.y;
     h[threadIdx.x] = 0;
     __syncthreads();
     const SelState ss = st[q];
-    const float* src = which ? s.b : s.a;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npix; p += gridDim.x * blockDim.x) {
-        if (!s.valid[p]) continue;
-        const unsigned k = fkey(src[(long)p * s.stride + band]);
+    const int n = s.count();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        float v;
+        if (!s.get(q, p, v)) continue;
+        const unsigned k = fkey(v);
         if ((k & ss.mask) == ss.prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
     }
     __syncthreads();
@@ -249,17 +275,44 @@ __global__ void k_sel_pick(SelState* __restrict__ st, int shift, unsigned* __res
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[q * 256 + i] = 0;
 }
+// ranks from a DEVICE count: mode 0 -> the two middle order statistics (median); mode 1 -> floor / floor+1 of
+// numpy's linear-interpolation position pct/100 * (n - 1).  n = *n_ptr, or n_total - *n_ptr when complement.
+struct PctList { double pct[8]; };
+__global__ void k_sel_init(SelState* __restrict__ st, int nprob, const int* __restrict__ n_ptr, int n_total, int complement,
+                           int mode, PctList pl) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nprob) return;
+    long long n = complement ? (long long)n_total - *n_ptr : *n_ptr;
+    SelState ss; ss.prefix = 0; ss.mask = 0; ss.k = 0;
+    if (n > 0) {
+        if (mode == 0) ss.k = (q & 1) ? n / 2 : (n - 1) / 2;
+        else {
+            const double pos = pl.pct[q >> 1] / 100.0 * (double)(n - 1);
+            long long lo = (long long)floor(pos) + (q & 1);
+            ss.k = lo > n - 1 ? n - 1 : lo;
+        }
+    }
+    st[q] = ss;
+}
+template <class SRC>
+static hipError_t radix_select(SRC src, SelState* st, unsigned* hist, int nprob, hipStream_t s) {
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL((k_sel_hist<SRC>), dim3(96, nprob), dim3(256), 0, s, src, st, shift, hist);
+        hipLaunchKernelGGL(k_sel_pick, dim3(nprob), dim3(64), 0, s, st, shift, hist);
+    }
+    return hipGetLastError();
+}
 
-// mean / variance of the valid elements (two passes in double), 20 problems = (band, which)
-__global__ void k_stat_sum(SelSrc s, const double* __restrict__ mean, double* __restrict__ out) {
-    const int q = blockIdx.y, band = q >> 1, which = q & 1;
-    const float* src = which ? s.b : s.a;
-    const double m = mean ? mean[q] : 0.0;
+// sum (pass 0) / sum of squared deviations from sum/n (pass 1) of the valid elements, 20 problems = (band, which)
+__global__ void k_stat_sum(SrcMosaic s, const double* __restrict__ sum, const int* __restrict__ count, double* __restrict__ out) {
+    const int q = blockIdx.y;
+    const double m = sum ? sum[q] / (double)max(*count, 1) : 0.0;
     double acc = 0.0;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < s.npix; p += gridDim.x * blockDim.x) {
-        if (!s.valid[p]) continue;
-        const double v = (double)src[(long)p * s.stride + band] - m;
-        acc += mean ? v * v : v;
+        float v;
+        if (!s.get(((q >> 1) << 2) | ((q & 1) << 1), p, v)) continue;
+        const double d = (double)v - m;
+        acc += sum ? d * d : d;
     }
     for (int k = 32; k >= 1; k >>= 1) acc += __shfl_xor(acc, k);
     if ((threadIdx.x & 63) == 0) atomicAdd(&out[q], acc);
@@ -389,7 +442,8 @@ __global__ void k_date_counts(const float* __restrict__ w, int npix, int date, i
 }
 // training rows of dates [t0, t1): pixels with w_t == 0 and not water, in (t, pixel) order -- 2-level scan compaction
 __global__ void k_rows_count(const float* __restrict__ w, const unsigned char* __restrict__ water, int npix, int t0, int nt,
-                             int* __restrict__ blk) {
+                             const DatePlan* __restrict__ plan, int* __restrict__ blk) {
+    if (plan) { t0 = plan->t0; nt = plan->nt; }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0;
     if (i < (long)nt * npix) { const int t = t0 + (int)(i / npix), p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
@@ -425,8 +479,9 @@ __global__ void k_rows_scan(int* __restrict__ blk, int nblk, int* __restrict__ t
     if (threadIdx.x == 0) *total = carry;
 }
 __global__ void k_rows_fill(const float* __restrict__ w, const unsigned char* __restrict__ water, const float* __restrict__ tiles,
-                            int npix, int t0, int nt, const int* __restrict__ blk, int* __restrict__ rows,
-                            float* __restrict__ evi) {
+                            int npix, int t0, int nt, const DatePlan* __restrict__ plan, const int* __restrict__ blk,
+                            int* __restrict__ rows, float* __restrict__ evi) {
+    if (plan) { t0 = plan->t0; nt = plan->nt; }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0, t = 0, p = 0;
     if (i < (long)nt * npix) { t = t0 + (int)(i / npix); p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
@@ -446,11 +501,13 @@ __global__ void k_rows_fill(const float* __restrict__ w, const unsigned char* __
 struct GramArgs {
     const float* tiles; const float* mosaic; const float* snow; const int* rows; const int* sample; const float* weight;
     long nsample; int npix; int t0;
+    const DatePlan* plan;     // device-controlled launch: nsample = plan->nrows, t0 = plan->t0
 };
 __global__ __launch_bounds__(256) void k_gram(GramArgs a, double* __restrict__ partial) {
     __shared__ float zs[64][33];
     __shared__ float ws[64];
     double acc[4] = {0, 0, 0, 0};
+    if (a.plan) { a.nsample = a.plan->nrows; a.t0 = a.plan->t0; }
     const int tid = threadIdx.x;
     const int r0 = tid >> 3, c0 = (tid & 7) * 4;          // thread owns Z'Z[r0][c0..c0+3]
     for (long base = (long)blockIdx.x * 64; base < a.nsample; base += (long)gridDim.x * 64) {
@@ -506,7 +563,7 @@ __global__ void k_row_weights(const float* __restrict__ evi, int n, Strata st, f
 // tile = tile * (1 - w) + pred * w
 struct Beta { double b[10][11]; int fitted; };
 __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restrict__ w, const float* __restrict__ mosaic,
-                                const float* __restrict__ snow, Beta be, int npix, int date) {
+                                const float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -515,6 +572,7 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
     float* tv = tiles + ((long)date * npix + p) * 10;
     const float* mv = mosaic + (long)p * 10;
     const double sn = (double)snow[p];
+    const Beta& be = *bep;
     for (int c = 0; c < 10; ++c) {
         float pred = mv[c];
         if (be.fitted) {
@@ -548,13 +606,13 @@ __global__ void k_not(const unsigned char* __restrict__ in, int n, unsigned char
     if (p < n) out[p] = !in[p];
 }
 __global__ void k_cloud_flags(const float* __restrict__ mosaic, const unsigned char* __restrict__ only1,
-                              const unsigned char* __restrict__ pf_dil, float ref_blue, float ref_red, int npix,
+                              const unsigned char* __restrict__ pf_dil, const float* __restrict__ thr, int npix,
                               unsigned char* __restrict__ out) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
     const float* m = mosaic + (long)p * 10;
-    bool c = (m[0] > ref_blue) && (m[2] > ref_red) && only1[p] && (((m[0] + m[1]) + m[2]) < 1.0f);
+    bool c = (m[0] > thr[0]) && (m[2] > thr[1]) && only1[p] && (((m[0] + m[1]) + m[2]) < 1.0f);
     if (pf_dil[p]) c = false;
     out[p] = c;
 }
@@ -568,8 +626,87 @@ __global__ void k_u8_from_bool(const unsigned char* __restrict__ in, int n, unsi
     if (p < n) out[p] = in[p] != 0;
 }
 
-// ---- host: Lawson-Hanson NNLS on the normal equations (n = 11) ---------------------------------
-void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
+// ---- device-side control of the per-date fit (no host round trips) --------------------------------
+__global__ void k_date_plan(const int* __restrict__ counters, int npix, int T, int date, DatePlan* __restrict__ plan,
+                            int* __restrict__ remove_flags) {
+    if (threadIdx.x) return;
+    const int c0 = counters[0], c1 = counters[1], c2 = counters[2];
+    DatePlan p;
+    p.proceed = c0 > 0 && c1 > 0 && ((double)c2 / npix) > 0.01;                 // CR.py:377-378
+    if (c1 > 40000) { p.t0 = date; p.nt = 1; }                                     // CR.py:394-402
+    else {
+        const int a = max(date == T - 1 ? date - 2 : date - 1, 0), b = min(date + 2, T);
+        p.t0 = a; p.nt = b - a;
+    }
+    if (!p.proceed) p.nt = 0;
+    p.nrows = 0; p.fitted = 0;
+    *plan = p;
+    remove_flags[date] = (c2 == 0);                                                // CR.py:958-959
+}
+struct StrataDev { float b[6]; int cnt[5]; };
+__global__ void k_strata_thresholds(const SelState* __restrict__ st, const DatePlan* __restrict__ plan, PctList pl,
+                                    StrataDev* __restrict__ sd) {
+    if (threadIdx.x) return;
+    const long long n = plan->nrows;
+    for (int k = 0; k < 6; ++k) {
+        const double pos = n > 0 ? pl.pct[k] / 100.0 * (double)(n - 1) : 0.0;
+        const double a = fkey_inv(st[2 * k].prefix), b = fkey_inv(st[2 * k + 1].prefix);
+        sd->b[k] = (float)(a + (b - a) * (pos - floor(pos)));
+    }
+    for (int k = 0; k < 5; ++k) sd->cnt[k] = 0;
+}
+__device__ __forceinline__ int stratum_of(float e, const float* b) { return e < b[1] ? 0 : (e < b[2] ? 1 : (e < b[3] ? 2 : (e < b[4] ? 3 : 4))); }
+__global__ void k_strata_count(const float* __restrict__ evi, const DatePlan* __restrict__ plan, StrataDev* __restrict__ sd) {
+    __shared__ int c[5];
+    if (threadIdx.x < 5) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = plan->nrows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&c[stratum_of(evi[i], sd->b)], 1);
+    __syncthreads();
+    if (threadIdx.x < 5 && c[threadIdx.x]) atomicAdd(&sd->cnt[threadIdx.x], c[threadIdx.x]);
+}
+__global__ void k_row_weights_dev(const float* __restrict__ evi, const DatePlan* __restrict__ plan, const StrataDev* __restrict__ sd,
+                                  float* __restrict__ weight) {
+    const int n = plan->nrows;
+    const double n_i = (double)(min(90000, n) / 5);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float e = evi[i];
+        const int cn = sd->cnt[stratum_of(e, sd->b)];
+        float w = cn > 0 ? (float)fmin(1.0, n_i / (double)cn) : 0.f;
+        if (e < sd->b[0]) w += 10.f;
+        if (e >= sd->b[5]) w += 10.f;
+        weight[i] = w;
+    }
+}
+__host__ __device__ void nnls_gram(const double G[11][11], const double g[11], double x[11]);
+__global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan, Beta* __restrict__ be) {
+    const int band = threadIdx.x;
+    if (band < 10) {
+        int col[11];
+        for (int j = 0; j < 11; ++j) col[j] = (j < band && j < 10) ? j : 11 + j;   // CR.py:522 / :550
+        double G[11][11], g[11], x[11];
+        for (int i = 0; i < 11; ++i) {
+            for (int j = 0; j < 11; ++j) G[i][j] = Z[col[i] * 32 + col[j]];
+            g[i] = Z[col[i] * 32 + 22 + band];
+        }
+        nnls_gram(G, g, x);
+        for (int j = 0; j < 11; ++j) be->b[band][j] = x[j];
+    }
+    if (band == 0) { const int f = plan->proceed && plan->nrows > 0; be->fitted = f; plan->fitted = f; }
+}
+__global__ void k_cloud_thresholds(const SelState* __restrict__ st, const int* __restrict__ n_only, int npix, float* __restrict__ thr) {
+    if (threadIdx.x) return;
+    const long long n = (long long)npix - *n_only;
+    if (n <= 0) { thr[0] = INFINITY; thr[1] = INFINITY; return; }                 // CR.py:718-719: no reference pixels
+    const double pos = 0.99 * (double)(n - 1), fr = pos - floor(pos);
+    for (int k = 0; k < 2; ++k) {
+        const double a = fkey_inv(st[2 * k].prefix), b = fkey_inv(st[2 * k + 1].prefix);
+        thr[k] = (float)(a + (b - a) * fr);
+    }
+}
+
+// ---- Lawson-Hanson NNLS on the normal equations (n = 11), host and device ----------------------
+__host__ __device__ void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
     const int n = 11;
     bool P[11] = {false};
     for (int i = 0; i < n; ++i) x[i] = 0.0;
@@ -577,7 +714,7 @@ void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
     for (int iter = 0; iter < 3 * n; ++iter) {
         for (int i = 0; i < n; ++i) { double s = g[i]; for (int j = 0; j < n; ++j) s -= G[i][j] * x[j]; wv[i] = s; }
         int best = -1; double bw = 0.0;
-        const double tol = 1e-12 * std::fabs(g[0] + 1e-300) + 1e-15;
+        const double tol = 1e-12 * fabs(g[0] + 1e-300) + 1e-15;
         for (int i = 0; i < n; ++i) if (!P[i] && wv[i] > tol && wv[i] > bw) { bw = wv[i]; best = i; }
         if (best < 0) break;
         P[best] = true;
@@ -589,10 +726,10 @@ void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
             for (int r = 0; r < m; ++r) { for (int c2 = 0; c2 < m; ++c2) A[r][c2] = G[idx[r]][idx[c2]]; A[r][m] = g[idx[r]]; }
             for (int c2 = 0; c2 < m; ++c2) {
                 int piv = c2;
-                for (int r = c2 + 1; r < m; ++r) if (std::fabs(A[r][c2]) > std::fabs(A[piv][c2])) piv = r;
-                if (piv != c2) for (int k = 0; k <= m; ++k) std::swap(A[piv][k], A[c2][k]);
+                for (int r = c2 + 1; r < m; ++r) if (fabs(A[r][c2]) > fabs(A[piv][c2])) piv = r;
+                if (piv != c2) for (int k = 0; k <= m; ++k) { const double tv = A[piv][k]; A[piv][k] = A[c2][k]; A[c2][k] = tv; }
                 const double d = A[c2][c2];
-                if (std::fabs(d) < 1e-300) continue;
+                if (fabs(d) < 1e-300) continue;
                 for (int r = 0; r < m; ++r) {
                     if (r == c2) continue;
                     const double f = A[r][c2] / d;
@@ -601,7 +738,7 @@ void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
             }
             double sfull[11] = {0};
             bool allpos = true;
-            for (int r = 0; r < m; ++r) { const double d = A[r][r]; sfull[idx[r]] = std::fabs(d) < 1e-300 ? 0.0 : A[r][m] / d; if (sfull[idx[r]] <= 0.0) allpos = false; }
+            for (int r = 0; r < m; ++r) { const double d = A[r][r]; sfull[idx[r]] = fabs(d) < 1e-300 ? 0.0 : A[r][m] / d; if (sfull[idx[r]] <= 0.0) allpos = false; }
             if (allpos) { for (int i = 0; i < n; ++i) x[i] = P[i] ? sfull[i] : 0.0; break; }
             double alpha = 1.0;
             for (int r = 0; r < m; ++r) { const int i = idx[r]; if (sfull[i] <= 0.0) { const double a = x[i] / (x[i] - sfull[i]); if (a < alpha) alpha = a; } }
@@ -710,28 +847,14 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     for (int i = 0; i < T; ++i) {
         TTC_HIP(c, hipMemsetAsync(count, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_mosaic_ref, grid, blk, 0, s, d_tiles, d_w, water, T, npix, i, ref, valid, count);
-        // the selection ranks depend on the count -> one small D2H per date
-        int n = 0;
-        TTC_HIP(c, hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, s));
-        TTC_HIP(c, hipStreamSynchronize(s));
-        if (n > 1000) {
-            SelState h[40];
-            for (int q = 0; q < 40; ++q) { h[q].prefix = 0; h[q].mask = 0; h[q].k = (q & 1) ? n / 2 : (n - 1) / 2; }
-            TTC_HIP(c, hipMemcpyAsync(st, h, sizeof(h), hipMemcpyHostToDevice, s));
-            SelSrc src{ref, d_tiles + (long)i * npix * 10, valid, npix, 10};
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                hipLaunchKernelGGL(k_sel_hist, dim3(96, 40), dim3(256), 0, s, src, st, shift, hist);
-                hipLaunchKernelGGL(k_sel_pick, dim3(40), dim3(64), 0, s, st, shift, hist);
-            }
-            TTC_HIP(c, hipMemsetAsync(mean, 0, sizeof(double) * 40, s));
-            hipLaunchKernelGGL(k_stat_sum, dim3(96, 20), dim3(256), 0, s, src, (const double*)nullptr, mean);
-            double hm[20];
-            TTC_HIP(c, hipMemcpyAsync(hm, mean, sizeof(hm), hipMemcpyDeviceToHost, s));
-            TTC_HIP(c, hipStreamSynchronize(s));
-            for (int q = 0; q < 20; ++q) hm[q] /= (double)n;
-            TTC_HIP(c, hipMemcpyAsync(mean, hm, sizeof(hm), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_stat_sum, dim3(96, 20), dim3(256), 0, s, src, (const double*)mean, var);
-        }
+        // device-side control: selection ranks, means and the n > 1000 decision all read the device count,
+        // so the whole mosaic is enqueued without a host round trip
+        hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, st, 40, count, 0, 0, 0, PctList{});
+        SrcMosaic src{ref, d_tiles + (long)i * npix * 10, valid, npix};
+        TTC_HIP(c, radix_select(src, st, hist, 40, s));
+        TTC_HIP(c, hipMemsetAsync(mean, 0, sizeof(double) * 40, s));
+        hipLaunchKernelGGL(k_stat_sum, dim3(96, 20), dim3(256), 0, s, src, (const double*)nullptr, count, mean);
+        hipLaunchKernelGGL(k_stat_sum, dim3(96, 20), dim3(256), 0, s, src, (const double*)mean, count, var);
         hipLaunchKernelGGL(k_align_params, dim3(1), dim3(64), 0, s, st, var, count, count + 1, ap);
         hipLaunchKernelGGL(k_mosaic_accum, grid, blk, 0, s, d_tiles, d_w, water, ap, npix, i, d_mosaic);
         TTC_HIP(c, hipGetLastError());
@@ -766,113 +889,91 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     TTC_CHECK(gapfill_feather(c, d_probs, T, X, Y, 20, 0, d_interp, s));                       // CR.py:910-923
     TTC_CHECK(gapfill_aligned_mosaic(c, d_tiles, d_interp, T, X, Y, mosaic, s));               // CR.py:925
     TTC_CHECK(water_mask(c, d_tiles, T, X, Y, true, false, water2, s));                        // CR.py:936-939
+    char* ctl = static_cast<char*>(c->scratch_buf("gf_ctl", 65536));
+    if (!ctl) return c->fail(TTC_ERR_NOMEM, "gap-fill control block");
+    DatePlan* plan = reinterpret_cast<DatePlan*>(ctl);                     // 32 B
+    Beta* d_beta = reinterpret_cast<Beta*>(ctl + 64);                      // 888 B
+    StrataDev* sd = reinterpret_cast<StrataDev*>(ctl + 1024);
+    SelState* st = reinterpret_cast<SelState*>(ctl + 2048);                // 12 problems
+    float* thr = reinterpret_cast<float*>(ctl + 3072);
+    int* remove_flags = reinterpret_cast<int*>(ctl + 3200);                // kMaxT ints
+    unsigned* hist = reinterpret_cast<unsigned*>(ctl + 4096);              // 12 * 256 * 4 = 12288 B
+    double* Zdev = gpart + 1024L * gram_blocks;
+    TTC_HIP(c, hipMemsetAsync(ctl, 0, 4096 + 12288, s));
+    const PctList pl6{{2, 20, 40, 60, 80, 98, 0, 0}};
+    const int nb3 = (int)((3L * npix + 255) / 256);
+
     KTimer kt(c, "gapfill_dates", s);
     std::vector<float> h_evi;
     std::vector<int64_t> h_idx;
-    int* d_sample = nullptr;
     for (int date = 0; date < T; ++date) {
         hipLaunchKernelGGL(k_snow_mean, grid, b256, 0, s, d_tiles, T, npix, snow);            // CR.py:372 (tiles mutate per date)
-        TTC_HIP(c, hipMemsetAsync(counters, 0, sizeof(int) * 8, s));
+        TTC_HIP(c, hipMemsetAsync(counters, 0, sizeof(int) * 4, s));
         hipLaunchKernelGGL(k_date_counts, dim3(64), b256, 0, s, d_interp, npix, date, counters);
-        int hc[3];
-        TTC_HIP(c, hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
-        TTC_HIP(c, hipStreamSynchronize(s));
-        Beta be{};
-        be.fitted = 0;
-        const bool proceed = hc[0] > 0 && hc[1] > 0 && ((double)hc[2] / npix) > 0.01;        // CR.py:377-378
-        if (proceed) {
-            int t0, t1;
-            if (hc[1] > 40000) { t0 = date; t1 = date + 1; }                                   // CR.py:394-402
-            else { t0 = std::max(date == T - 1 ? date - 2 : date - 1, 0); t1 = std::min(date + 2, T); }
-            const int nt = t1 - t0;
-            const int nb = (int)(((long)nt * npix + 255) / 256);
-            hipLaunchKernelGGL(k_rows_count, dim3(nb), b256, 0, s, d_interp, water2, npix, t0, nt, blk);
-            hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, blk, nb, counters + 3);
-            hipLaunchKernelGGL(k_rows_fill, dim3(nb), b256, 0, s, d_interp, water2, d_tiles, npix, t0, nt, blk, rows, evi);
-            int nrows = 0;
-            TTC_HIP(c, hipMemcpyAsync(&nrows, counters + 3, sizeof(int), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, counters, npix, T, date, plan, remove_flags);
+        // training rows of the 1 or 3 dates the plan names, in (t, pixel) order
+        hipLaunchKernelGGL(k_rows_count, dim3(nb3), b256, 0, s, d_interp, water2, npix, 0, 0, plan, blk);
+        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, blk, nb3, &plan->nrows);
+        hipLaunchKernelGGL(k_rows_fill, dim3(nb3), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plan, blk, rows, evi);
+        GramArgs ga{d_tiles, mosaic, snow, rows, nullptr, nullptr, 0, npix, 0, plan};
+        if (sampler) {
+            // reference replay: host round trip through the callback, which returns row indices
+            DatePlan hp;
+            TTC_HIP(c, hipMemcpyAsync(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost, s));
             TTC_HIP(c, hipStreamSynchronize(s));
-            if (nrows > 0) {
-                h_evi.resize(nrows);
-                TTC_HIP(c, hipMemcpyAsync(h_evi.data(), evi, sizeof(float) * nrows, hipMemcpyDeviceToHost, s));
+            if (hp.proceed && hp.nrows > 0) {
+                h_evi.resize(hp.nrows);
+                TTC_HIP(c, hipMemcpyAsync(h_evi.data(), evi, sizeof(float) * hp.nrows, hipMemcpyDeviceToHost, s));
                 TTC_HIP(c, hipStreamSynchronize(s));
-                GramArgs ga{d_tiles, mosaic, snow, rows, nullptr, nullptr, nrows, npix, t0};
-                if (sampler) {
-                    // reference replay: the callback returns row indices (with repeats), at most 2.5 * nrows of them
-                    h_idx.resize((size_t)nrows * 3 + 16);
-                    const int64_t ns = sampler(h_evi.data(), nrows, h_idx.data(), (int64_t)h_idx.size(), user);
-                    if (ns <= 0 || ns > (int64_t)h_idx.size()) return c->fail(TTC_ERR_ARG, "sampler callback returned a bad count");
-                    std::vector<int> idx32(ns);
-                    for (int64_t i = 0; i < ns; ++i) {
-                        if (h_idx[i] < 0 || h_idx[i] >= nrows) return c->fail(TTC_ERR_ARG, "sampler callback returned an out-of-range row");
-                        idx32[i] = (int)h_idx[i];
-                    }
-                    d_sample = static_cast<int*>(c->scratch_buf("gf_sample", sizeof(int) * (size_t)ns));
-                    if (!d_sample) return c->fail(TTC_ERR_NOMEM, "sample buffer");
-                    TTC_HIP(c, hipMemcpyAsync(d_sample, idx32.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
-                    TTC_HIP(c, hipStreamSynchronize(s));
-                    ga.sample = d_sample; ga.nsample = ns;
-                } else {
-                    // expected multiplicities: strata thresholds from the host copy of EVI (numpy-style percentiles)
-                    std::vector<float> tmp(h_evi);
-                    Strata stt{};
-                    float* bp[6] = {&stt.b2, &stt.b20, &stt.b40, &stt.b60, &stt.b80, &stt.b98};
-                    const double qs[6] = {2, 20, 40, 60, 80, 98};
-                    for (int k = 0; k < 6; ++k) *bp[k] = percentile_host(tmp, qs[k]);
-                    long cnt[5] = {0, 0, 0, 0, 0};
-                    for (float e : h_evi) cnt[e < stt.b20 ? 0 : (e < stt.b40 ? 1 : (e < stt.b60 ? 2 : (e < stt.b80 ? 3 : 4)))]++;
-                    const long n_i = std::min<long>(90000, nrows) / 5;
-                    for (int k = 0; k < 5; ++k) stt.wq[k] = cnt[k] > 0 ? (float)std::min(1.0, (double)n_i / (double)cnt[k]) : 0.f;
-                    hipLaunchKernelGGL(k_row_weights, dim3((nrows + 255) / 256), b256, 0, s, evi, nrows, stt, weight);
-                    ga.weight = weight;
+                h_idx.resize((size_t)hp.nrows * 3 + 16);
+                const int64_t ns = sampler(h_evi.data(), hp.nrows, h_idx.data(), (int64_t)h_idx.size(), user);
+                if (ns <= 0 || ns > (int64_t)h_idx.size()) return c->fail(TTC_ERR_ARG, "sampler callback returned a bad count");
+                std::vector<int> idx32(ns);
+                for (int64_t i = 0; i < ns; ++i) {
+                    if (h_idx[i] < 0 || h_idx[i] >= hp.nrows) return c->fail(TTC_ERR_ARG, "sampler callback returned an out-of-range row");
+                    idx32[i] = (int)h_idx[i];
                 }
-                hipLaunchKernelGGL(k_gram, dim3(gram_blocks), b256, 0, s, ga, gpart);
-                hipLaunchKernelGGL(k_gram_reduce, dim3(4), b256, 0, s, gpart, gram_blocks, gpart + 1024L * gram_blocks);
-                double Z[32][32];
-                TTC_HIP(c, hipMemcpyAsync(Z, gpart + 1024L * gram_blocks, sizeof(Z), hipMemcpyDeviceToHost, s));
+                int* d_sample = static_cast<int*>(c->scratch_buf("gf_sample", sizeof(int) * (size_t)ns));
+                if (!d_sample) return c->fail(TTC_ERR_NOMEM, "sample buffer");
+                TTC_HIP(c, hipMemcpyAsync(d_sample, idx32.data(), sizeof(int) * ns, hipMemcpyHostToDevice, s));
                 TTC_HIP(c, hipStreamSynchronize(s));
-                for (int band = 0; band < 10; ++band) {
-                    // design column j: clipped copy (Z col j) for j < band, raw (Z col 11 + j) otherwise (CR.py:522, :550)
-                    int col[11];
-                    for (int j = 0; j < 11; ++j) col[j] = (j < band && j < 10) ? j : 11 + j;
-                    double G[11][11], g[11];
-                    for (int i = 0; i < 11; ++i) {
-                        for (int j = 0; j < 11; ++j) G[i][j] = Z[col[i]][col[j]];
-                        g[i] = Z[col[i]][22 + band];
-                    }
-                    nnls_gram(G, g, be.b[band]);
-                }
-                be.fitted = 1;
+                ga.sample = d_sample; ga.nsample = ns; ga.t0 = hp.t0; ga.plan = nullptr;
             }
+        } else {
+            // expected multiplicities: EVI percentiles by radix select, strata counts and weights, all on the device
+            hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, st, 12, &plan->nrows, 0, 0, 1, pl6);
+            TTC_HIP(c, radix_select(SrcEvi{evi, plan}, st, hist, 12, s));
+            hipLaunchKernelGGL(k_strata_thresholds, dim3(1), dim3(64), 0, s, st, plan, pl6, sd);
+            hipLaunchKernelGGL(k_strata_count, dim3(128), b256, 0, s, evi, plan, sd);
+            hipLaunchKernelGGL(k_row_weights_dev, dim3(256), b256, 0, s, evi, plan, sd, weight);
+            ga.weight = weight;
         }
-        hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, be, npix, date);
+        hipLaunchKernelGGL(k_gram, dim3(gram_blocks), b256, 0, s, ga, gpart);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(4), b256, 0, s, gpart, gram_blocks, Zdev);
+        hipLaunchKernelGGL(k_nnls, dim3(1), dim3(64), 0, s, Zdev, plan, d_beta);               // 10 fits of 11 unknowns
+        hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, d_beta, npix, date);
         TTC_HIP(c, hipGetLastError());
-        if (hc[2] == 0 && h_to_remove && n_to_remove) h_to_remove[(*n_to_remove)++] = date;   // mean(w == 1) == 1 (CR.py:958-959)
     }
     // a9: clouds that survive in the mosaic (CR.py:964-968)
     unsigned char *only1 = bits, *pfd = bits + npix, *cl = bits + 2 * (size_t)npix, *tmp = bits + 3 * (size_t)npix;
     if (d_pfcps) hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, d_pfcps, X, Y, 10, 0, pfd);
     else TTC_HIP(c, hipMemsetAsync(pfd, 0, npix, s));
-    TTC_HIP(c, hipMemsetAsync(counters + 4, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_only1, grid, b256, 0, s, d_interp, pfd, T, npix, only1, counters + 4);
-    int n_only = 0;
-    TTC_HIP(c, hipMemcpyAsync(&n_only, counters + 4, sizeof(int), hipMemcpyDeviceToHost, s));
-    TTC_HIP(c, hipStreamSynchronize(s));
-    if (n_only < npix) {
-        std::vector<float> hm((size_t)npix * 10);
-        std::vector<unsigned char> ho(npix);
-        TTC_HIP(c, hipMemcpyAsync(hm.data(), mosaic, sizeof(float) * hm.size(), hipMemcpyDeviceToHost, s));
-        TTC_HIP(c, hipMemcpyAsync(ho.data(), only1, npix, hipMemcpyDeviceToHost, s));
-        TTC_HIP(c, hipStreamSynchronize(s));
-        std::vector<float> blue, red;
-        blue.reserve(npix); red.reserve(npix);
-        for (int p = 0; p < npix; ++p) if (!ho[p]) { blue.push_back(hm[(size_t)p * 10]); red.push_back(hm[(size_t)p * 10 + 2]); }
-        const float rb = percentile_host(blue, 99.0), rr = percentile_host(red, 99.0);
-        hipLaunchKernelGGL(k_cloud_flags, grid, b256, 0, s, mosaic, only1, pfd, rb, rr, npix, cl);
-        hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, cl, X, Y, 3, 1, tmp);     // dilate(1 - c, 3)
-        hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, tmp, X, Y, 8, 1, cl);      // dilate(1 - that, 8)
-        hipLaunchKernelGGL(k_add_clouds, grid, b256, 0, s, d_interp, cl, T, npix);
-    }
+    TTC_HIP(c, hipMemsetAsync(counters, 0, sizeof(int) * 4, s));
+    hipLaunchKernelGGL(k_only1, grid, b256, 0, s, d_interp, pfd, T, npix, only1, counters);
+    const PctList pl99{{99, 99, 0, 0, 0, 0, 0, 0}};
+    hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, st, 4, counters, npix, 1, 1, pl99);
+    TTC_HIP(c, radix_select(SrcBlueRed{mosaic, only1, npix}, st, hist, 4, s));
+    hipLaunchKernelGGL(k_cloud_thresholds, dim3(1), dim3(64), 0, s, st, counters, npix, thr);
+    hipLaunchKernelGGL(k_cloud_flags, grid, b256, 0, s, mosaic, only1, pfd, thr, npix, cl);
+    hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, cl, X, Y, 3, 1, tmp);              // dilate(1 - c, 3)
+    hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, tmp, X, Y, 8, 1, cl);               // dilate(1 - that, 8)
+    hipLaunchKernelGGL(k_add_clouds, grid, b256, 0, s, d_interp, cl, T, npix);
     TTC_HIP(c, hipGetLastError());
+    if (h_to_remove && n_to_remove) {          // the only host read-back; skipped when the caller does not ask
+        int flags[kMaxT];
+        TTC_HIP(c, hipMemcpyAsync(flags, remove_flags, sizeof(int) * T, hipMemcpyDeviceToHost, s));
+        TTC_HIP(c, hipStreamSynchronize(s));
+        for (int t = 0; t < T; ++t) if (flags[t]) h_to_remove[(*n_to_remove)++] = t;
+    }
     return TTC_OK;
 }
