@@ -263,17 +263,27 @@ __global__ void k_sel_hist(SRC s, const SelState* __restrict__ st, int shift, un
     if (h[threadIdx.x]) atomicAdd(&hist[q * 256 + threadIdx.x], h[threadIdx.x]);
 }
 __global__ void k_sel_pick(SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
-    const int q = blockIdx.x;
-    if (threadIdx.x == 0) {
-        SelState ss = st[q];
-        long long k = ss.k;
+    // one wave per problem: lane l owns bins 4l..4l+3; wave prefix sum finds the bin holding rank k
+    const int q = blockIdx.x, lane = threadIdx.x;
+    unsigned c[4];
+    unsigned mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = hist[q * 256 + 4 * lane + j]; mine += c[j]; hist[q * 256 + 4 * lane + j] = 0; }
+    unsigned incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const long long excl = (long long)incl - mine;
+    SelState ss = st[q];
+    const long long k = ss.k;
+    const bool here = k >= excl && k < (long long)incl;
+    const unsigned long long m = __ballot(here);
+    const int owner = m ? __ffsll((long long)m) - 1 : 63;       // ranks past the last element (empty set) fall in the last bin
+    if (lane == owner) {
+        long long r = k - excl;
         int b = 0;
-        for (; b < 255; ++b) { const unsigned c = hist[q * 256 + b]; if (k < (long long)c) break; k -= c; }
-        ss.prefix |= (unsigned)b << shift; ss.mask |= 255u << shift; ss.k = k;
+        for (; b < 3; ++b) { if (r < (long long)c[b]) break; r -= c[b]; }
+        ss.prefix |= (unsigned)(4 * lane + b) << shift; ss.mask |= 255u << shift; ss.k = m ? r : 0;
         st[q] = ss;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[q * 256 + i] = 0;
 }
 // ranks from a DEVICE count: mode 0 -> the two middle order statistics (median); mode 1 -> floor / floor+1 of
 // numpy's linear-interpolation position pct/100 * (n - 1).  n = *n_ptr, or n_total - *n_ptr when complement.
@@ -541,11 +551,19 @@ __global__ __launch_bounds__(256) void k_gram(GramArgs a, double* __restrict__ p
     for (int k = 0; k < 4; ++k) partial[(long)blockIdx.x * 1024 + r0 * 32 + c0 + k] = acc[k];
 }
 __global__ void k_gram_reduce(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 1024) return;
+    // 16 Z'Z entries per workgroup (coalesced along the entry index), 16 lanes split the blocks of each entry
+    __shared__ double red[16][17];
+    const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * 1024 + i];
-    out[i] = s;
+    for (int b = part; b < nblk; b += 16) s += partial[(long)b * 1024 + i];
+    red[part][e] = s;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k][e];      // fixed order: deterministic
+        out[i] = t;
+    }
 }
 // expected multiplicity of a row under the reference's stratified sampling (CR.py:453-496), from EVI thresholds
 struct Strata { float b2, b20, b40, b60, b80, b98; float wq[5]; };
@@ -680,19 +698,23 @@ __global__ void k_row_weights_dev(const float* __restrict__ evi, const DatePlan*
 }
 __host__ __device__ void nnls_gram(const double G[11][11], const double g[11], double x[11]);
 __global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan, Beta* __restrict__ be) {
-    const int band = threadIdx.x;
-    if (band < 10) {
+    // one workgroup per band (10 launched): the 32x32 Gram matrix is staged in LDS, lane 0 runs the active-set loop
+    __shared__ double Zs[32 * 32];
+    const int band = blockIdx.x;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) Zs[i] = Z[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int col[11];
         for (int j = 0; j < 11; ++j) col[j] = (j < band && j < 10) ? j : 11 + j;   // CR.py:522 / :550
         double G[11][11], g[11], x[11];
         for (int i = 0; i < 11; ++i) {
-            for (int j = 0; j < 11; ++j) G[i][j] = Z[col[i] * 32 + col[j]];
-            g[i] = Z[col[i] * 32 + 22 + band];
+            for (int j = 0; j < 11; ++j) G[i][j] = Zs[col[i] * 32 + col[j]];
+            g[i] = Zs[col[i] * 32 + 22 + band];
         }
         nnls_gram(G, g, x);
         for (int j = 0; j < 11; ++j) be->b[band][j] = x[j];
+        if (band == 0) { const int f = plan->proceed && plan->nrows > 0; be->fitted = f; plan->fitted = f; }
     }
-    if (band == 0) { const int f = plan->proceed && plan->nrows > 0; be->fitted = f; plan->fitted = f; }
 }
 __global__ void k_cloud_thresholds(const SelState* __restrict__ st, const int* __restrict__ n_only, int npix, float* __restrict__ thr) {
     if (threadIdx.x) return;
@@ -879,7 +901,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     float* weight = static_cast<float*>(c->scratch_buf("gf_weight", sizeof(float) * 3 * (size_t)npix));
     const int nblk_rows = (3 * npix + 255) / 256;
     int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * (nblk_rows + 16)));
-    const int gram_blocks = 512;
+    const int gram_blocks = 256;
     double* gpart = static_cast<double*>(c->scratch_buf("gf_gram", sizeof(double) * 1024 * (gram_blocks + 1)));
     if (!mosaic || !snow || !water2 || !bits || !rows || !evi || !weight || !blk || !gpart) return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
     int* counters = blk + nblk_rows;                                     // [0..2] date counts, [3] total rows, [4] n_only
@@ -949,8 +971,8 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
             ga.weight = weight;
         }
         hipLaunchKernelGGL(k_gram, dim3(gram_blocks), b256, 0, s, ga, gpart);
-        hipLaunchKernelGGL(k_gram_reduce, dim3(4), b256, 0, s, gpart, gram_blocks, Zdev);
-        hipLaunchKernelGGL(k_nnls, dim3(1), dim3(64), 0, s, Zdev, plan, d_beta);               // 10 fits of 11 unknowns
+        hipLaunchKernelGGL(k_gram_reduce, dim3(64), b256, 0, s, gpart, gram_blocks, Zdev);
+        hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Zdev, plan, d_beta);               // 10 fits of 11 unknowns
         hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, d_beta, npix, date);
         TTC_HIP(c, hipGetLastError());
     }
