@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttc_hip.so")
+LIB_PATH = os.environ.get("TTC_LIB", os.path.join(_HERE, "libttc_hip.so"))      # TTC_LIB: experiment builds only
 
 EXPORTS = [
     "ttc_version", "ttc_create", "ttc_destroy", "ttc_last_error", "ttc_device_bytes",

@@ -1,7 +1,7 @@
 """GPU-box probe: wall time of the gap-fill stage on a 618x618, T=12 tile (deterministic sampler)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ttc
 from ttc import job, synth, weights
 sess = job.TTCSession(weights.synth_weights(0), win_in=44, length=4, dsen2_weights=None)
