@@ -177,6 +177,15 @@ ttc_status ttc_superresolve_tile(ttc_ctx* ctx, float* d_s2, int32_t T, int32_t X
 ttc_status ttc_upsample_20m(ttc_ctx* ctx, const float* d_s2_10, const float* d_s2_20, int32_t T,
                             int32_t h, int32_t w, float* d_out, void* stream);
 
+/* ---- storage codecs / Sentinel-1 scaling ------------------------------------------------
+ * to_float32 (src/tof/tof_downloading.py:64-72): uint16 / 65535 -> float32;  to_int16 (:51-61):
+ * trunc(clip(x, 0, 1) * 65535) -> uint16.  n = element count. */
+ttc_status ttc_u16_to_float(ttc_ctx* ctx, const uint16_t* d_in, int64_t n, float* d_out, void* stream);
+ttc_status ttc_float_to_u16(ttc_ctx* ctx, const float* d_in, int64_t n, uint16_t* d_out, void* stream);
+/* Sentinel-1 preparation of process_tile (job.py:699-708): /65535, saturated (== 1) samples -> the image's
+ * median, convert_to_db(., 22) (job.py:74-89).  d_u16 [T, X, Y, 2] -> d_out [T, X, Y, 2] float32. */
+ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t X, int32_t Y, float* d_out, void* stream);
+
 /* ---- introspection for parity tests -------------------------------------------------
  * Copies a named internal activation (device) to host after synchronising the device.
  * Returns TTC_ERR_ARG for unknown names; *n_floats is the element count.  Test aid only. */

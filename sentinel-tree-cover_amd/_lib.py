@@ -21,6 +21,7 @@ EXPORTS = [
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
+    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -74,6 +75,9 @@ def load():
     lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
     lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
+    lib.ttc_u16_to_float.argtypes = [P, VP, C.c_int64, VP, VP]
+    lib.ttc_float_to_u16.argtypes = [P, VP, C.c_int64, VP, VP]
+    lib.ttc_s1_to_db.argtypes = [P, VP, I32, I32, I32, VP, VP]
     lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.ttc_debug_timing.argtypes = [P, I32]
     lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -231,6 +235,37 @@ class Context:
                                         C.c_void_p(u8.data_ptr()), C.c_void_p(f32.data_ptr()) if want_float else None,
                                         self._stream()), "ttc_mosaic")
         return u8, f32
+
+    # -- codecs ---------------------------------------------------------------------------
+    def to_float32(self, u16):
+        """uint16 numpy / cuda (viewed as int16 storage) -> cuda float32 (tof_downloading.py:64-72)"""
+        t = self.torch
+        a = u16 if isinstance(u16, t.Tensor) else t.from_numpy(np.ascontiguousarray(u16).view(np.int16))
+        a = a.to(f"cuda:{self.device}").contiguous()
+        out = t.empty(a.shape, dtype=t.float32, device=a.device)
+        self._check(self.lib.ttc_u16_to_float(self._h, C.c_void_p(a.data_ptr()), a.numel(), C.c_void_p(out.data_ptr()),
+                                              self._stream()), "ttc_u16_to_float")
+        return out
+
+    def to_int16(self, x):
+        """float32 -> uint16 (returned as a cuda int16 tensor holding the uint16 bit patterns)"""
+        t = self.torch
+        a = self._dev(x, t.float32)
+        out = t.empty(a.shape, dtype=t.int16, device=a.device)
+        self._check(self.lib.ttc_float_to_u16(self._h, C.c_void_p(a.data_ptr()), a.numel(), C.c_void_p(out.data_ptr()),
+                                              self._stream()), "ttc_float_to_u16")
+        return out
+
+    def s1_to_db(self, s1_u16):
+        """uint16 [T, X, Y, 2] -> cuda float32 dB-scaled (job.py:699-708)"""
+        t = self.torch
+        a = s1_u16 if isinstance(s1_u16, t.Tensor) else t.from_numpy(np.ascontiguousarray(s1_u16).view(np.int16))
+        a = a.to(f"cuda:{self.device}").contiguous()
+        T, X, Y = (int(v) for v in a.shape[:3])
+        out = t.empty(a.shape, dtype=t.float32, device=a.device)
+        self._check(self.lib.ttc_s1_to_db(self._h, C.c_void_p(a.data_ptr()), T, X, Y, C.c_void_p(out.data_ptr()),
+                                          self._stream()), "ttc_s1_to_db")
+        return out
 
     # -- cloud gap-fill ------------------------------------------------------------------
     def feather(self, mask, closing=20, clip=False):

@@ -21,6 +21,10 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
                                  ttc_sampler_fn sampler, void* user, float* d_interp, float* d_mosaic_out, int32_t* h_to_remove,
                                  int32_t* n_to_remove, hipStream_t s);
 
+ttc_status codec_u16_to_f32(ttc_ctx* c, const uint16_t* d_in, int64_t n, float* d_out, hipStream_t s);
+ttc_status codec_f32_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* d_out, hipStream_t s);
+ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s);
+
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
         float ms = 0.f;
@@ -149,6 +153,19 @@ ttc_status ttc_upsample_20m(ttc_ctx* c, const float* d_s2_10, const float* d_s2_
                             float* d_out, void* stream) {
     if (!c) return TTC_ERR_ARG;
     return upsample_20m(c, d_s2_10, d_s2_20, T, h, w, d_out, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_u16_to_float(ttc_ctx* c, const uint16_t* d_in, int64_t n, float* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return codec_u16_to_f32(c, d_in, n, d_out, static_cast<hipStream_t>(stream));
+}
+ttc_status ttc_float_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return codec_f32_to_u16(c, d_in, n, d_out, static_cast<hipStream_t>(stream));
+}
+ttc_status ttc_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int32_t T, int32_t X, int32_t Y, float* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return codec_s1_to_db(c, d_u16, T, X, Y, d_out, static_cast<hipStream_t>(stream));
 }
 
 ttc_status ttc_debug_fetch(ttc_ctx* c, const char* name, float* h_dst, size_t cap, size_t* n_floats) {

@@ -88,6 +88,24 @@ class TTCSession:
 
 
 # ------------------------------------------------------------------------------------------
+def to_float32(arr, sess):
+    """src/tof/tof_downloading.py:64-72 on the device: uint16 -> float32 / 65535 (floats pass through)."""
+    if isinstance(arr, np.ndarray) and np.issubdtype(arr.dtype, np.floating):
+        return sess.ctx._dev(arr.astype(np.float32), sess.ctx.torch.float32)
+    return sess.ctx.to_float32(arr)
+
+
+def to_int16(arr, sess):
+    """src/tof/tof_downloading.py:51-61: trunc(clip(x, 0, 1) * 65535) as uint16 (numpy, host copy)."""
+    return sess.ctx.to_int16(arr).cpu().numpy().view(np.uint16)
+
+
+def sentinel1_to_db(s1_u16, sess):
+    """The Sentinel-1 preparation of process_tile (src/download_and_predict_job.py:699-708) + convert_to_db
+    (:74-89): uint16 [T, X, Y, 2] -> cuda float32."""
+    return sess.ctx.s1_to_db(s1_u16)
+
+
 def normalize_subtile(subtile, ctx=None):
     """job.py:316-325, in place on [..., 17].  (Pure float32 numpy: used only on the
     predict_subtile drop-in path where the caller normalises itself; the per-tile path
