@@ -31,6 +31,16 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3        # v_mfma_f32_32x32x2_f32, dense
 
 
+def pmc_traffic(args):
+    """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the
+    timed process).  Only valid for the configuration the counters were collected on."""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_conv_gates.json")
+    if args.win != 172 or not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def conv_gates_flops(W, n_windows):
     """algorithmic FLOPs of ONE conv_gates launch: 3x3, 49 -> 64, W^2 px, both directions"""
     return 2.0 * 9 * 49 * 64 * W * W * (2 * n_windows)
@@ -177,7 +187,7 @@ def main():
             "roofline": {
                 "kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
                 "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None,
+                "frac": ach / FP32_MFMA_PEAK_TF, "traffic": pmc_traffic(args),
                 "launch_ms": gates_ms, "launches_timed": gates_n,
                 "flops_per_launch": conv_gates_flops(args.win, 36),
             },

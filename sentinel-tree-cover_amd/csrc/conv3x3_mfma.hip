@@ -44,7 +44,7 @@ constexpr int kBQ = kWaves * kQG * 32;       // 512 flattened positions per work
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 template <int CK, int NCG, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q) {
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q, int ncb) {
     constexpr int BN = NCG * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Wp = a.Wp, Hp = a.Hp;
@@ -57,7 +57,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchun
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int bq = blockIdx.x, cb = blockIdx.y, n = blockIdx.z;
+    // XCD-aware tile order: the dispatcher deals workgroup ids round-robin over the 8 XCDs, so id -> (id % 8) owns
+    // the contiguous slice [start(xcd), ...) of the logical tile list.  Neighbouring q tiles (which share a
+    // 2*Wp+2 halo, +68 % input bytes at Wp = 174) then meet in ONE XCD's L2 instead of being fetched from HBM twice.
+    int bq, cb, n;
+    {
+        const int G = gridDim.x, id = blockIdx.x;
+        const int per = G >> 3, rem = G & 7, xcd = id & 7, slot = id >> 3;
+        const int lid = xcd * per + (xcd < rem ? xcd : rem) + slot;
+        bq = lid % nblk_q;
+        const int rest = lid / nblk_q;
+        cb = rest % ncb; n = rest / ncb;
+    }
     const int set = n / a.n_per_set, nn = n - set * a.n_per_set;
     const int q0 = bq * kBQ;
 
@@ -276,8 +287,8 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
         configured = lds;
     }
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
-    dim3 grid(nblk_q, pw.ncb, n);
-    hipLaunchKernelGGL((conv3x3_f32<CK, NCG, EPI>), grid, dim3(kThreads), lds, s, a, pw.nchunk, nblk_q);
+    dim3 grid(nblk_q * pw.ncb * n);
+    hipLaunchKernelGGL((conv3x3_f32<CK, NCG, EPI>), grid, dim3(kThreads), lds, s, a, pw.nchunk, nblk_q, pw.ncb);
     return hipGetLastError();
 }
 
