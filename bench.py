@@ -59,6 +59,9 @@ def cpu_baseline(args, tile):
     ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
     size, T = args.win - 14, args.dates
     tm = {}
+    t0 = time.time()
+    s2_10, s2_20, s1 = O.to_float32(s2_10), O.to_float32(s2_20), O.s1_to_db(s1)
+    tm["codecs"] = time.time() - t0
     t0 = time.time(); s2 = O.upsample_20m(s2_10, s2_20); tm["bilinear"] = time.time() - t0
     # gap-fill on a quarter tile (x4)
     q = TILE // 2
@@ -129,19 +132,24 @@ def main():
     # (cloudy S2 stack + binary cloud/shadow mask from synth_gapfill_scene; S1 / DEM from synth_tile)
     s2, dates, probs, _ = synth.synth_gapfill_scene(seed=1234 + rank, T=args.dates, H=TILE, W=TILE)
     _, _, _, s1, dem = synth.synth_tile(seed=1234 + rank, T=2, H=TILE, W=TILE)
-    s2_10 = np.ascontiguousarray(s2[..., :4])
-    s2_20 = np.ascontiguousarray(s2[:, ::2, ::2, 4:])
+    # the raw tile as stored (uint16, src/tof/tof_downloading.py:51-61): decoding is part of the step
+    def u16(a):
+        return np.trunc(np.clip(a, 0, 1) * 65535).astype(np.uint16)
+    s2_10 = u16(s2[..., :4])
+    s2_20 = u16(s2[:, ::2, ::2, 4:])
+    s1 = u16(s1)
     host_tile = (s2_10, s2_20, probs, dates, s1, dem)
     dev = f"cuda:{local}"
-    d10, d20 = torch.from_numpy(s2_10).to(dev), torch.from_numpy(s2_20).to(dev)
-    dprobs, ds1, ddem = torch.from_numpy(probs).to(dev), torch.from_numpy(s1).to(dev), torch.from_numpy(dem).to(dev)
+    d10, d20 = torch.from_numpy(s2_10.view(np.int16)).to(dev), torch.from_numpy(s2_20.view(np.int16)).to(dev)
+    dprobs, ds1, ddem = torch.from_numpy(probs).to(dev), torch.from_numpy(s1.view(np.int16)).to(dev), torch.from_numpy(dem).to(dev)
     gather_buf = [torch.empty((TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
-        s2d = ctx.upsample_20m(d10, d20)                              # job.py:734-782
+        f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(ds1)   # tof_downloading.py:64-72, job.py:699-708
+        s2d = ctx.upsample_20m(f10, f20)                              # job.py:734-782
         dint, _, _ = ctx.remove_cloud_and_shadows(s2d, dprobs, None, None)   # cloud_removal.py:888-973 (deterministic sampler)
         ctx.superresolve_tile(s2d, quirks=True)                       # job.py:95-147
-        f32, u8 = job.predict_tile(s2d, dates, dint, ds1, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
+        f32, u8 = job.predict_tile(s2d, dates, dint, s1db, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
         if world > 1:
             shard.gather_rasters(u8, rank, world, 0, gather_buf)     # final-mosaic gather (RCCL over xGMI)
         return u8
@@ -175,7 +183,7 @@ def main():
             "config": {
                 "workload": f"one 618x618 tile per GPU per step, T={args.dates} dates, 36 overlapping {args.win}x{args.win} "
                             f"windows (out {size}), L={args.length}, fp32 (BASELINE.json configs[1])",
-                "stages": ["bilinear_20m", "cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
+                "stages": ["u16_decode+s1_db", "bilinear_20m", "cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
                            "dsen2_superresolve(31 windows x T)", "temporal_operator+indices+medians",
                            "window_assembly+normalise", "biConvGRU+UNet forward", "post_masks", "gaussian_mosaic"]
                           + (["rccl_gather_u8"] if world > 1 else []),

@@ -44,7 +44,7 @@ constexpr int kBQ = kWaves * kQG * 32;       // 512 flattened positions per work
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 template <int CK, int NCG, int EPI>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q, int ncb) {
+__global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q, int ncb) {
     constexpr int BN = NCG * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Wp = a.Wp, Hp = a.Hp;
@@ -218,6 +218,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchun
         const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
 #pragma unroll
         for (int g = 0; g < NCG; ++g) {
+            float rv[16];
+            if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) {
+                // all 16 residual loads in flight at once, branch-free (a load under `if (ok)` costs a full
+                // memory round trip each: BIAS_RES was 43 % slower than BIAS_RELU on the same conv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = valid && (co < a.Cout);
+                    rv[r] = resn[ok ? (long)co * a.out_plane + opix : 0];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -228,8 +239,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_f32(ConvArgs a, int nchun
                 if (EPI >= EPI_BIAS) {
                     if (co < a.Cout) v += aux[co];
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                    if (EPI == EPI_BIAS_RES && ok) v = resn[(long)co * a.out_plane + opix] + 0.1f * v;
-                    if (EPI == EPI_BIAS_TANH_ADD && ok) v = resn[(long)co * a.out_plane + opix] + tanhf(v);
+                    if (EPI == EPI_BIAS_RES) v = rv[r] + 0.1f * v;
+                    if (EPI == EPI_BIAS_TANH_ADD) v = rv[r] + tanhf(v);
                 }
                 if (ok) outn[(long)co * a.out_plane + opix] = v;
                 if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
