@@ -1,0 +1,266 @@
+// Implicit-GEMM 3x3 convolution on the gfx950 bf16 matrix cores with SPLIT operands ("bf16x3"):
+//     x = x_hi + x_lo (two bf16, 16 mantissa bits together),  w likewise,
+//     x * w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi           (fp32 accumulate inside v_mfma_f32_32x32x16_bf16)
+// i.e. three bf16 MFMAs per K block replace one fp32 MFMA chain at 1/16 of the matrix rate: ~5x the fp32 engine's
+// ceiling at ~2^-17 relative operand error (max |dprob| 5e-5 vs the exact-fp32 model on the oracle; plain bf16
+// or fp16 operands measured 4e-2 / 4e-3 and FAIL the 1e-3 contract).
+// Selected by ttc_config.precision = 1; precision = 0 keeps the exact fp32 engine (conv3x3_mfma.hip).
+//
+// Same "flattened padded plane" formulation, same tile (512 consecutive q x 32*NCG couts, 4 waves), same fused
+// epilogues (conv_common.h) and the SAME fp32 planar activations in HBM: the split happens while staging.
+//   * Cin chunk = 8 channels = one 16-byte K vector per pixel.  A lane loads 8 planes x float4 (4 consecutive q),
+//     splits them into hi/lo and writes 4 + 4 ds_write_b128.  LDS slot of position p is (p & 3) * TLq + (p >> 2)
+//     with TLq = 4 (mod 16): the writes of one instruction are contiguous, and the 32 consecutive positions a
+//     half-wave reads as a B operand fall into four contiguous runs on disjoint banks.
+//   * One MFMA K block (16) = the 8 channels of TWO taps: lanes 0-31 read tap 2*kb, lanes 32-63 tap 2*kb+1 (each
+//     half-wave addresses LDS independently, so pairing taps costs nothing); tap "9" has zero weights.  5 K blocks per
+//     chunk, 10 % K padding; Cin is padded to a multiple of 8 (49 -> 56).
+//   * Weights are packed on the host into the exact LDS image [kb][hi|lo][k-half][cout][8 bf16].
+#include "conv_common.h"
+
+using namespace ttcconv;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef TTC_B3_ABL
+#define TTC_B3_ABL 0     // probe builds only: 1 no output stores, 3 no MFMA
+#endif
+
+namespace {
+
+constexpr int kKB = 5;                      // K blocks per 8-channel chunk (tap pairs)
+
+__device__ __forceinline__ int slots_per_residue(int TL4) { return ((TL4 + 11) & ~15) + 4; }   // >= TL4, = 4 mod 16
+
+// Schedule: 4 waves per workgroup, two workgroups per CU.  Per chunk: [barrier] split + write the chunk's inputs to LDS
+// [barrier] issue the NEXT chunk's loads (inputs -> registers, weights global -> LDS into the other weight buffer),
+// then the chunk's 120 MFMAs per wave: the load latency hides under the MFMA phase.
+// Measured (ConvGRU gates, 72 x 172^2, 49 -> 64): 0.47 ms vs 1.04 ms for the exact fp32 engine.  Ablations: no output
+// stores 0.34 ms, no MFMAs 0.31 ms -- the kernel moves 1.1 GB of fp32 activations per launch (3.6 TB/s with the
+// MFMAs removed), so it sits between the HBM floor (~0.25 ms) and the bf16x3 MFMA floor (0.18 ms), not yet overlapped.
+// Tried and kept under csrc/experiments/: one 8-wave workgroup per CU running two tiles half a step apart
+// ("ping-pong", deterministic MFMA/staging alternation): 0.56 ms -- a single MFMA wave per SIMD cannot hide its own
+// LDS-read latency, and the barrier couples every slot to the slower of the two groups.
+template <int NCG, int EPI>
+__global__ __launch_bounds__(kThreads, NCG == 1 ? 3 : 2) void conv3x3_b3(ConvArgs a, const uint4* __restrict__ w3, long w3_set_stride,
+                                                              int nchunk, int nblk_q, int ncb) {
+    constexpr int BN = NCG * 32;
+    constexpr int WU = kKB * 2 * 2 * BN;              // 16-byte units of weights per chunk
+    constexpr int NWV = (WU + kThreads - 1) / kThreads;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Wp = a.Wp, Hp = a.Hp;
+    const int plane = Hp * Wp;
+    const int TL = kBQ + 2 * Wp + 2;
+    const int TL4 = (TL + 3) >> 2;
+    const int TLq = slots_per_residue(TL4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+
+    uint4* hi_tile = reinterpret_cast<uint4*>(smem);  // [4][TLq] x 8 bf16
+    uint4* lo_tile = hi_tile + 4 * TLq;
+    uint4* w_tile = lo_tile + 4 * TLq;                // 2 x [kKB][2][2][BN] x 8 bf16 (double-buffered)
+
+    int bq, cb, n;
+    tile_index(nblk_q, ncb, bq, cb, n);
+    const int set = n / a.n_per_set, nn = n - set * a.n_per_set;
+    const int q0 = bq * kBQ;
+
+    const float* seg0 = a.seg[0].base + (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
+    const float* seg1 = a.seg[1].C > 0 ? a.seg[1].base + (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set] : nullptr;
+    const int C0 = a.seg[0].C;
+    const float* aux = a.aux ? a.aux + (long)set * a.aux_set_stride : nullptr;
+    const uint4* wsrc = w3 + (long)set * w3_set_stride + (long)cb * nchunk * WU;
+
+    f32x16 acc[NCG][kQG];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int j = 0; j < kQG; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
+
+    // B-operand slots: independent of the chunk.  Lane half `hi` takes tap 2*kb + hi (tap 9 -> tap 8, zero weights).
+    // Pixel group j adds 32 positions = 8 slots within the same residue: an immediate offset of the ds_read.
+    int bslot[kKB];
+#pragma unroll
+    for (int kb = 0; kb < kKB; ++kb) {
+        const int tap = (2 * kb + hi) > 8 ? 8 : (2 * kb + hi);
+        const int p = wave * (kQG * 32) + lo + (tap / 3) * Wp + (tap % 3);
+        bslot[kb] = (p & 3) * TLq + (p >> 2);
+    }
+
+    const bool vec_ok = ((plane & 3) == 0) && (TL4 <= kThreads);
+    const int i4 = tid;                                // staging task: positions 4*i4 .. 4*i4+3 of the tile
+    const int qs = q0 + 4 * i4;
+    const bool in_tile = i4 < TL4;
+    const bool inside = qs < plane;
+
+    float4 iv[8];
+    const float* seg1s = seg1 ? seg1 : seg0;
+    // Stage loads of chunk cc.  Inputs go to registers (they must be split before they reach LDS), branch-free on the
+    // aligned path; the weights go global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16,
+    // exactly the linear LDS image) into the OTHER weight buffer.  Issued before the MFMA phase of chunk cc-1.
+#define TTC_B3_ISSUE(cc)                                                                                        \
+    {                                                                                                           \
+        if (vec_ok) {                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                     \
+                const int ci = (cc) * 8 + k;                                                                    \
+                const bool first = ci < C0;                                                                     \
+                const bool ok = (ci < a.Cin) && in_tile && inside;                                              \
+                const float* b = (first || !ok) ? seg0 : seg1s;                                                 \
+                const long off = ok ? (long)(first ? ci : ci - C0) * plane + qs : 0L;                           \
+                iv[k] = *reinterpret_cast<const float4*>(b + off);                                              \
+            }                                                                                                   \
+        } else {                                                                                                \
+            _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                     \
+                const int ci = (cc) * 8 + k;                                                                    \
+                const float* src = ci < C0 ? seg0 + (long)ci * plane : seg1s + (long)(ci - C0) * plane;         \
+                float t[4];                                                                                     \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                   \
+                    t[p] = ((ci < a.Cin) && in_tile && qs + p < plane) ? src[qs + p] : 0.0f;                    \
+                iv[k] = make_float4(t[0], t[1], t[2], t[3]);                                                    \
+            }                                                                                                   \
+        }                                                                                                       \
+        {                                                                                                       \
+            const uint4* ws = wsrc + (long)(cc) * WU;                                                           \
+            uint4* wdst = w_tile + ((cc) & 1) * WU;                                                             \
+            _Pragma("unroll") for (int k = 0; k < NWV; ++k) {                                                   \
+                const int i0 = k * kThreads + wave * 64;               /* wave-uniform */                       \
+                if (i0 < WU)                                                                                    \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + i0 + lane), \
+                                                     (__attribute__((address_space(3))) void*)(wdst + i0), 16, 0, 0); \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
+    TTC_B3_ISSUE(0)
+    for (int c = 0; c < nchunk; ++c) {
+        // ---- stage: this chunk's loads have landed (the MFMA reads of the previous chunk ended at the last barrier)
+        if (in_tile) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float x = p == 0 ? iv[k].x : (p == 1 ? iv[k].y : (p == 2 ? iv[k].z : iv[k].w));
+                    x = (c * 8 + k < a.Cin && inside) ? x : 0.0f;
+                    const __bf16 xb = (__bf16)x;
+                    h[k] = xb;
+                    l[k] = (__bf16)(x - (float)xb);
+                }
+                *reinterpret_cast<bf16x8*>(hi_tile + p * TLq + i4) = h;
+                *reinterpret_cast<bf16x8*>(lo_tile + p * TLq + i4) = l;
+            }
+        }
+        __syncthreads();
+        // ---- prefetch + MFMA
+        if (c + 1 < nchunk) TTC_B3_ISSUE(c + 1)
+        if (TTC_B3_ABL == 3) { if (c == 0) acc[0][0][0] = reinterpret_cast<float*>(hi_tile)[tid] + reinterpret_cast<float*>(w_tile)[tid]; }
+        else {
+        const uint4* wt = w_tile + (c & 1) * WU;
+#pragma unroll
+        for (int kb = 0; kb < kKB; ++kb) {
+            bf16x8 ah[NCG], al[NCG], bh[kQG], bl[kQG];
+#pragma unroll
+            for (int g = 0; g < NCG; ++g) {
+                ah[g] = *reinterpret_cast<const bf16x8*>(wt + ((kb * 2 + 0) * 2 + hi) * BN + g * 32 + lo);
+                al[g] = *reinterpret_cast<const bf16x8*>(wt + ((kb * 2 + 1) * 2 + hi) * BN + g * 32 + lo);
+            }
+#pragma unroll
+            for (int j = 0; j < kQG; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(hi_tile + bslot[kb] + 8 * j);
+                bl[j] = *reinterpret_cast<const bf16x8*>(lo_tile + bslot[kb] + 8 * j);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)      // lo*hi, hi*lo, hi*hi: 8 independent MFMAs between dependent ones
+#pragma unroll
+                for (int g = 0; g < NCG; ++g)
+#pragma unroll
+                    for (int j = 0; j < kQG; ++j)
+                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 0 ? al[g] : ah[g], term == 1 ? bl[j] : bh[j],
+                                                                            acc[g][j], 0, 0, 0);
+        }
+        }
+        __syncthreads();
+    }
+#undef TTC_B3_ISSUE
+    if (TTC_B3_ABL == 1) {
+        float t = 0.f;
+        for (int g = 0; g < NCG; ++g) for (int j = 0; j < kQG; ++j) for (int r = 0; r < 16; ++r) t += acc[g][j][r];
+        if (t == 1234.5f) a.out[tid] = t;
+    } else {
+        conv_epilogue<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
+    }
+}
+
+template <int NCG, int EPI>
+hipError_t launch_b3(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t s) {
+    constexpr int BN = NCG * 32;
+    const int TL = kBQ + 2 * a.Wp + 2;
+    const int TL4 = (TL + 3) >> 2;
+    const int TLq = ((TL4 + 11) & ~15) + 4;
+    const size_t lds = (size_t)(2 * 4 * TLq + 2 * kKB * 2 * 2 * BN) * 16;
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_b3<NCG, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
+    dim3 grid(nblk_q * pw.ncb * n);
+    hipLaunchKernelGGL((conv3x3_b3<NCG, EPI>), grid, dim3(kThreads), lds, s, a,
+                       reinterpret_cast<const uint4*>(pw.d_w3), pw.nsets > 1 ? pw.set_stride3 : 0L, pw.nchunk3, nblk_q, pw.ncb);
+    return hipGetLastError();
+}
+
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+long conv_pack_b3(const float* const* hwio, int nsets, int Cin, int Cout, int BN, std::vector<uint16_t>& out) {
+    const int nchunk = (Cin + 7) / 8, ncb = (Cout + BN - 1) / BN;
+    const long per_set = (long)ncb * nchunk * kKB * 2 * 2 * BN * 8;       // u16 elements
+    out.assign((size_t)per_set * nsets, 0);
+    for (int s = 0; s < nsets; ++s)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int c = 0; c < nchunk; ++c)
+                for (int kb = 0; kb < kKB; ++kb)
+                    for (int kh = 0; kh < 2; ++kh)
+                        for (int co = 0; co < BN; ++co)
+                            for (int k = 0; k < 8; ++k) {
+                                const int tap = 2 * kb + kh, ci = c * 8 + k, o = cb * BN + co;
+                                if (tap > 8 || ci >= Cin || o >= Cout) continue;
+                                const float w = hwio[s][((long)tap * Cin + ci) * Cout + o];      // HWIO, tap = 3*dy + dx
+                                const uint16_t h = bf16_rne(w), l = bf16_rne(w - bf16_to_f(h));
+                                const long base = (long)s * per_set + (((long)cb * nchunk + c) * kKB + kb) * (2 * 2 * BN * 8);
+                                out[base + ((0 * 2 + kh) * BN + co) * 8 + k] = h;
+                                out[base + ((1 * 2 + kh) * BN + co) * 8 + k] = l;
+                            }
+    return per_set / 8;                                                   // 16-byte units per set
+}
+
+hipError_t conv_launch_b3(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
+#define TTC_B3_CASE(ncg, e) if (pw.BN == ncg * 32 && epi == e) return launch_b3<ncg, e>(a, pw, n, s);
+    TTC_B3_CASE(2, EPI_RAW)
+    TTC_B3_CASE(1, EPI_SSE)
+    TTC_B3_CASE(2, EPI_SWISH)
+    TTC_B3_CASE(1, EPI_BIAS_RELU)
+    TTC_B3_CASE(1, EPI_BIAS_RES)
+    TTC_B3_CASE(1, EPI_BIAS_TANH_ADD)
+#undef TTC_B3_CASE
+    return hipErrorInvalidValue;
+}

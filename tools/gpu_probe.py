@@ -9,7 +9,8 @@ from ttc import _lib, synth, weights
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 172
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 36
-ctx = _lib.Context(win_in=W, length=L, max_windows=N)
+PREC = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=PREC)
 ctx.load_weights(weights.synth_weights(0))
 x = torch.from_numpy(synth.synth_windows(seed=1, N=N, L=L, W=W)).cuda()
 print("device bytes", ctx.device_bytes / 1e9, "GB")

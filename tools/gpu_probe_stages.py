@@ -8,7 +8,8 @@ import ttc  # noqa
 from ttc import job, synth, weights as Wt
 
 TILE = 618
-sess = job.TTCSession(Wt.synth_weights(0), win_in=172, length=4, max_windows=36)
+PREC = os.environ.get('TTC_PREC', 'fp32')
+sess = job.TTCSession(Wt.synth_weights(0), win_in=172, length=4, max_windows=36, precision=PREC)
 ctx = sess.ctx
 s2, dates, probs, _ = synth.synth_gapfill_scene(seed=1234, T=12, H=TILE, W=TILE)
 _, _, _, s1, dem = synth.synth_tile(seed=1234, T=2, H=TILE, W=TILE)
