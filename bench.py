@@ -41,6 +41,24 @@ def pmc_traffic(args):
         return json.load(f)["traffic_bytes_per_launch"]
 
 
+def roofline(args, gates_ms, gates_n):
+    """dominant kernel = the ConvGRU gates convolution (49 -> 64, both directions, 36 windows per launch)."""
+    W = args.win
+    flops = conv_gates_flops(W, 36)
+    if args.precision == "fp32":
+        ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
+        return {"kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
+                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
+                "traffic": pmc_traffic(args), "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops}
+    # split-bf16 engine: 3 bf16 MFMAs per term put the matrix floor (0.18 ms) below the HBM floor of the fp32 activations
+    nbytes = 4.0 * 72 * (49 * (W + 2) ** 2 + 64 * W * W)          # algorithmic: padded input planes + output planes
+    ach = nbytes / (gates_ms * 1e-3) / 1e9 if gates_ms > 0 else 0.0
+    return {"kernel": "conv3x3_b3<NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions, split-bf16 MFMA)",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "launch_ms": gates_ms, "launches_timed": gates_n, "bytes_per_launch": nbytes,
+            "mfma_bf16_frac": 3.0 * flops * (56.0 / 49) * (10.0 / 9) / (gates_ms * 1e-3) / 2.5e15 if gates_ms > 0 else 0.0}
+
+
 def conv_gates_flops(W, n_windows):
     """algorithmic FLOPs of ONE conv_gates launch: 3x3, 49 -> 64, W^2 px, both directions"""
     return 2.0 * 9 * 49 * 64 * W * W * (2 * n_windows)
@@ -105,6 +123,10 @@ def main():
     ap.add_argument("--win", type=int, default=172, help="model input window (172 = reference default; 168 also legal)")
     ap.add_argument("--length", type=int, default=4, help="ConvGRU steps (reference default 4; 12 = monthly)")
     ap.add_argument("--dates", type=int, default=12, help="raw acquisition dates T")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="conv engine: exact fp32 MFMA chains (BASELINE configs[1], default) or split-bf16 MFMA (3 products per "
+                         "term, fp32 accumulate; max |dprob| 7e-5 vs fp32)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational second measurement with the other conv engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -125,8 +147,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
 
     size = args.win - 14
-    sess = job.TTCSession(Wt.synth_weights(0), win_in=args.win, length=args.length, max_windows=36, device=local)
-    ctx = sess.ctx
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=args.win, length=args.length, max_windows=36, device=local,
+                          precision=args.precision)
 
     # synthetic tile, seed 1234 + tile_id (tile_id = rank): 10 m bands, 20 m bands, interp, S1, DEM -> HBM
     # (cloudy S2 stack + binary cloud/shadow mask from synth_gapfill_scene; S1 / DEM from synth_tile)
@@ -144,7 +166,8 @@ def main():
     dprobs, ds1, ddem = torch.from_numpy(probs).to(dev), torch.from_numpy(s1.view(np.int16)).to(dev), torch.from_numpy(dem).to(dev)
     gather_buf = [torch.empty((TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    def step():
+    def step(sess):
+        ctx = sess.ctx
         f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(ds1)   # tof_downloading.py:64-72, job.py:699-708
         s2d = ctx.upsample_20m(f10, f20)                              # job.py:734-782
         dint, _, _ = ctx.remove_cloud_and_shadows(s2d, dprobs, None, None)   # cloud_removal.py:888-973 (deterministic sampler)
@@ -159,19 +182,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.timing(2)                     # HIP events around the conv-engine launches only (on the launch stream)
-    ctx.kernel_ms(None)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    gates_ms, gates_n = ctx.kernel_ms("conv_gates")
-    ctx.timing(0)
-    dt = shard.max_over_ranks(dt, dev, world)
+    def measure(sess):
+        ctx = sess.ctx
+        for _ in range(args.warmup):
+            step(sess)
+        ctx.timing(2)                 # HIP events around the conv-engine launches only (on the launch stream)
+        ctx.kernel_ms(None)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(sess)
+        sync()
+        dt = time.perf_counter() - t0
+        gates_ms, gates_n = ctx.kernel_ms("conv_gates")
+        ctx.timing(0)
+        return shard.max_over_ranks(dt, dev, world), gates_ms, gates_n
+
+    dt, gates_ms, gates_n = measure(sess)
+    alt = None
+    if world == 1 and not args.no_alt:
+        other = "bf16x3" if args.precision == "fp32" else "fp32"
+        sess.close()
+        sess2 = job.TTCSession(Wt.synth_weights(0), win_in=args.win, length=args.length, max_windows=36, device=local, precision=other)
+        dt2, g2, _ = measure(sess2)
+        alt = {"precision": other, "value": TILE * TILE * args.steps / dt2, "unit": "px/s", "ms_per_step": dt2 / args.steps * 1e3,
+               "conv_gates_launch_ms": g2,
+               "note": "same step with the other conv engine; informational, not the headline value"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -179,10 +215,12 @@ def main():
         out = {
             "metric": "10m pixels/s tree-cover inference", "value": world * TILE * TILE * args.steps / dt, "unit": "px/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 storage/accumulate, split-bf16 (bf16x3) MFMA products",
+            "data": "synthetic",
             "config": {
                 "workload": f"one 618x618 tile per GPU per step, T={args.dates} dates, 36 overlapping {args.win}x{args.win} "
-                            f"windows (out {size}), L={args.length}, fp32 (BASELINE.json configs[1])",
+                            f"windows (out {size}), L={args.length}, {args.precision} (BASELINE.json configs[1])",
                 "stages": ["u16_decode+s1_db", "bilinear_20m", "cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
                            "dsen2_superresolve(31 windows x T)", "temporal_operator+indices+medians",
                            "window_assembly+normalise", "biConvGRU+UNet forward", "post_masks", "gaussian_mosaic"]
@@ -192,14 +230,10 @@ def main():
                 "weights": "synthetic seed 0 (ConvGRU/U-Net weights absent from the reference checkout); DSen2 real",
                 "tiles_per_step_per_gpu": 1, "win_in": args.win, "length": args.length, "dates": args.dates,
             },
-            "roofline": {
-                "kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
-                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": ach / FP32_MFMA_PEAK_TF, "traffic": pmc_traffic(args),
-                "launch_ms": gates_ms, "launches_timed": gates_n,
-                "flops_per_launch": conv_gates_flops(args.win, 36),
-            },
+            "roofline": roofline(args, gates_ms, gates_n),
         }
+        if alt:
+            out["alt_precision"] = alt
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_tile)
         print(json.dumps(out))
