@@ -623,24 +623,93 @@ __global__ void k_row_weights_dev(const float* __restrict__ evi, const DatePlan*
     }
 }
 __host__ __device__ void nnls_gram(const double G[11][11], const double g[11], double x[11]);
+// Lawson-Hanson NNLS on the normal equations, ONE WAVE per band: lane r owns row r of the active system.  The
+// arithmetic per matrix element is the same as the serial nnls_gram below (row operations of the Gauss-Jordan
+// elimination are independent per row), so both produce identical results; the serial single-lane version took
+// 170-340 us per date (fp64 arrays in scratch), this one ~15 us.
+__device__ __forceinline__ int wave_argmax_first(double v, bool eligible) {
+    // lowest lane index among the eligible lanes holding the maximum; -1 if none
+    double m = eligible ? v : -INFINITY;
+    for (int k = 32; k >= 1; k >>= 1) m = fmax(m, __shfl_xor(m, k));
+    const unsigned long long b = __ballot(eligible && v == m);
+    return b ? __ffsll((long long)b) - 1 : -1;
+}
 __global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan, Beta* __restrict__ be) {
-    // one workgroup per band (10 launched): the 32x32 Gram matrix is staged in LDS, lane 0 runs the active-set loop
-    __shared__ double Zs[32 * 32];
-    const int band = blockIdx.x;
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) Zs[i] = Z[i];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int col[11];
-        for (int j = 0; j < 11; ++j) col[j] = (j < band && j < 10) ? j : 11 + j;   // CR.py:522 / :550
-        double G[11][11], g[11], x[11];
-        for (int i = 0; i < 11; ++i) {
-            for (int j = 0; j < 11; ++j) G[i][j] = Zs[col[i] * 32 + col[j]];
-            g[i] = Zs[col[i] * 32 + 22 + band];
-        }
-        nnls_gram(G, g, x);
-        for (int j = 0; j < 11; ++j) be->b[band][j] = x[j];
-        if (band == 0) { const int f = plan->proceed && plan->nrows > 0; be->fitted = f; plan->fitted = f; }
+    __shared__ double G[11][11], g[11], A[11][12], x[11], sf[11];
+    __shared__ int idx[11];
+    const int band = blockIdx.x, lane = threadIdx.x;
+    const int n = 11;
+    if (!plan->proceed || plan->nrows <= 0) {          // nothing to fit for this date (CR.py:377-378)
+        if (lane < n) be->b[band][lane] = 0.0;
+        if (band == 0 && lane == 0) { be->fitted = 0; plan->fitted = 0; }
+        return;
     }
+    if (lane < n) {
+        const int ci = (lane < band && lane < 10) ? lane : 11 + lane;            // CR.py:522 / :550
+        for (int j = 0; j < n; ++j) {
+            const int cj = (j < band && j < 10) ? j : 11 + j;
+            G[lane][j] = Z[ci * 32 + cj];
+        }
+        g[lane] = Z[ci * 32 + 22 + band];
+        x[lane] = 0.0;
+    }
+    __syncthreads();
+    unsigned P = 0;                                    // active set (uniform)
+    const double tol = 1e-12 * fabs(g[0] + 1e-300) + 1e-15;
+    for (int iter = 0; iter < 3 * n; ++iter) {
+        double w = 0.0;
+        if (lane < n) { w = g[lane]; for (int j = 0; j < n; ++j) w -= G[lane][j] * x[j]; }
+        const int best = wave_argmax_first(w, lane < n && !((P >> lane) & 1u) && w > tol);
+        if (best < 0) break;
+        P |= 1u << best;
+        for (int inner = 0; inner < 3 * n; ++inner) {
+            const int m = __popc(P);
+            if (lane < n && ((P >> lane) & 1u)) idx[__popc(P & ((1u << lane) - 1u))] = lane;
+            __syncthreads();
+            if (lane < m) {
+                for (int c2 = 0; c2 < m; ++c2) A[lane][c2] = G[idx[lane]][idx[c2]];
+                A[lane][m] = g[idx[lane]];
+            }
+            __syncthreads();
+            for (int c2 = 0; c2 < m; ++c2) {
+                // partial pivoting: first row r >= c2 with the largest |A[r][c2]|
+                const int piv = wave_argmax_first(lane < m ? fabs(A[lane][c2]) : 0.0, lane >= c2 && lane < m);
+                if (piv != c2 && lane <= m) { const double tv = A[piv][lane]; A[piv][lane] = A[c2][lane]; A[c2][lane] = tv; }
+                __syncthreads();
+                const double d = A[c2][c2];
+                if (fabs(d) >= 1e-300 && lane < m && lane != c2) {
+                    const double f = A[lane][c2] / d;
+                    if (f != 0.0) for (int k = c2; k <= m; ++k) A[lane][k] -= f * A[c2][k];
+                }
+                __syncthreads();
+            }
+            double sv = 0.0;
+            if (lane < m) { const double d = A[lane][lane]; sv = fabs(d) < 1e-300 ? 0.0 : A[lane][m] / d; }
+            if (lane < n) sf[lane] = 0.0;
+            __syncthreads();
+            if (lane < m) sf[idx[lane]] = sv;
+            __syncthreads();
+            const bool allpos = __ballot(lane < m && sv <= 0.0) == 0ull;
+            if (allpos) {
+                if (lane < n) x[lane] = ((P >> lane) & 1u) ? sf[lane] : 0.0;
+                __syncthreads();
+                break;
+            }
+            double a = 1.0;
+            if (lane < n && ((P >> lane) & 1u) && sf[lane] <= 0.0) a = x[lane] / (x[lane] - sf[lane]);
+            for (int k = 32; k >= 1; k >>= 1) a = fmin(a, __shfl_xor(a, k));
+            bool drop = false;
+            if (lane < n && ((P >> lane) & 1u)) {
+                const double xn = x[lane] + a * (sf[lane] - x[lane]);
+                drop = xn <= 1e-15;
+                x[lane] = drop ? 0.0 : xn;
+            }
+            P &= ~(unsigned)__ballot(drop);
+            __syncthreads();
+        }
+    }
+    if (lane < n) be->b[band][lane] = x[lane];
+    if (band == 0 && lane == 0) { be->fitted = 1; plan->fitted = 1; }
 }
 __global__ void k_cloud_thresholds(const SelState* __restrict__ st, const int* __restrict__ n_only, int npix, float* __restrict__ thr) {
     if (threadIdx.x) return;
