@@ -132,8 +132,10 @@ ttc_status ttc_tile_fix_missing(ttc_ctx* ctx, float* d_s2, int32_t T, int32_t X,
 ttc_status ttc_feather(ttc_ctx* ctx, const float* d_mask, int32_t T, int32_t X, int32_t Y, int32_t closing,
                        int32_t clip, float* d_w, void* stream);
 /* == make_aligned_mosaic (cloud_removal.py:578-699).  d_tiles [T, X, Y, 10]; d_w [T, X, Y] in/out
- * (dates that cannot be aligned are set to 1, :679-680); d_mosaic [X, Y, 10] out.  Fully asynchronous:
- * row counts, selection ranks and the ">1000 rows" decisions are taken on the device. */
+ * (dates that cannot be aligned are set to 1, :679-680); d_mosaic [X, Y, 10] out.  Row counts, selection ranks
+ * and the per-date statistics are computed on the device for all dates at once; the call waits for the stream
+ * ONCE to read T flags back (does any date have <= 1000 usable rows?) and then either finishes in one launch or
+ * falls back to the reference's date-by-date order. */
 ttc_status ttc_aligned_mosaic(ttc_ctx* ctx, const float* d_tiles, float* d_w, int32_t T, int32_t X, int32_t Y,
                               float* d_mosaic, void* stream);
 /* Row sampler for the per-date fit (align_interp_array_randomforest, cloud_removal.py:453-505):
@@ -148,7 +150,7 @@ typedef int64_t (*ttc_sampler_fn)(const float* h_evi, int64_t n_rows, int64_t* o
  * sampler NULL = deterministic expected-multiplicity weighting on the device (no RNG);
  * d_interp [T, X, Y] out (areas_interpolated); d_mosaic [X, Y, 10] out or NULL;
  * h_to_remove [T] / n_to_remove: dates that are interpolated everywhere (:958-959); filling them is the
- * one place this call waits for the stream (a [T] int32 read-back) -- pass NULL to stay asynchronous.
+ * second place this call waits for the stream (the first is the aligned mosaic's flag read-back).
  * With a `sampler` the call additionally synchronises once per date to hand the EVI column to the host. */
 ttc_status ttc_remove_cloud_and_shadows(ttc_ctx* ctx, float* d_tiles, const float* d_probs, const uint8_t* d_pfcps,
                                         int32_t T, int32_t X, int32_t Y, ttc_sampler_fn sampler, void* user,

@@ -837,9 +837,11 @@ static ttc_status water_mask(ttc_ctx* c, const float* d_tiles, int T, int X, int
     return TTC_OK;
 }
 
-ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
-                                  hipStream_t s) {
-    if (!d_tiles || !d_w || !d_mosaic || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "aligned_mosaic: bad argument (T in [1,32])");
+// Date-by-date form: exactly the reference's loop, including the `interp[i] = 1` side effect of a date that cannot be
+// aligned (CR.py:679-680), which changes the reference set of every LATER date.  Used when the batched form below
+// finds such a date.
+static ttc_status aligned_mosaic_sequential(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
+                                            hipStream_t s) {
     const int npix = X * Y;
     unsigned char* water = static_cast<unsigned char*>(c->scratch_buf("gf_water", (size_t)npix));
     unsigned char* valid = static_cast<unsigned char*>(c->scratch_buf("gf_valid", (size_t)npix));
@@ -853,7 +855,6 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     double* var = mean + 20;                                              // 20
     int* count = reinterpret_cast<int*>(var + 20);                        // count, n_land
     AlignPar* ap = reinterpret_cast<AlignPar*>(count + 4);
-    KTimer kt(c, "aligned_mosaic", s);
     TTC_CHECK(water_mask(c, d_tiles, T, X, Y, false, true, water, s));
     const dim3 grid((npix + 255) / 256), blk(256);
     TTC_HIP(c, hipMemsetAsync(d_mosaic, 0, sizeof(float) * 10 * (size_t)npix, s));
@@ -877,6 +878,255 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
         TTC_HIP(c, hipGetLastError());
     }
     GF_T(k_mosaic_final, T, grid, blk, 0, s, d_tiles, divisor, T, npix, d_mosaic);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+// ---- batched form: all T dates at once ---------------------------------------------------------------------------
+// Without an unalignable date the T iterations of make_aligned_mosaic are independent, so every stage runs once with
+// the date as a grid dimension: ~20 launches instead of ~20 per date, one pass over the stack for the T reference
+// means (the per-date form re-reads all T dates T times), single-pass statistics, and 20 selection problems per date
+// (the upper median comes from one extra counting pass instead of a second radix select).
+template <int TM>
+__global__ void k_ref_all(const float* __restrict__ tiles, const float* __restrict__ w, const unsigned char* __restrict__ water,
+                          int T, int npix, float* __restrict__ ref_all, unsigned* __restrict__ vmask, int* __restrict__ count) {
+#pragma clang fp contract(off)
+    __shared__ int cnt[TM];
+    if (threadIdx.x < TM) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const long total = (long)npix * 10;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id - threadIdx.x < total; id += (long)gridDim.x * blockDim.x) {
+        unsigned mask = 0;
+        const bool live = id < total;
+        const int p = live ? (int)(id / 10) : 0;
+        const int ch = (int)(id - (long)p * 10);
+        if (live) {
+            float wv[TM], v[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                wv[t] = t < T ? w[(long)t * npix + p] : 1.0f;
+                v[t] = t < T ? tiles[(long)t * total + id] : 0.0f;
+            }
+            if (!water[p]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (i < T && wv[i] < 0.25f) {
+                        float sum = 0.f;
+                        int n = 0;
+#pragma unroll
+                        for (int b = 0; b < TM; ++b)
+                            if (b < T && b != i && wv[b] < 1.0f) { sum += v[b]; ++n; }
+                        if (n > 0) { mask |= 1u << i; ref_all[(long)i * total + id] = sum / (float)n; }
+                    }
+                }
+            }
+            if (ch == 0) vmask[p] = mask;
+        }
+        for (int i = 0; i < T; ++i) {
+            const int k = __popcll(__ballot(live && ch == 0 && ((mask >> i) & 1u)));
+            if ((threadIdx.x & 63) == 0 && k) atomicAdd(&cnt[i], k);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < T && cnt[threadIdx.x]) atomicAdd(&count[threadIdx.x], cnt[threadIdx.x]);
+}
+// problems q = date*20 + band*2 + which (0 = reference mean, 1 = the date itself); rank = lower median
+__global__ void k_sel_init_dates(SelState* __restrict__ st, const int* __restrict__ count, int T) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= T * 20) return;
+    const int n = count[q / 20];
+    SelState ss; ss.prefix = 0; ss.mask = 0; ss.k = n > 0 ? (n - 1) / 2 : 0;
+    st[q] = ss;
+}
+__global__ void k_hist_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
+                           int npix, const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[20 * 256];
+    __shared__ unsigned pf[20], mk[20];
+    const int i = blockIdx.y;
+    for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x) h[k] = 0;
+    if (threadIdx.x < 20) { pf[threadIdx.x] = st[i * 20 + threadIdx.x].prefix; mk[threadIdx.x] = st[i * 20 + threadIdx.x].mask; }
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        if (!((vmask[p] >> i) & 1u)) continue;
+        const float* r = ref_all + ((long)i * npix + p) * 10;
+        const float* sv = tiles + ((long)i * npix + p) * 10;
+#pragma unroll
+        for (int ch = 0; ch < 10; ++ch) {
+            const unsigned k0 = fkey(r[ch]), k1 = fkey(sv[ch]);
+            if ((k0 & mk[2 * ch]) == pf[2 * ch]) atomicAdd(&h[(2 * ch) * 256 + ((k0 >> shift) & 255u)], 1u);
+            if ((k1 & mk[2 * ch + 1]) == pf[2 * ch + 1]) atomicAdd(&h[(2 * ch + 1) * 256 + ((k1 >> shift) & 255u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x)
+        if (h[k]) atomicAdd(&hist[(long)i * 20 * 256 + k], h[k]);
+}
+// per (date, column): sum, sum of squares (double), #(v <= lower median), min key of (v > lower median)
+struct ColStat { double sum, sq; int n_le; unsigned min_gt; };
+__global__ void k_stat_init(ColStat* cs) { cs[threadIdx.x].sum = 0.0; cs[threadIdx.x].sq = 0.0; cs[threadIdx.x].n_le = 0; cs[threadIdx.x].min_gt = 0xffffffffu; }
+__global__ void k_stat_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
+                           int npix, const SelState* __restrict__ st, ColStat* __restrict__ out) {
+    __shared__ double ssum[20], ssq[20];
+    __shared__ int sle[20];
+    __shared__ unsigned smin[20];
+    __shared__ float med[20];
+    const int i = blockIdx.y;
+    if (threadIdx.x < 20) {
+        ssum[threadIdx.x] = 0.0; ssq[threadIdx.x] = 0.0; sle[threadIdx.x] = 0; smin[threadIdx.x] = 0xffffffffu;
+        med[threadIdx.x] = fkey_inv(st[i * 20 + threadIdx.x].prefix);
+    }
+    __syncthreads();
+    double a[20], a2[20];
+    int le[20];
+    unsigned mn[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) { a[q] = 0.0; a2[q] = 0.0; le[q] = 0; mn[q] = 0xffffffffu; }
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        if (!((vmask[p] >> i) & 1u)) continue;
+        const float* r = ref_all + ((long)i * npix + p) * 10;
+        const float* sv = tiles + ((long)i * npix + p) * 10;
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
+            const float v = (q & 1) ? sv[q >> 1] : r[q >> 1];
+            a[q] += (double)v; a2[q] += (double)v * (double)v;
+            le[q] += v <= med[q];
+            if (v > med[q]) mn[q] = min(mn[q], fkey(v));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+        for (int k = 32; k >= 1; k >>= 1) {
+            a[q] += __shfl_xor(a[q], k); a2[q] += __shfl_xor(a2[q], k);
+            le[q] += __shfl_xor(le[q], k); mn[q] = min(mn[q], (unsigned)__shfl_xor((int)mn[q], k));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&ssum[q], a[q]); atomicAdd(&ssq[q], a2[q]); atomicAdd(&sle[q], le[q]); atomicMin(&smin[q], mn[q]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 20) {
+        ColStat* o = out + i * 20 + threadIdx.x;
+        atomicAdd(&o->sum, ssum[threadIdx.x]); atomicAdd(&o->sq, ssq[threadIdx.x]);
+        atomicAdd(&o->n_le, sle[threadIdx.x]); atomicMin(&o->min_gt, smin[threadIdx.x]);
+    }
+}
+__global__ void k_params_all(const SelState* __restrict__ st, const ColStat* __restrict__ cs, const int* __restrict__ count,
+                             const int* __restrict__ n_land, int T, AlignPar* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i >= T) return;
+    const int n = count[i];
+    AlignPar ap;
+    ap.ok = n > 1000;
+    ap.any_land = *n_land > 0;
+    float med[2], sd[2];
+    for (int b = 0; b < 10; ++b) {
+        for (int which = 0; which < 2; ++which) {
+            const int q = i * 20 + b * 2 + which;
+            const float lo = fkey_inv(st[q].prefix);
+            // upper median = order statistic n/2: the same value when enough elements are <= it, else the next larger one
+            float up = lo;
+            if (n > 0 && (n & 1) == 0 && cs[q].n_le < n / 2 + 1) up = fkey_inv(cs[q].min_gt);
+            med[which] = 0.5f * (lo + up);
+            const double mean = cs[q].sum / (double)max(n, 1);
+            double var = cs[q].sq / (double)max(n, 1) - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sd[which] = (float)sqrt(var);
+        }
+        const float k = sd[0] / sd[1];                 // std_ref / std_src, CR.py:633
+        ap.k[b] = k; ap.add[b] = med[0] - med[1] * k;
+    }
+    out[i] = ap;
+}
+// mosaic = sum_i (1 - w_i) * aligned_i (date order, CR.py:676), / divisor, NaN -> 10th percentile over dates, clamp
+template <int TM>
+__global__ void k_accum_final_all(const float* __restrict__ tiles, const float* __restrict__ w, const unsigned char* __restrict__ water,
+                                  const AlignPar* __restrict__ ap, const float* __restrict__ divisor, int T, int npix,
+                                  float* __restrict__ mosaic) {
+#pragma clang fp contract(off)
+    const long total = (long)npix * 10;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int p = (int)(id / 10), ch = (int)(id - (long)p * 10);
+    const bool land = !water[p];
+    float v[TM];
+    float m = 0.f, mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        v[t] = INFINITY;
+        if (t < T) {
+            v[t] = tiles[(long)t * total + id];
+            mn = fminf(mn, v[t]); mx = fmaxf(mx, v[t]);
+            if (ap[t].ok) {
+                const float wi = 1.0f - w[(long)t * npix + p];
+                const float a = land ? v[t] * ap[t].k[ch] + ap[t].add[ch] : v[t];
+                m = m + wi * a;
+            }
+        }
+    }
+    float d = divisor[p];
+    if (d < 0.f) d = 0.f;
+    m = m / d;
+    if (isnan(m)) {
+        bitonic_sort<TM>(v);
+        const double pos = 0.1 * (T - 1);
+        const int lo = (int)floor(pos);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) { if (t == lo) a = v[t]; if (t == lo + 1 && lo + 1 < T) b = v[t]; }
+        if (lo + 1 >= T) b = a;
+        m = (float)((double)a + ((double)b - (double)a) * (pos - lo));
+    }
+    m = fmaxf(m, mn);
+    m = fminf(m, mx);
+    mosaic[id] = m;
+}
+
+ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
+                                  hipStream_t s) {
+    if (!d_tiles || !d_w || !d_mosaic || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "aligned_mosaic: bad argument (T in [1,32])");
+    const int npix = X * Y;
+    const long total = (long)npix * 10;
+    unsigned char* water = static_cast<unsigned char*>(c->scratch_buf("gf_water", (size_t)npix));
+    float* ref_all = static_cast<float*>(c->scratch_buf("gf_ref_all", sizeof(float) * (size_t)T * total));
+    unsigned* vmask = static_cast<unsigned*>(c->scratch_buf("gf_vmask", sizeof(unsigned) * (size_t)npix));
+    float* divisor = static_cast<float*>(c->scratch_buf("gf_div", sizeof(float) * (size_t)npix));
+    const size_t ctl_bytes = 8192 + sizeof(SelState) * kMaxT * 20 + sizeof(ColStat) * kMaxT * 20 + sizeof(AlignPar) * kMaxT +
+                             sizeof(unsigned) * kMaxT * 20 * 256;
+    char* ctl = static_cast<char*>(c->scratch_buf("gf_ctl_all", ctl_bytes));
+    if (!water || !ref_all || !vmask || !divisor || !ctl) return c->fail(TTC_ERR_NOMEM, "aligned_mosaic scratch");
+    int* count = reinterpret_cast<int*>(ctl);                              // [kMaxT] valid rows per date, [kMaxT] = n_land
+    SelState* st = reinterpret_cast<SelState*>(ctl + 8192);
+    ColStat* cs = reinterpret_cast<ColStat*>(st + kMaxT * 20);
+    AlignPar* ap = reinterpret_cast<AlignPar*>(cs + kMaxT * 20);
+    unsigned* hist = reinterpret_cast<unsigned*>(ap + kMaxT);
+    {
+        KTimer kt(c, "aligned_mosaic", s);
+        TTC_CHECK(water_mask(c, d_tiles, T, X, Y, false, true, water, s));
+        const dim3 grid((npix + 255) / 256), blk(256);
+        TTC_HIP(c, hipMemsetAsync(ctl, 0, ctl_bytes, s));
+        hipLaunchKernelGGL(k_divisor, grid, blk, 0, s, d_w, T, npix, divisor);
+        hipLaunchKernelGGL(k_count_land, dim3(64), blk, 0, s, water, npix, count + kMaxT);
+        GF_T(k_ref_all, T, dim3(2048), blk, 0, s, d_tiles, d_w, water, T, npix, ref_all, vmask, count);
+        hipLaunchKernelGGL(k_sel_init_dates, dim3((T * 20 + 63) / 64), dim3(64), 0, s, st, count, T);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(k_hist_all, dim3(64, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, shift, hist);
+            hipLaunchKernelGGL(k_sel_pick, dim3(T * 20), dim3(64), 0, s, st, shift, hist);
+        }
+        hipLaunchKernelGGL(k_stat_init, dim3(1), dim3(kMaxT * 20), 0, s, cs);
+        hipLaunchKernelGGL(k_stat_all, dim3(48, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, cs);
+        hipLaunchKernelGGL(k_params_all, dim3(1), dim3(64), 0, s, st, cs, count, count + kMaxT, T, ap);
+        TTC_HIP(c, hipGetLastError());
+    }
+    // the one host decision: a date with <= 1000 usable rows on a tile that has land marks itself fully interpolated
+    // and thereby changes every later date (CR.py:679-680) -> redo date by date.  T small ints, one stream wait.
+    AlignPar h_ap[kMaxT];
+    TTC_HIP(c, hipMemcpyAsync(h_ap, ap, sizeof(AlignPar) * T, hipMemcpyDeviceToHost, s));
+    TTC_HIP(c, hipStreamSynchronize(s));
+    bool redo = false;
+    for (int i = 0; i < T; ++i) redo |= (!h_ap[i].ok && h_ap[i].any_land);
+    if (redo) return aligned_mosaic_sequential(c, d_tiles, d_w, T, X, Y, d_mosaic, s);
+    KTimer kt(c, "aligned_mosaic", s);
+    GF_T(k_accum_final_all, T, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_tiles, d_w, water, ap, divisor, T, npix, d_mosaic);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }
