@@ -65,7 +65,7 @@ def test_single_step_intermediates():
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("W,L,N", [(44, 4, 2), (60, 12, 1), (172, 4, 2)])
+@pytest.mark.parametrize("W,L,N", [(44, 4, 2), (60, 12, 1), (172, 4, 2), (168, 12, 1)])
 def test_forward_matches_oracle(W, L, N):
     ctx, w, x, ref, tr = _setup(W, L, N, seed=W + L)
     out = ctx.forward_windows(x).cpu().numpy()

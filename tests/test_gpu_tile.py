@@ -212,6 +212,21 @@ def test_bf16x3_tile_end_to_end_vs_oracle():
     _report("superresolve tile (bf16x3)", dd.cpu().numpy(), ref, 2e-4)
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 1e-4)])
+def test_dsen2_ragged_windows(precision, tol):
+    """odd / tiny window sizes: planes whose size is not a multiple of 4 take the conv engines' unaligned staging path"""
+    import torch
+    from oracle import restate_model as M
+    from ttc import weights as Wt
+    sess, _ = _session(44, 2, precision=precision)
+    net = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    rng = np.random.default_rng(11)
+    for n, H, W in [(2, 11, 13), (1, 3, 3), (3, 17, 40), (1, 120, 7)]:
+        x = rng.random((n, H, W, 10)).astype(np.float32)
+        got = sess.ctx.dsen2_forward(x, x[..., 4:]).cpu().numpy()
+        _report(f"DSen2 {n}x{H}x{W} ({precision})", got, net(x, x[..., 4:]), tol)
+
+
 @pytest.mark.parametrize("h,w", [(20, 18), (21, 19), (21, 18), (20, 19)])
 def test_upsample_20m(h, w):
     """even grids and the three odd-grid branches of job.py:760-782 (309 x 309 is the production case)"""
