@@ -86,6 +86,13 @@ ttc_status ttc_load_dsen2_weights(ttc_ctx* ctx, const ttc_tensor* tensors, int32
  * d_out: [n, W-14, W-14]    float32 probabilities                                      */
 ttc_status ttc_forward_windows(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, void* stream);
 
+/* Forward + the two feature tensors of --gen_feats (job.py:1429-1445; tensors named at :1808-1809):
+ * d_early [n, W, W, 64]       == sess.run("predict/gru_drop/drop_block2d/cond/Merge:0")  (bi-ConvGRU output)
+ * d_late  [n, W-14, W-14, 64] == sess.run("predict/csse_out_mul/mul:0")                  (last block after its sSE gate)
+ * either may be NULL. */
+ttc_status ttc_forward_taps(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, float* d_early, float* d_late,
+                            void* stream);
+
 /* ---- per-tile numeric core ----------------------------------------------------------
  * == process_subtiles (job.py:1125-1483) up to and including the per-window post-masks,
  * for one tile whose dates have already been screened on the host (deal_w_missing_px's
@@ -187,6 +194,8 @@ ttc_status ttc_upsample_20m(ttc_ctx* ctx, const float* d_s2_10, const float* d_s
  * trunc(clip(x, 0, 1) * 65535) -> uint16.  n = element count. */
 ttc_status ttc_u16_to_float(ttc_ctx* ctx, const uint16_t* d_in, int64_t n, float* d_out, void* stream);
 ttc_status ttc_float_to_u16(ttc_ctx* ctx, const float* d_in, int64_t n, uint16_t* d_out, void* stream);
+/* float_to_int16 (job.py:174-180): NaN -> -32768; trunc(clip(x, -32768/precision, 32767/precision) * precision). */
+ttc_status ttc_float_to_int16(ttc_ctx* ctx, const float* d_in, int64_t n, float precision, int16_t* d_out, void* stream);
 /* Sentinel-1 preparation of process_tile (job.py:699-708): /65535, saturated (== 1) samples -> the image's
  * median, convert_to_db(., 22) (job.py:74-89).  d_u16 [T, X, Y, 2] -> d_out [T, X, Y, 2] float32. */
 ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t X, int32_t Y, float* d_out, void* stream);

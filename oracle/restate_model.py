@@ -154,10 +154,23 @@ class TreeCoverNet:
         up2 = self.block("up2_out", torch.cat([up2, conv1[:, :, 2:-2, 2:-2]], 1), "SAME")
         up3 = self.block("up3", F.interpolate(up2, scale_factor=2, mode="nearest"), "SAME")
         up3 = self.block("out", torch.cat([up3, concat[:, :, 6:-6, 6:-6]], 1), "VALID")
+        self._t("late", up3)                             # == predict/csse_out_mul/mul:0 (job.py:1808)
         fm = torch.sigmoid(F.conv2d(up3, _k(self.w, "head/kernel", self.dt), _v(self.w, "head/bias", self.dt)))
         return fm.permute(0, 2, 3, 1).contiguous().numpy()
 
     __call__ = forward
+
+    def features(self, inp):
+        """job.py:1808-1809 taps: (probs [B,o,o,1], early = bi-GRU output [B,W,W,64], late = last block output [B,o,o,64]),
+        NHWC like the tensors Session.run returns."""
+        keep, self.trace = self.trace, {}
+        try:
+            probs = self.forward(inp)
+            early = np.moveaxis(self.trace["gru"], 1, -1).copy()
+            late = np.moveaxis(self.trace["late"], 1, -1).copy()
+        finally:
+            self.trace = keep
+        return probs, early, late
 
 
 def model_flops(W, L):

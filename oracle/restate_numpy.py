@@ -41,6 +41,15 @@ def to_int16(a):
     return np.trunc(np.clip(a, 0, 1) * 65535).astype(np.uint16)
 
 
+def float_to_int16(arr, precision=1000):
+    """job.py:174-180."""
+    arr = np.array(arr, dtype=np.float32)
+    arr[np.isnan(arr)] = -32768
+    arr = np.clip(arr, (-32768 / precision), (32767 / precision))
+    arr = arr * precision
+    return np.int16(arr)
+
+
 def convert_to_db(x, min_db=22):
     """job.py:74-89."""
     x = 10 * np.log10(x + 1 / 65535)

@@ -21,7 +21,7 @@ EXPORTS = [
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
-    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db",
+    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -75,6 +75,8 @@ def load():
     lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
     lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
+    lib.ttc_forward_taps.argtypes = [P, VP, I32, VP, VP, VP, VP]
+    lib.ttc_float_to_int16.argtypes = [P, VP, C.c_int64, C.c_float, VP, VP]
     lib.ttc_u16_to_float.argtypes = [P, VP, C.c_int64, VP, VP]
     lib.ttc_float_to_u16.argtypes = [P, VP, C.c_int64, VP, VP]
     lib.ttc_s1_to_db.argtypes = [P, VP, I32, I32, I32, VP, VP]
@@ -235,6 +237,29 @@ class Context:
                                         C.c_void_p(u8.data_ptr()), C.c_void_p(f32.data_ptr()) if want_float else None,
                                         self._stream()), "ttc_mosaic")
         return u8, f32
+
+    def forward_taps(self, x, early=True, late=True):
+        """forward + feature taps: -> (probs [n, o, o], early [n, W, W, 64] | None, late [n, o, o, 64] | None), cuda float32"""
+        t = self.torch
+        a = self._dev(x, t.float32)
+        n, W = int(a.shape[0]), self.cfg.win_in
+        o = W - 14
+        out = t.empty((n, o, o), dtype=t.float32, device=a.device)
+        e = t.empty((n, W, W, 64), dtype=t.float32, device=a.device) if early else None
+        l = t.empty((n, o, o, 64), dtype=t.float32, device=a.device) if late else None
+        self._check(self.lib.ttc_forward_taps(self._h, C.c_void_p(a.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(e.data_ptr()) if early else None,
+                                              C.c_void_p(l.data_ptr()) if late else None, self._stream()), "ttc_forward_taps")
+        return out, e, l
+
+    def float_to_int16(self, x, precision=1000):
+        """job.py:174-180 on the device -> cuda int16"""
+        t = self.torch
+        a = self._dev(x, t.float32)
+        out = t.empty(a.shape, dtype=t.int16, device=a.device)
+        self._check(self.lib.ttc_float_to_int16(self._h, C.c_void_p(a.data_ptr()), a.numel(), float(precision),
+                                                C.c_void_p(out.data_ptr()), self._stream()), "ttc_float_to_int16")
+        return out
 
     # -- codecs ---------------------------------------------------------------------------
     def to_float32(self, u16):

@@ -24,6 +24,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
 ttc_status codec_u16_to_f32(ttc_ctx* c, const uint16_t* d_in, int64_t n, float* d_out, hipStream_t s);
 ttc_status codec_f32_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* d_out, hipStream_t s);
 ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s);
+ttc_status codec_f32_to_i16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, hipStream_t s);
 
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
@@ -88,6 +89,21 @@ ttc_status ttc_forward_windows(ttc_ctx* c, const float* d_in, int32_t n, float* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
     return model_forward_frames(c, n, d_out, s);
+}
+
+ttc_status ttc_forward_taps(ttc_ctx* c, const float* d_in, int32_t n, float* d_out, float* d_early, float* d_late, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    if (!d_in || !d_out) return c->fail(TTC_ERR_ARG, "null buffer");
+    if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
+    TTC_CHECK(model_forward_frames(c, n, d_out, s));
+    return model_taps(c, n, d_early, d_late, s);
+}
+
+ttc_status ttc_float_to_int16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return codec_f32_to_i16(c, d_in, n, precision, d_out, static_cast<hipStream_t>(stream));
 }
 
 ttc_status ttc_process_subtiles(ttc_ctx* c, const float* d_s2, int32_t T, int32_t X, int32_t Y, const float* h_wmat,

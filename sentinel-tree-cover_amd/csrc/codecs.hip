@@ -20,6 +20,18 @@ __global__ void k_f32_to_u16(const float* __restrict__ in, long n, unsigned shor
     if (i < n) out[i] = (unsigned short)truncf(fminf(fmaxf(in[i], 0.f), 1.f) * 65535.0f);
 }
 
+// float_to_int16 (job.py:174-180): NaN -> -32768, clip to [-32768, 32767] / precision, * precision, truncate
+__global__ void k_f32_to_i16(const float* __restrict__ in, long n, float precision, short* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = in[i];
+    if (isnan(x)) x = -32768.0f;
+    const float lo = (float)(-32768.0 / (double)precision), hi = (float)(32767.0 / (double)precision);
+    x = fminf(fmaxf(x, lo), hi) * precision;
+    out[i] = (short)x;
+}
+
 // every problem = one image t (both polarisations pooled, as the reference's boolean-mask indexing does)
 struct SrcS1 {
     const float* s1; int per_image;
@@ -55,6 +67,14 @@ ttc_status codec_f32_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* 
     if (n == 0) return TTC_OK;
     if (!d_in || !d_out || n < 0) return c->fail(TTC_ERR_ARG, "float_to_u16: bad argument");
     hipLaunchKernelGGL(k_f32_to_u16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (long)n, d_out);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+ttc_status codec_f32_to_i16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, hipStream_t s) {
+    if (n == 0) return TTC_OK;
+    if (!d_in || !d_out || n < 0 || !(precision > 0.f)) return c->fail(TTC_ERR_ARG, "float_to_int16: bad argument");
+    hipLaunchKernelGGL(k_f32_to_i16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in, (long)n, precision, d_out);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }

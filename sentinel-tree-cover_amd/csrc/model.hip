@@ -212,6 +212,40 @@ __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__
     out[(long)n * P + p] = sigm(logit);
 }
 
+// ---- feature taps (--gen_feats, job.py:1429-1445, tensors named at :1808-1809) -------------------------
+// early = the bi-ConvGRU output (`gru_drop/.../Merge:0`, inference: identity), [n, W, W, 64] NHWC
+__global__ void k_tap_early(const float* __restrict__ gru_out, int W, int N, float* __restrict__ out) {
+    const int Wp = W + 2;
+    const long PP = (long)Wp * Wp, total = (long)N * W * W * 64;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int ch = (int)(id & 63);
+    const long pix = id >> 6;
+    const int n = (int)(pix / ((long)W * W)), r = (int)(pix - (long)n * W * W);
+    const int y = r / W, x = r - y * W;
+    out[id] = gru_out[((long)n * 64 + ch) * PP + (long)(y + 1) * Wp + (x + 1)];
+}
+// late = output of the last conv_swish_gn block after its sSE gate (`csse_out_mul/mul:0`), [n, o, o, C] NHWC
+__global__ void k_tap_late(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
+                           float* __restrict__ out, int C, int P) {
+    extern __shared__ float sm[];            // scale shift ssew
+    const int n = blockIdx.y, cpg = C / 8;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mean = gn[((long)n * 8 + c / cpg) * 2], rstd = gn[((long)n * 8 + c / cpg) * 2 + 1];
+        const float sc = rstd * prm[c];
+        sm[c] = sc; sm[C + c] = prm[C + c] - mean * sc; sm[2 * C + c] = prm[2 * C + c];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* y = yraw + (long)n * C * P + p;
+    float gate = prm[3 * C];
+    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * P] * sm[c] + sm[C + c]);
+    gate = sigm(gate);
+    float* o = out + ((long)n * P + p) * C;
+    for (int c = 0; c < C; ++c) o[c] = (y[(long)c * P] * sm[c] + sm[C + c]) * gate;
+}
+
 struct Geo {
     int W, Wp, L, c1, c2, u2, u3, o;
     explicit Geo(const ttc_config& c) : W(c.win_in), Wp(c.win_in + 2), L(c.length) {
@@ -478,5 +512,25 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
                            prm(7), sm + c->small_off["head/"], d_out, F, Po);
         TTC_HIP(c, hipGetLastError());
     }
+    return TTC_OK;
+}
+
+// the two feature tensors of the forward that has just run for the same n (buffers are still in the workspace)
+ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStream_t s) {
+    if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
+    const Geo g(c->cfg);
+    const int F = c->cfg.base_filters;
+    KTimer kt(c, "taps", s);
+    if (d_early) {
+        const long total = (long)n * g.W * g.W * 64;
+        hipLaunchKernelGGL(k_tap_early, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru_out, g.W, n, d_early);
+    }
+    if (d_late) {
+        const int Po = g.o * g.o;
+        const float* gn7 = c->gn + (size_t)7 * c->cfg.max_windows * 2 * 32;
+        hipLaunchKernelGGL(k_tap_late, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
+                           c->d_small + c->small_off["out/"], d_late, F, Po);
+    }
+    TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }

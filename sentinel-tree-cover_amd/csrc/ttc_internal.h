@@ -140,6 +140,7 @@ ttc_status model_alloc(ttc_ctx* c);
 ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n);
 ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s);
 ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStream_t s);
+ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStream_t s);
 // dsen2.hip
 ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n);
 

@@ -36,6 +36,8 @@ max_all = [0.2691233691920348, 0.3740291447318227, 0.5171435111009385, 0.6027466
 PREDICT_INP = "predict/Placeholder:0"
 PREDICT_LENGTH = "predict/PlaceholderWithDefault:0"
 PREDICT_LOGITS = ("predict/conv2d/Sigmoid:0", "predict/conv2d_13/Sigmoid:0")
+PREDICT_LATEFEATS = "predict/csse_out_mul/mul:0"                        # job.py:1808
+PREDICT_EARLYFEATS = "predict/gru_drop/drop_block2d/cond/Merge:0"       # job.py:1809
 SUPERRESOLVE_INP = "superresolve/Placeholder:0"
 SUPERRESOLVE_INP_BILINEAR = "superresolve/Placeholder_1:0"
 SUPERRESOLVE_LOGITS = "superresolve/Add_2:0"
@@ -81,6 +83,10 @@ class TTCSession:
                 if PREDICT_LENGTH in feeds and int(np.asarray(feeds[PREDICT_LENGTH]).ravel()[0]) != self.length:
                     raise ValueError("predict_length does not match the session's ConvGRU length")
                 outs.append(self.ctx.forward_windows(x).cpu().numpy()[..., np.newaxis])
+            elif n in (PREDICT_LATEFEATS, PREDICT_EARLYFEATS):
+                x = np.asarray(feeds[PREDICT_INP], dtype=np.float32)
+                _, early, late = self.ctx.forward_taps(x, early=n == PREDICT_EARLYFEATS, late=n == PREDICT_LATEFEATS)
+                outs.append((early if n == PREDICT_EARLYFEATS else late).cpu().numpy())
             elif n == SUPERRESOLVE_LOGITS or n.endswith("Add_2:0"):
                 outs.append(self.ctx.dsen2_forward(feeds[SUPERRESOLVE_INP], feeds[SUPERRESOLVE_INP_BILINEAR]).cpu().numpy())
             else:
@@ -102,6 +108,24 @@ def to_float32(arr, sess):
 def to_int16(arr, sess):
     """src/tof/tof_downloading.py:51-61: trunc(clip(x, 0, 1) * 65535) as uint16 (numpy, host copy)."""
     return sess.ctx.to_int16(arr).cpu().numpy().view(np.uint16)
+
+
+def float_to_int16(arr, sess, precision=1000):
+    """job.py:174-180 on the device; returns a numpy int16 array."""
+    return sess.ctx.float_to_int16(arr, precision).cpu().numpy()
+
+
+def predict_features(subtile, sess, size=SIZE):
+    """The --gen_feats branch of process_subtiles (job.py:1429-1445) for one window: the early (bi-ConvGRU) and late
+    (last U-Net block) feature maps, first 32 channels each, centre-cropped to `size` like predict_subtile (:360-362),
+    quantised with float_to_int16 and concatenated -> int16 [size, size, 64].  Also returns the probabilities."""
+    x = np.asarray(subtile, dtype=np.float32)[np.newaxis]
+    probs, early, late = sess.ctx.forward_taps(x)
+    clip = (early.shape[1] - size) // 2
+    early = early[0, clip:early.shape[1] - clip, clip:early.shape[2] - clip, :32] if clip > 0 else early[0, ..., :32]
+    late = late[0, ..., :32]
+    feats = sess.ctx.torch.cat([sess.ctx.float_to_int16(early.contiguous()), sess.ctx.float_to_int16(late.contiguous())], -1)
+    return probs[0].cpu().numpy(), feats.cpu().numpy()
 
 
 def sentinel1_to_db(s1_u16, sess):

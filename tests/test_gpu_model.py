@@ -90,6 +90,39 @@ def test_forward_bf16x3_matches_oracle(W, L, N):
         assert np.isfinite(yg).all()
 
 
+def test_feature_taps_match_oracle():
+    """--gen_feats (job.py:1429-1445): early / late feature tensors, their Session.run names, the int16 packing"""
+    import torch
+    from oracle import restate_model as M, restate_numpy as R
+    from ttc import job, weights as Wt
+    from tests.helpers import golden
+    W, L, N = 44, 2, 2
+    w = Wt.synth_weights(3)
+    x = synth.synth_windows(seed=4, N=N, L=L, W=W)
+    probs, early, late = M.TreeCoverNet(w, dtype=torch.float32).features(x)
+    sess = job.TTCSession(w, win_in=W, length=L, max_windows=N, dsen2_weights=None)
+    gp, ge, gl = sess.ctx.forward_taps(x)
+    fails = []
+    for name, got, ref, tol in [("probs", gp.cpu().numpy(), probs[..., 0], PROB_TOL), ("early", ge.cpu().numpy(), early, 2e-5),
+                                ("late", gl.cpu().numpy(), late, 1e-4)]:
+        ok, m = _cmp(name, got, ref, tol); ok or fails.append(m)
+    assert not fails, "\n".join(fails)
+    via = sess.run([job.PREDICT_EARLYFEATS, job.PREDICT_LATEFEATS], feed_dict={job.PREDICT_INP: x})
+    np.testing.assert_array_equal(via[0], ge.cpu().numpy())
+    np.testing.assert_array_equal(via[1], gl.cpu().numpy())
+    # int16 packing: bit-exact against the reference's float_to_int16 golden vector and on the features themselves
+    g = golden("float_to_int16.npz")
+    np.testing.assert_array_equal(job.float_to_int16(g["x"], sess), g["y"])
+    size = W - 14
+    p1, feats = job.predict_features(x[0], sess, size=size)
+    clip = (W - size) // 2
+    want = np.concatenate([R.float_to_int16(ge.cpu().numpy()[0, clip:-clip, clip:-clip, :32]),
+                           R.float_to_int16(gl.cpu().numpy()[0, ..., :32])], -1)
+    assert feats.dtype == np.int16 and feats.shape == (size, size, 64)
+    np.testing.assert_array_equal(feats, want)
+    np.testing.assert_array_equal(p1, gp.cpu().numpy()[0])
+
+
 def test_errors_are_loud():
     from ttc import _lib, weights as Wt
     ctx = _lib.Context(win_in=44, length=1, max_windows=1)

@@ -121,3 +121,8 @@ def test_superresolve_tiling_quirks():
     # the dead branch: x in [0,507], y in [550,617] is never refined
     np.testing.assert_array_equal(res[:, :508, 550:, 4:], inp[:, :508, 550:, 4:])
     assert not np.allclose(res[:, :508, :550, 4:], inp[:, :508, :550, 4:])
+
+
+def test_float_to_int16_matches_reference():
+    g = golden("float_to_int16.npz")
+    np.testing.assert_array_equal(O.float_to_int16(g["x"]), g["y"])

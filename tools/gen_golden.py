@@ -59,6 +59,9 @@ def main():
     s1db = s1f.copy()
     s1db[..., -1] = J.convert_to_db(s1db[..., -1], 22)
     s1db[..., -2] = J.convert_to_db(s1db[..., -2], 22)
+    fi = np.concatenate([(np.random.default_rng(99).random(500) * 80 - 40).astype(np.float32),
+                         np.float32([np.nan, 0, -0.0, 32.767, 32.7675, -32.768, -32.7685, 1e9, -1e9, 0.0004999, 0.0005, -0.0009999, 12.3456])])
+    np.savez_compressed(os.path.join(OUT, "float_to_int16.npz"), x=fi, y=J.float_to_int16(fi.copy()))
     np.savez_compressed(os.path.join(OUT, "codecs.npz"), u16=u, to_float32=TD.to_float32(u),
                         f32=f, to_int16=TD.to_int16(f), db_in=f, db_out=J.convert_to_db(f.copy(), 22),
                         s1_u16=s1u, s1_db=s1db.astype(np.float32))
