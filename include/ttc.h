@@ -174,6 +174,12 @@ ttc_status ttc_mosaic(ttc_ctx* ctx, const float* d_windows, int32_t n, const int
                       int32_t size, int32_t out_rows, int32_t out_cols,
                       uint8_t* d_out_u8, float* d_out_f32, void* stream);
 
+/* == load_mosaic_predictions(feats_folder, depth = 64), job.py:1552-1592 (feature export): Gaussian blend of the
+ * int16 feature windows.  d_feats [n, size, size, depth] int16; h_xy as above; d_out [depth, out_rows, out_cols] int16,
+ * 0 where no window covers a pixel. */
+ttc_status ttc_mosaic_features(ttc_ctx* ctx, const int16_t* d_feats, int32_t n, const int32_t* h_xy, int32_t size,
+                               int32_t depth, int32_t out_rows, int32_t out_cols, int16_t* d_out, void* stream);
+
 /* ---- 20 m -> 10 m -------------------------------------------------------------------
  * DSen2-lite on one padded window batch: == sess.run(superresolve_logits, ...) in
  * superresolve_large_tile._worker_fn, job.py:112-118.

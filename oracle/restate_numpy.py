@@ -529,6 +529,28 @@ def mosaic_predictions(windows: dict, size=158, sigma=36, return_float=False):
 
 
 # --------------------------------------------------------------------------- 20 m -> 10 m
+def mosaic_features(windows: dict, size, depth):
+    """job.py:1515-1592, depth > 1 (feature export): {(outer, inner): int16 [size, size, depth]} -> int16
+    [depth, max_outer + size, max_inner + size].  Gaussian weights without the no-data handling of depth 1."""
+    keys = sorted(windows.keys())
+    max_x = max(k[0] for k in keys) + size
+    max_y = max(k[1] for k in keys) + size
+    n = len(keys)
+    out = np.zeros((depth, max_x, max_y), dtype=np.int16)
+    for start in range(0, depth, 8):
+        end = min(start + 8, depth)
+        preds = np.full((end - start, max_x, max_y, n), np.nan, dtype=np.float32)
+        mults = np.zeros((1, max_x, max_y, n), dtype=np.float32)
+        for i, (a, b) in enumerate(keys):
+            p = windows[(a, b)][..., start:end].T.astype(np.float32)
+            preds[:, a:a + size, b:b + size, i] = p
+            mults[:, a:a + size, b:b + size, i] = fspecial_gauss(size, 36)
+        with np.errstate(all='ignore'):
+            mults = mults / np.sum(mults, axis=-1)[..., np.newaxis]
+            out[start:end] = np.int16(np.nansum(preds * mults, axis=-1))
+    return out
+
+
 def resize_bilinear(img, shape):
     """skimage.transform.resize(img, shape, order=1) as skimage >= 0.19 evaluates it for
     upsampling: scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) in float64.

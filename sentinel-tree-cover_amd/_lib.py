@@ -21,7 +21,7 @@ EXPORTS = [
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
-    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16",
+    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -75,6 +75,7 @@ def load():
     lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
     lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
+    lib.ttc_mosaic_features.argtypes = [P, VP, I32, VP, I32, I32, I32, I32, VP, VP]
     lib.ttc_forward_taps.argtypes = [P, VP, I32, VP, VP, VP, VP]
     lib.ttc_float_to_int16.argtypes = [P, VP, C.c_int64, C.c_float, VP, VP]
     lib.ttc_u16_to_float.argtypes = [P, VP, C.c_int64, VP, VP]
@@ -237,6 +238,18 @@ class Context:
                                         C.c_void_p(u8.data_ptr()), C.c_void_p(f32.data_ptr()) if want_float else None,
                                         self._stream()), "ttc_mosaic")
         return u8, f32
+
+    def mosaic_features(self, feats, xy, size, depth, rows, cols):
+        """feats [n, size, size, depth] int16 (numpy / cuda), xy [n, 2] int32 (folder_x, folder_y) -> cuda int16 [depth, rows, cols]"""
+        t = self.torch
+        fd = feats if isinstance(feats, t.Tensor) else t.from_numpy(np.ascontiguousarray(feats, dtype=np.int16))
+        fd = fd.to(f"cuda:{self.device}").contiguous()
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        out = t.empty((depth, rows, cols), dtype=t.int16, device=fd.device)
+        self._check(self.lib.ttc_mosaic_features(self._h, C.c_void_p(fd.data_ptr()), int(fd.shape[0]),
+                                                 xy.ctypes.data_as(C.POINTER(C.c_int32)), size, depth, rows, cols,
+                                                 C.c_void_p(out.data_ptr()), self._stream()), "ttc_mosaic_features")
+        return out
 
     def forward_taps(self, x, early=True, late=True):
         """forward + feature taps: -> (probs [n, o, o], early [n, W, W, 64] | None, late [n, o, o, 64] | None), cuda float32"""

@@ -26,6 +26,9 @@ ttc_status codec_f32_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* 
 ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s);
 ttc_status codec_f32_to_i16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, hipStream_t s);
 
+ttc_status mosaic_features(ttc_ctx* c, const int16_t* d_feats, int n, const int32_t* h_xy, int size, int depth, int rows, int cols,
+                           int16_t* d_out, hipStream_t s);
+
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
         float ms = 0.f;
@@ -99,6 +102,12 @@ ttc_status ttc_forward_taps(ttc_ctx* c, const float* d_in, int32_t n, float* d_o
     TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
     TTC_CHECK(model_forward_frames(c, n, d_out, s));
     return model_taps(c, n, d_early, d_late, s);
+}
+
+ttc_status ttc_mosaic_features(ttc_ctx* c, const int16_t* d_feats, int32_t n, const int32_t* h_xy, int32_t size, int32_t depth,
+                               int32_t out_rows, int32_t out_cols, int16_t* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return mosaic_features(c, d_feats, n, h_xy, size, depth, out_rows, out_cols, d_out, static_cast<hipStream_t>(stream));
 }
 
 ttc_status ttc_float_to_int16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, void* stream) {

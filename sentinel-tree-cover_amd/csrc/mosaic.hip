@@ -147,7 +147,57 @@ __global__ void k_mos_dil_cols(const unsigned char* __restrict__ tmp, int rows, 
     if (v) u8[i] = 255;
 }
 
+// feature mosaic, depth > 1 (job.py:1552-1592): plain Gaussian blend of the int16 feature windows, no no-data logic;
+// uncovered pixels give 0 (nansum of nothing).  feats [n][size][size][depth], out [depth][rows][cols].
+__global__ void k_mos_feats(const short* __restrict__ feats, MWin mw, int size, int depth, int rows, int cols, double inv2s2,
+                            short* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int R = i / cols, C = i % cols;
+    const int half = size / 2 - 1;
+    int wj[8];
+    float wg[8];
+    int nw = 0;
+    float wsum = 0.f;
+    for (int j = 0; j < mw.n && nw < 8; ++j) {
+        const int rr = R - mw.fy[j], cc = C - mw.fx[j];
+        if (rr < 0 || rr >= size || cc < 0 || cc >= size) continue;
+        const int a = rr - half, b = cc - half;
+        wg[nw] = (float)exp(-((double)(a * a + b * b)) * inv2s2);
+        wj[nw] = (j * size + cc) * size + rr;                  // window j, element [cc][rr]
+        wsum += wg[nw];
+        ++nw;
+    }
+    for (int k = 0; k < nw; ++k) wg[k] = wg[k] / wsum;
+    for (int d = 0; d < depth; ++d) {
+        float acc = 0.f;
+        for (int k = 0; k < nw; ++k) acc += (float)feats[(long)wj[k] * depth + d] * wg[k];
+        out[(long)d * rows * cols + i] = (short)acc;
+    }
+}
+
 }  // namespace
+
+ttc_status mosaic_features(ttc_ctx* c, const int16_t* d_feats, int n, const int32_t* h_xy, int size, int depth, int rows, int cols,
+                           int16_t* d_out, hipStream_t s) {
+    if (!d_feats || !h_xy || !d_out) return c->fail(TTC_ERR_ARG, "mosaic_features: null argument");
+    if (n < 1 || n > kMaxWin || depth < 1) return c->fail(TTC_ERR_ARG, "mosaic_features: window count must be in [1, 64], depth >= 1");
+    if (size % 2 != 0) return c->fail(TTC_ERR_ARG, "mosaic_features: window size must be even");
+    MWin mw{};
+    mw.n = n;
+    for (int i = 0; i < n; ++i) {
+        mw.fx[i] = h_xy[2 * i]; mw.fy[i] = h_xy[2 * i + 1];
+        if (mw.fx[i] < 0 || mw.fy[i] < 0 || mw.fx[i] + size > cols || mw.fy[i] + size > rows)
+            return c->fail(TTC_ERR_ARG, "mosaic_features: window outside the output raster");
+    }
+    KTimer kt(c, "mosaic_features", s);
+    const int np = rows * cols;
+    hipLaunchKernelGGL(k_mos_feats, dim3((np + 255) / 256), dim3(256), 0, s, d_feats, mw, size, depth, rows, cols,
+                       1.0 / (2.0 * 36.0 * 36.0), d_out);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
 
 ttc_status mosaic_run(ttc_ctx* c, const float* d_windows, int n, const int32_t* h_xy, int size, int rows, int cols,
                       uint8_t* d_u8, float* d_f32, hipStream_t s) {

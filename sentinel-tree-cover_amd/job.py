@@ -210,13 +210,19 @@ def process_subtiles(x, y, s2, dates, interp, s1, dem, sess, bbx=None, size=SIZE
 
 
 def load_mosaic_predictions(windows, depth=1, sess=None, size=SIZE, return_float=False):
-    """job.py:1515-1641 for depth == 1, from the dict returned by process_subtiles.
-    Returns uint8 [max_y + size, max_x + size] -- transposed like the reference (job.py:1578)."""
-    if depth != 1:
-        raise NotImplementedError("feature mosaics (depth > 1) are outside the built path (SURVEY.md 8f-4)")
+    """job.py:1515-1641, from the dict returned by process_subtiles (depth == 1) or a dict of int16 feature windows
+    [size, size, depth] (depth > 1, the --gen_feats branch, :1552-1592).
+    Returns uint8 [max_y + size, max_x + size] -- transposed like the reference (job.py:1578) -- or int16
+    [depth, max_y + size, max_x + size]."""
     if sess is None:
         raise ValueError("load_mosaic_predictions needs the TTCSession whose GPU holds the windows")
     keys = sorted(windows.keys())
+    if depth != 1:
+        stack = np.stack([np.asarray(windows[k], dtype=np.int16)[..., :depth] for k in keys])
+        xy = np.array([[fx, fy] for (fy, fx) in keys], dtype=np.int32)
+        rows = int(max(k[0] for k in keys) + size)
+        cols = int(max(k[1] for k in keys) + size)
+        return sess.ctx.mosaic_features(stack, xy, size, depth, rows, cols).cpu().numpy()
     stack = np.stack([np.asarray(windows[k], dtype=np.float32) for k in keys])
     xy = np.array([[fx, fy] for (fy, fx) in keys], dtype=np.int32)
     rows = int(max(k[0] for k in keys) + size)

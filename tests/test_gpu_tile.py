@@ -212,6 +212,19 @@ def test_bf16x3_tile_end_to_end_vs_oracle():
     _report("superresolve tile (bf16x3)", dd.cpu().numpy(), ref, 2e-4)
 
 
+def test_feature_mosaic_matches_reference():
+    """depth > 1 branch of load_mosaic_predictions (feature export) against the reference's own output"""
+    from ttc import job
+    sess, _ = _session(44, 2)
+    g = golden("mosaic_features.npz")
+    wins = {tuple(int(v) for v in k): g["windows"][i] for i, k in enumerate(g["keys"])}
+    got = job.load_mosaic_predictions(wins, depth=16, sess=sess, size=30)
+    assert got.shape == g["mosaic"].shape and got.dtype == np.int16
+    d = np.abs(got.astype(int) - g["mosaic"].astype(int))
+    print(f"[parity] feature mosaic: max|d| = {d.max()}, differing = {(d > 0).mean():.2e}")
+    assert d.max() <= 1 and (d > 0).mean() < 1e-2
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 1e-4)])
 def test_dsen2_ragged_windows(precision, tol):
     """odd / tiny window sizes: planes whose size is not a multiple of 4 take the conv engines' unaligned staging path"""

@@ -126,3 +126,12 @@ def test_superresolve_tiling_quirks():
 def test_float_to_int16_matches_reference():
     g = golden("float_to_int16.npz")
     np.testing.assert_array_equal(O.float_to_int16(g["x"]), g["y"])
+
+
+def test_feature_mosaic_matches_reference():
+    g = golden("mosaic_features.npz")
+    wins = {tuple(int(v) for v in k): g["windows"][i] for i, k in enumerate(g["keys"])}
+    got = O.mosaic_features(wins, size=30, depth=16)
+    assert got.shape == g["mosaic"].shape and got.dtype == np.int16
+    d = np.abs(got.astype(int) - g["mosaic"].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-2, (d.max(), (d > 0).mean())     # float32 summation follows os.listdir order

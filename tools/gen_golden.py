@@ -202,6 +202,25 @@ def main():
                         windows_permille=np.round(np.stack([mw[tuple(k)] for k in mk]) * 1000).astype(np.int32),
                         mosaic=J.load_mosaic_predictions(proc, depth=1))
 
+    # ---- feature mosaic (depth > 1 branch of load_mosaic_predictions), small geometry: SIZE 30, 3 x 3 windows, depth 16 ----
+    procf = os.path.join(scratch, "mosf") + "/"
+    rf = np.random.default_rng(17)
+    old_size = J.SIZE
+    J.SIZE = 30
+    fk, fw = [], []
+    for a in (0, 22, 44):            # outer folder
+        for b in (0, 20, 44):        # file name
+            arr = rf.integers(-3000, 12000, size=(30, 30, 16)).astype(np.int16)
+            os.makedirs(procf + str(a), exist_ok=True)
+            np.save(procf + f"{a}/{b}.npy", arr)
+            fk.append((a, b)); fw.append(arr)
+    try:
+        fm = J.load_mosaic_predictions(procf, depth=16)
+    finally:
+        J.SIZE = old_size
+    np.savez_compressed(os.path.join(OUT, "mosaic_features.npz"), keys=np.array(fk), windows=np.stack(fw), mosaic=fm)
+    print("feature mosaic", fm.shape, fm.dtype)
+
     # ---- cloud gap-fill (stdlib RNG pinned: the reference samples with random.shuffle) -----
     tiles, gdates, probs, pf = synth.synth_gapfill_scene(31, 6, 224, 224)
     ia = CR.id_areas_to_interp(tiles.copy(), probs.copy(), probs.copy(), gdates, pfcps=pf)
