@@ -209,6 +209,8 @@ ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t 
 /* ---- introspection for parity tests -------------------------------------------------
  * Copies a named internal activation (device) to host after synchronising the device.
  * Returns TTC_ERR_ARG for unknown names; *n_floats is the element count.  Test aid only. */
+/* on != 0: subsequent forwards also write intermediates that the fused kernels otherwise keep in registers ("u"). */
+ttc_status ttc_debug_keep(ttc_ctx* ctx, int32_t on);
 ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t cap_floats,
                            size_t* n_floats);
 /* average device time (ms) of the named kernel family over the launches since the last

@@ -21,7 +21,7 @@ EXPORTS = [
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
-    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features",
+    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -75,6 +75,7 @@ def load():
     lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
     lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
+    lib.ttc_debug_keep.argtypes = [P, I32]
     lib.ttc_mosaic_features.argtypes = [P, VP, I32, VP, I32, I32, I32, I32, VP, VP]
     lib.ttc_forward_taps.argtypes = [P, VP, I32, VP, VP, VP, VP]
     lib.ttc_float_to_int16.argtypes = [P, VP, C.c_int64, C.c_float, VP, VP]
@@ -145,6 +146,9 @@ class Context:
         if dtype is not None and x.dtype != dtype:
             x = x.to(dtype)
         return x.to(f"cuda:{self.device}", non_blocking=False).contiguous()
+
+    def keep_intermediates(self, on=True):
+        self._check(self.lib.ttc_debug_keep(self._h, 1 if on else 0), "ttc_debug_keep")
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

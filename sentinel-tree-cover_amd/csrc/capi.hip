@@ -194,6 +194,12 @@ ttc_status ttc_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int32_t T, int32_t X,
     return codec_s1_to_db(c, d_u16, T, X, Y, d_out, static_cast<hipStream_t>(stream));
 }
 
+ttc_status ttc_debug_keep(ttc_ctx* c, int32_t on) {
+    if (!c) return TTC_ERR_ARG;
+    c->keep_debug = on != 0;
+    return TTC_OK;
+}
+
 ttc_status ttc_debug_fetch(ttc_ctx* c, const char* name, float* h_dst, size_t cap, size_t* n_floats) {
     if (!c || !name) return TTC_ERR_ARG;
     auto it = c->named.find(name);

@@ -58,37 +58,30 @@ __global__ void k_gn_finalize(const float* __restrict__ stats, float* __restrict
 
 // ---------------------------------------------------------------------------------------
 // ConvGRU, after the gates conv (model.py:259-270):
-//   r = sigmoid(GN(y[:32])), u = sigmoid(GN(y[32:])); writes r*h (reflect-padded) and u.
+//   r = sigmoid(GN(y[:32])); writes r*h (reflect-padded).  The update gate u = sigmoid(GN(y[32:])) is formed where it
+//   is consumed (k_gru_apply2) instead of making a round trip through HBM.
 struct GruParams { const float* base; long dir_stride; };   // per-direction parameter block
 // parameter block layout (floats): gr[32] br[32] gu[32] bu[32] k1[32] gy[32] by[32]
 constexpr int kGruParamFloats = 7 * 32;
 
 __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm,
-                             const float* __restrict__ hcur, float* __restrict__ rh, float* __restrict__ u,
-                             int W, int N) {
+                             const float* __restrict__ hcur, float* __restrict__ rh, int W, int N) {
     const int Wp = W + 2, PP = Wp * Wp, P = W * W;
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
-    const int sy0 = py - 1, sx0 = px - 1;
-    const bool interior = sy0 >= 0 && sy0 < W && sx0 >= 0 && sx0 < W;
-    const int s = reflect_idx(sy0, W) * W + reflect_idx(sx0, W);
+    const int s = reflect_idx(py - 1, W) * W + reflect_idx(px - 1, W);
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yg + (long)n * 64 * P + s;
     const float* g = gn + (long)n * 32;      // 16 groups x (mean, rstd): 0-7 r, 8-15 u
     const float* h = hcur + (long)n * 32 * PP + p;
     float* o = rh + (long)n * 32 * PP + p;
-    float* uo = u + (long)n * 32 * P + s;
 #pragma unroll 4
     for (int c = 0; c < 32; ++c) {
         const int gi = c >> 2;
         const float r = sigm((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[c] + pr[32 + c]);
         o[(long)c * PP] = r * h[(long)c * PP];
-        if (interior) {
-            const float uu = sigm((y[(long)(32 + c) * P] - g[16 + 2 * gi]) * g[16 + 2 * gi + 1] * pr[64 + c] + pr[96 + c]);
-            uo[(long)c * P] = uu;
-        }
     }
 }
 
@@ -97,7 +90,8 @@ __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restri
 //   (ZoneoutWrapper inference branch, model.py:571-574).  On the last step also writes the
 //   final state zero-padded into gru_out[n][dir*32 + c] (train-model.py:165 concat order).
 __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
-                             const float* __restrict__ u, const float* __restrict__ hcur, float* __restrict__ hnext,
+                             const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
+                             const float* __restrict__ hcur, float* __restrict__ hnext,
                              float* __restrict__ gru_out, int W, int N, float z) {
     const int Wp = W + 2, PP = Wp * Wp, P = W * W;
     const int n = blockIdx.y, dir = n / N;
@@ -110,15 +104,19 @@ __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restri
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yc + (long)n * 32 * P + s;
     const float* g = gn + (long)n * 16;      // 8 groups x (mean, rstd)
-    const float* uu = u + (long)n * 32 * P + s;
+    const float* yu = yg + ((long)n * 64 + 32) * P + s;
+    const float* gu = gn_gates + (long)n * 32 + 16;   // gates groups 8-15 = u
     const float* h = hcur + (long)n * 32 * PP + p;
     float* hn = hnext + (long)n * 32 * PP + p;
     float* go = gru_out ? gru_out + ((long)(n - dir * N) * 64 + dir * 32) * PP + p : nullptr;
+    float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * P + s : nullptr;
 #pragma unroll 4
     for (int c = 0; c < 32; ++c) {
         const int gi = c >> 2;
         const float cand = tanhf((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
-        const float hv = h[(long)c * PP], uv = uu[(long)c * P];
+        const float uv = sigm((yu[(long)c * P] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
+        if (uk) uk[(long)c * P] = uv;
+        const float hv = h[(long)c * PP];
         const float hnew = uv * hv + (1.0f - uv) * cand;
         const float hz = hv * z + hnew * (1.0f - z);
         hn[(long)c * PP] = hz;
@@ -439,7 +437,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         {
             KTimer kt(c, "gru_apply1", s);
             hipLaunchKernelGGL(k_gru_apply1, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
-                               c->h[cur], c->rh, c->ug, g.W, N);
+                               c->h[cur], c->rh, g.W, N);
             TTC_HIP(c, hipGetLastError());
         }
         a.seg[1].base = c->rh;
@@ -451,7 +449,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         {
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
-                               c->ug, c->h[cur], c->h[cur ^ 1], st == g.L - 1 ? c->gru_out : nullptr, g.W, N,
+                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h[cur], c->h[cur ^ 1], st == g.L - 1 ? c->gru_out : nullptr, g.W, N,
                                c->cfg.zoneout);
             TTC_HIP(c, hipGetLastError());
         }

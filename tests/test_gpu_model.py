@@ -42,6 +42,7 @@ def test_single_step_intermediates():
     """L=1: every buffer of the first ConvGRU step and of the U-Net is comparable."""
     W, L, N = 44, 1, 3
     ctx, w, x, ref, tr = _setup(W, L, N)
+    ctx.keep_intermediates(True)              # the update gate u is otherwise never written to HBM
     out = ctx.forward_windows(x).cpu().numpy()
     P = W * W
     fails = []
