@@ -142,12 +142,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # debugging aid for 1-GPU boxes: TTC_BENCH_BACKEND=gloo + TTC_BENCH_DEVICE=0 runs every rank on one device with CPU-staged
+    # collectives, which exercises the multi-rank control flow (barriers, gathers, rank-0-only sections) without RCCL
+    backend = os.environ.get("TTC_BENCH_BACKEND", "nccl")
+    if "TTC_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["TTC_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     size = args.win - 14
     def make_sessions(precision):
@@ -181,14 +189,14 @@ def main():
                 with torch.cuda.stream(st):
                     tile_step(sess, slot)
 
-    def tile_step(sess, slot):
+    def tile_step(sess, slot, gather=True):
         ctx = sess.ctx
         f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(ds1)   # tof_downloading.py:64-72, job.py:699-708
         s2d = ctx.upsample_20m(f10, f20)                              # job.py:734-782
         dint, _, _ = ctx.remove_cloud_and_shadows(s2d, dprobs, None, None)   # cloud_removal.py:888-973 (deterministic sampler)
         ctx.superresolve_tile(s2d, quirks=True)                       # job.py:95-147
         f32, u8 = job.predict_tile(s2d, dates, dint, s1db, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
-        if world > 1:
+        if world > 1 and gather:
             shard.gather_rasters(u8, rank, world, 0, gather_bufs[slot])     # final-mosaic gather (RCCL over xGMI)
         return u8
 
@@ -221,7 +229,7 @@ def main():
         c0 = sessions[0].ctx
         c0.timing(2); c0.kernel_ms(None)
         for _ in range(3):
-            tile_step(sessions[0], 0)
+            tile_step(sessions[0], 0, gather=False)      # rank-local: no collective here
         torch.cuda.synchronize()
         iso_ms, _ = c0.kernel_ms("conv_gates")
         c0.timing(0)

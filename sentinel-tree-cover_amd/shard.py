@@ -19,6 +19,13 @@ def gather_rasters(raster, rank: int, world: int, dst: int = 0, bufs=None):
         return [raster]
     if rank == dst and bufs is None:
         bufs = [torch.empty_like(raster) for _ in range(world)]
+    if raster.is_cuda and dist.get_backend() == "gloo":          # debug runs without RCCL: stage through the host
+        host = [torch.empty(raster.shape, dtype=raster.dtype) for _ in range(world)] if rank == dst else None
+        dist.gather(raster.cpu(), host, dst=dst)
+        if rank == dst:
+            for b, h in zip(bufs, host):
+                b.copy_(h)
+        return bufs if rank == dst else None
     dist.gather(raster, bufs if rank == dst else None, dst=dst)
     return bufs if rank == dst else None
 
@@ -28,6 +35,6 @@ def max_over_ranks(seconds: float, device, world: int) -> float:
     import torch.distributed as dist
     if world == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
