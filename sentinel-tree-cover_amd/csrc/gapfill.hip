@@ -938,6 +938,20 @@ __global__ void k_sel_init_dates(SelState* __restrict__ st, const int* __restric
     SelState ss; ss.prefix = 0; ss.mask = 0; ss.k = n > 0 ? (n - 1) / 2 : 0;
     st[q] = ss;
 }
+// LDS histogram update with run-length aggregation: neighbouring pixels mostly share the high key bytes, and 64 lanes
+// adding to ONE LDS word serialise (the top-byte pass cost 250-1000 us per launch that way).  A lane whose bin differs
+// from its predecessor's heads a run and adds the run length once.
+__device__ __forceinline__ void hist_add_runs(unsigned* h, int bin /* < 0 = lane does not contribute */) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(bin, 1);
+    const bool head = lane == 0 || prev != bin;
+    const unsigned long long heads = __ballot(head);
+    if (head && bin >= 0) {
+        const unsigned long long rest = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = rest ? __ffsll((long long)rest) : 64 - lane;
+        atomicAdd(&h[bin], (unsigned)len);
+    }
+}
 __global__ void k_hist_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
                            int npix, const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
     __shared__ unsigned h[20 * 256];
@@ -946,15 +960,18 @@ __global__ void k_hist_all(const float* __restrict__ ref_all, const float* __res
     for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x) h[k] = 0;
     if (threadIdx.x < 20) { pf[threadIdx.x] = st[i * 20 + threadIdx.x].prefix; mk[threadIdx.x] = st[i * 20 + threadIdx.x].mask; }
     __syncthreads();
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
-        if (!((vmask[p] >> i) & 1u)) continue;
-        const float* r = ref_all + ((long)i * npix + p) * 10;
-        const float* sv = tiles + ((long)i * npix + p) * 10;
+    const int stride = gridDim.x * blockDim.x;
+    for (int p0 = blockIdx.x * blockDim.x; p0 < npix; p0 += stride) {       // block-uniform trip count (wave collectives inside)
+        const int p = p0 + threadIdx.x;
+        const bool valid = p < npix && ((vmask[p] >> i) & 1u);
+        const float* r = ref_all + ((long)i * npix + (valid ? p : 0)) * 10;
+        const float* sv = tiles + ((long)i * npix + (valid ? p : 0)) * 10;
 #pragma unroll
         for (int ch = 0; ch < 10; ++ch) {
             const unsigned k0 = fkey(r[ch]), k1 = fkey(sv[ch]);
-            if ((k0 & mk[2 * ch]) == pf[2 * ch]) atomicAdd(&h[(2 * ch) * 256 + ((k0 >> shift) & 255u)], 1u);
-            if ((k1 & mk[2 * ch + 1]) == pf[2 * ch + 1]) atomicAdd(&h[(2 * ch + 1) * 256 + ((k1 >> shift) & 255u)], 1u);
+            const bool in0 = valid && (k0 & mk[2 * ch]) == pf[2 * ch], in1 = valid && (k1 & mk[2 * ch + 1]) == pf[2 * ch + 1];
+            hist_add_runs(h + (2 * ch) * 256, in0 ? (int)((k0 >> shift) & 255u) : -1);
+            hist_add_runs(h + (2 * ch + 1) * 256, in1 ? (int)((k1 >> shift) & 255u) : -1);
         }
     }
     __syncthreads();
@@ -964,7 +981,7 @@ __global__ void k_hist_all(const float* __restrict__ ref_all, const float* __res
 // per (date, column): sum, sum of squares (double), #(v <= lower median), min key of (v > lower median)
 struct ColStat { double sum, sq; int n_le; unsigned min_gt; };
 __global__ void k_stat_init(ColStat* cs) { cs[threadIdx.x].sum = 0.0; cs[threadIdx.x].sq = 0.0; cs[threadIdx.x].n_le = 0; cs[threadIdx.x].min_gt = 0xffffffffu; }
-__global__ void k_stat_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
+__global__ __launch_bounds__(256, 2) void k_stat_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
                            int npix, const SelState* __restrict__ st, ColStat* __restrict__ out) {
     __shared__ double ssum[20], ssq[20];
     __shared__ int sle[20];
@@ -1113,7 +1130,7 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
             hipLaunchKernelGGL(k_sel_pick, dim3(T * 20), dim3(64), 0, s, st, shift, hist);
         }
         hipLaunchKernelGGL(k_stat_init, dim3(1), dim3(kMaxT * 20), 0, s, cs);
-        hipLaunchKernelGGL(k_stat_all, dim3(48, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, cs);
+        hipLaunchKernelGGL(k_stat_all, dim3(192, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, cs);
         hipLaunchKernelGGL(k_params_all, dim3(1), dim3(64), 0, s, st, cs, count, count + kMaxT, T, ap);
         TTC_HIP(c, hipGetLastError());
     }
