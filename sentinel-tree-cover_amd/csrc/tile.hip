@@ -155,16 +155,45 @@ __device__ __forceinline__ void smooth_store(const float (&v)[TM], const WMat& w
     }
 }
 
+// One wave per 64 pixels.  The [T, X, Y, 10] stack is pixel-major (40-byte records): a thread-per-pixel load touches 20
+// cache lines per instruction for 512 useful bytes, and the kernel sat at 0.76 TB/s.  The wave therefore copies its
+// 64 x 10 floats per date into LDS with coalesced float4 loads (all T x 3 loads of a lane in flight at once) and every
+// lane then picks its pixel's series out of LDS (40-byte lane stride: conflict-free for ds_read_b64).
 template <int TM>
-__global__ __launch_bounds__(256) void k_tile_temporal(const float* __restrict__ s2, WMat wm, int npix, int L,
-                                                       float* __restrict__ sm, float* __restrict__ med) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
+__global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ s2, WMat wm, int npix, int L,
+                                                      float* __restrict__ sm, float* __restrict__ med) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];      // [T][64 px][10]
+    const int lane = threadIdx.x;
+    const int p0 = blockIdx.x * 64;
     const int T = wm.T;
+    {
+        const int nfl = min(64, npix - p0) * 10;                      // floats of this block per date
+        if (nfl == 640 && (npix & 1) == 0) {     // (odd pixel counts break the 16-byte alignment of odd dates)
+            // global -> LDS DMA (wave-uniform LDS base + lane * 16 = exactly this linear copy); no staging registers
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (t < T) {
+                    const float* src = s2 + ((long)t * npix + p0) * 10;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (k < 2 || lane < 32)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (lane + 64 * k) * 4),
+                                                             (__attribute__((address_space(3))) void*)(stage + t * 640 + 256 * k), 16, 0, 0);
+                    }
+                }
+            }
+        } else {                                                       // ragged last block / unaligned: element-wise
+            for (int t = 0; t < T; ++t)
+                for (int i = lane; i < nfl; i += 64) stage[t * 640 + i] = s2[((long)t * npix + p0) * 10 + i];
+        }
+    }
+    __syncthreads();
+    const int p = p0 + lane;
+    if (p >= npix) return;
     const unsigned all = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
     const long fstride = 14L * npix;     // sm frame stride
-    const float2* px = reinterpret_cast<const float2*>(s2) + (long)p * 5;
-    const long tstride = (long)npix * 5;  // float2 per date
+    const float2* px = reinterpret_cast<const float2*>(stage) + lane * 5;
+    const int tstride = 320;             // float2 per date in the stage
 
     // ---- bands 0,1,2,3,8,9 (the index inputs + the last band) ----
     float b0[TM], b1[TM], b2[TM], b3[TM], b8[TM], b9[TM];
@@ -596,7 +625,13 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     }
     const unsigned gp = (unsigned)((npix + 255) / 256);
     { KTimer kt(c, "tile_temporal", s);
-      LAUNCH_T(k_tile_temporal, T, dim3(gp), dim3(256), 0, s, d_s2, wm, (int)npix, L, sm, med);
+      const int TM = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
+      if (TM == 32) {
+          static bool big_lds = false;
+          if (!big_lds) { TTC_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_temporal<32>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 640 * 4)); big_lds = true; }
+      }
+      LAUNCH_T(k_tile_temporal, T, dim3((unsigned)((npix + 63) / 64)), dim3(64), (size_t)TM * 640 * sizeof(float), s, d_s2, wm, (int)npix, L, sm, med);
       TTC_HIP(c, hipGetLastError()); }
     { KTimer kt(c, "tile_s1", s);
       hipLaunchKernelGGL(k_tile_s1, dim3(gp), dim3(256), 0, s, d_s1, (int)npix, L, s1q, s1med);
