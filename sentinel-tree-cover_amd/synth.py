@@ -120,7 +120,8 @@ def synth_gapfill_scene(seed=31, T=6, H=224, W=224):
             m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
             probs[t][m] = 1.0
             tiles[t][m] += (0.35 if b % 2 == 0 else -0.04)          # cloud / shadow
-    probs[3, : (6 * H) // 10, :] = 1.0            # one date mostly covered (< 40 000 clear px -> multi-date fit)
-    tiles[3, : (6 * H) // 10, :, :] += 0.3
+    big = min(3, T - 1)
+    probs[big, : (6 * H) // 10, :] = 1.0          # one date mostly covered (< 40 000 clear px -> multi-date fit)
+    tiles[big, : (6 * H) // 10, :, :] += 0.3
     tiles = np.clip(tiles, 0.001, 0.98).astype(np.float32)
     return tiles, dates, probs, np.zeros((H, W), dtype=bool)

@@ -86,3 +86,21 @@ def test_deterministic_sampler_is_close_and_reproducible(sess):
     # reference sampling noise: two different seeds of the reference itself differ by about this much
     print(f"[parity] deterministic vs seeded reference: max|d| = {err.max():.3e}, rms = {np.sqrt((err**2).mean()):.3e}")
     assert err.max() < 0.03 and np.sqrt((err ** 2).mean()) < 2e-3
+
+
+@pytest.mark.parametrize("T", [2, 3, 9, 20])
+def test_gapfill_date_count_range(sess, T):
+    """T-template boundaries (8 / 16 / 32 register arrays) and the short-stack window rules of the per-date fit, against
+    the oracle with the reference's sampler replayed (same stdlib RNG stream on both sides)."""
+    from oracle import restate_gapfill as G
+    from ttc import job
+    tiles, dates, probs, pf = synth.synth_gapfill_scene(70 + T, T, 96, 88)
+    random.seed(5)
+    want, wi, wrem = G.remove_cloud_and_shadows(tiles.copy(), probs.copy(), pf.copy())
+    random.seed(5)
+    got, gi, grem = job.remove_cloud_and_shadows(tiles.copy(), probs, probs, dates, pf, sess=sess, sampler="reference")
+    np.testing.assert_array_equal(gi, wi)
+    assert grem == [int(v) for v in wrem]
+    err = np.abs(got - want)
+    print(f"[parity] gap-fill T={T}: max|d| = {err.max():.3e}, mean = {err.mean():.3e}")
+    assert err.max() < 2e-3 and err.mean() < 1e-5

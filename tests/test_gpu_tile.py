@@ -98,6 +98,32 @@ def test_small_tile_all_stages_vs_oracle(L):
     assert np.mean(np.abs(g - r) > 1e-6) < 0.02
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 8, 17, 32])
+def test_tile_date_count_range(T):
+    """register-array template boundaries of the per-pixel kernels (T <= 8 / 16 / 32), and the < 2 dates rule"""
+    import torch
+    from oracle import restate_model as M, restate_numpy as O
+    from ttc import job
+    W, size, L = 44, 30, 4
+    sess, w = _session(W, L)
+    s2, dates, interp, s1, dem = synth.synth_tile(seed=40 + T, T=T, H=100, W=100, cloud_frac=0.2)
+    if T > 2:
+        s2[1, 5:9, 7:11, :] = 0.0
+        s2[T - 1, 20:22, 3:6, 4] = 1.0
+    net = M.TreeCoverNet(w, dtype=torch.float32)
+    pf = lambda win: O.predict_subtile(win, net, size)
+    ref_w = O.process_subtiles(s2.copy(), dates.copy(), interp.copy(), s1.copy(), dem.copy(), pf, size=size, length=L)
+    got = job.process_subtiles(0, 0, s2.copy(), dates, interp, s1, dem, sess, size=size)
+    assert set(got.keys()) == set(ref_w.keys())
+    k = sorted(got.keys())
+    g, r = np.stack([got[a] for a in k]), np.stack([ref_w[a] for a in k])
+    assert np.array_equal(g > 1.0, r > 1.0), "no-data windows differ"
+    if T < 2:
+        assert np.all(g == 255.0)                    # job.py:1418-1422
+    _report(f"windows T={T}", g, r, 1.1e-3)
+    assert np.mean(np.abs(g - r) > 1e-6) < 0.02
+
+
 def test_full_tile_model_inputs_match_reference_feeds():
     """The tensors fed to the model for a 618^2 tile == what the REFERENCE fed its session."""
     from ttc import job
