@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="tiles in flight per GPU per step, each on its own HIP stream + context: one tile's latency-bound "
                          "gap-fill / tile kernels run under another tile's convolutions")
+    ap.add_argument("--from-host", action="store_true",
+                    help="informational: every step uploads the raw tile from pinned host memory first (PCIe-inclusive rate, "
+                         "reported in DESIGN.md, never the headline value)")
     ap.add_argument("--no-alt", action="store_true", help="skip the informational second measurement with the other conv engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -189,7 +192,18 @@ def main():
                 with torch.cuda.stream(st):
                     tile_step(sess, slot)
 
+    pinned = None
+    if args.from_host:
+        pinned = [torch.from_numpy(a).pin_memory() for a in (s2_10.view(np.int16), s2_20.view(np.int16), probs, s1.view(np.int16), dem)]
+
     def tile_step(sess, slot, gather=True):
+        ctx = sess.ctx
+        if pinned is not None:                      # H2D on the tile's own stream: overlaps the other tile's kernels
+            d10_, d20_, dprobs_, ds1_, ddem_ = (t.to(dev, non_blocking=True) for t in pinned)
+            return tile_body(sess, slot, gather, d10_, d20_, dprobs_, ds1_, ddem_)
+        return tile_body(sess, slot, gather, d10, d20, dprobs, ds1, ddem)
+
+    def tile_body(sess, slot, gather, d10, d20, dprobs, ds1, ddem):
         ctx = sess.ctx
         f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(ds1)   # tof_downloading.py:64-72, job.py:699-708
         s2d = ctx.upsample_20m(f10, f20)                              # job.py:734-782
@@ -261,7 +275,8 @@ def main():
                            "dsen2_superresolve(31 windows x T)", "temporal_operator+indices+medians",
                            "window_assembly+normalise", "biConvGRU+UNet forward", "post_masks", "gaussian_mosaic"]
                           + (["rccl_gather_u8"] if world > 1 else []),
-                "not_in_timed_region": ["H2D of the raw tile (inputs resident in HBM)",
+                "not_in_timed_region": [("nothing: the raw tile is uploaded from pinned host memory every step" if args.from_host
+                                         else "H2D of the raw tile (inputs resident in HBM)"),
                                         "cloud/shadow DETECTION (out of scope, SURVEY 8f-1): the mask is an input"],
                 "weights": "synthetic seed 0 (ConvGRU/U-Net weights absent from the reference checkout); DSen2 real",
                 "tiles_per_step_per_gpu": args.inflight, "streams_per_gpu": args.inflight, "win_in": args.win, "length": args.length, "dates": args.dates,
