@@ -361,6 +361,22 @@ __global__ void k_snow_mean(const float* __restrict__ tiles, int T, int npix, fl
     for (int t = 0; t < T; ++t) s += snow_prob_px(tiles + ((long)t * npix + p) * 10);
     snow[p] = s / (float)T;
 }
+// The mean snow probability is re-evaluated for every date because the stack is blended in place (CR.py:372); only ONE
+// date changes between evaluations, so the per-date probabilities are cached and the mean re-sums T floats per pixel
+// (same values, same order) instead of re-reading the whole stack.
+__global__ void k_snow_prob_all(const float* __restrict__ tiles, int T, int npix, float* __restrict__ snowp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)T * npix) return;
+    snowp[i] = snow_prob_px(tiles + i * 10);
+}
+__global__ void k_snow_mean_cached(const float* __restrict__ snowp, int T, int npix, float* __restrict__ snow) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += snowp[(long)t * npix + p];
+    snow[p] = s / (float)T;
+}
 __device__ __forceinline__ float evi_unclipped(const float* v) {          // CR.py:332-345
 #pragma clang fp contract(off)
     const float e = 2.5f * ((v[3] - v[2]) / (((v[3] + (6.0f * v[2])) - (7.5f * v[0])) + 1.0f));
@@ -376,10 +392,21 @@ __global__ void k_date_counts(const float* __restrict__ w, int npix, int date, i
     for (int k = 32; k >= 1; k >>= 1) { a += __shfl_xor(a, k); b += __shfl_xor(b, k); c += __shfl_xor(c, k); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicAdd(&out[1], b); atomicAdd(&out[2], c); }
 }
+// all dates at once (the feather weights and the water mask do not change inside the date loop)
+__global__ void k_date_counts_all(const float* __restrict__ w, int npix, int* __restrict__ out /*[T][4]*/) {
+    const int date = blockIdx.y;
+    int a = 0, b = 0, c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const float v = w[(long)date * npix + p];
+        a += v > 0.f; b += v == 0.f; c += v < 1.f;
+    }
+    for (int k = 32; k >= 1; k >>= 1) { a += __shfl_xor(a, k); b += __shfl_xor(b, k); c += __shfl_xor(c, k); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[date * 4 + 0], a); atomicAdd(&out[date * 4 + 1], b); atomicAdd(&out[date * 4 + 2], c); }
+}
 // training rows of dates [t0, t1): pixels with w_t == 0 and not water, in (t, pixel) order -- 2-level scan compaction
 __global__ void k_rows_count(const float* __restrict__ w, const unsigned char* __restrict__ water, int npix, int t0, int nt,
                              const DatePlan* __restrict__ plan, int* __restrict__ blk) {
-    if (plan) { t0 = plan->t0; nt = plan->nt; }
+    if (plan) { plan += blockIdx.y; blk += (long)blockIdx.y * gridDim.x; t0 = plan->t0; nt = plan->nt; }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0;
     if (i < (long)nt * npix) { const int t = t0 + (int)(i / npix), p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
@@ -391,7 +418,8 @@ __global__ void k_rows_count(const float* __restrict__ w, const unsigned char* _
     __syncthreads();
     if (threadIdx.x == 0) blk[blockIdx.x] = cnt;
 }
-__global__ void k_rows_scan(int* __restrict__ blk, int nblk, int* __restrict__ total) {     // single block exclusive scan
+__global__ void k_rows_scan(int* __restrict__ blk, int nblk, int* __restrict__ total, int total_stride) {   // one block per list
+    blk += (long)blockIdx.x * nblk; total += (long)blockIdx.x * total_stride;
     __shared__ int carry;
     __shared__ int tmp[1024];
     if (threadIdx.x == 0) carry = 0;
@@ -417,7 +445,7 @@ __global__ void k_rows_scan(int* __restrict__ blk, int nblk, int* __restrict__ t
 __global__ void k_rows_fill(const float* __restrict__ w, const unsigned char* __restrict__ water, const float* __restrict__ tiles,
                             int npix, int t0, int nt, const DatePlan* __restrict__ plan, const int* __restrict__ blk,
                             int* __restrict__ rows, float* __restrict__ evi) {
-    if (plan) { t0 = plan->t0; nt = plan->nt; }
+    if (plan) { plan += blockIdx.y; blk += (long)blockIdx.y * gridDim.x; rows += (long)blockIdx.y * 3 * npix; t0 = plan->t0; nt = plan->nt; }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0, t = 0, p = 0;
     if (i < (long)nt * npix) { t = t0 + (int)(i / npix); p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
@@ -429,7 +457,16 @@ __global__ void k_rows_fill(const float* __restrict__ w, const unsigned char* __
     int off = blk[blockIdx.x];
     for (int k = 0; k < wv; ++k) off += wbase[k];
     off += __popcll(m & ((1ull << lane) - 1ull));
-    if (f) { rows[off] = (int)((long)(t - t0) * npix + p); evi[off] = evi_unclipped(tiles + ((long)t * npix + p) * 10); }
+    if (f) { rows[off] = (int)((long)(t - t0) * npix + p); if (evi) evi[off] = evi_unclipped(tiles + ((long)t * npix + p) * 10); }
+}
+// EVI of the listed rows from the CURRENT stack (the list itself is date-loop invariant, the values are not)
+__global__ void k_rows_evi(const int* __restrict__ rows, const DatePlan* __restrict__ plan, const float* __restrict__ tiles, int npix,
+                           float* __restrict__ evi) {
+    const int n = plan->nrows, t0 = plan->t0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int rr = rows[i];
+        evi[i] = evi_unclipped(tiles + ((long)(t0 + rr / npix) * npix + rr % npix) * 10);
+    }
 }
 
 // Z'Z for Z = [clip(x,0.005,1)(10) snow | x(10) snow | y(10)] (32 columns), rows given by an index list with
@@ -507,7 +544,8 @@ __global__ void k_row_weights(const float* __restrict__ evi, int n, Strata st, f
 // tile = tile * (1 - w) + pred * w
 struct Beta { double b[10][11]; int fitted; };
 __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restrict__ w, const float* __restrict__ mosaic,
-                                const float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date) {
+                                const float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date,
+                                float* __restrict__ snowp) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -528,6 +566,7 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
         }
         tv[c] = tv[c] * (1.0f - wd) + pred * wd;
     }
+    snowp[(long)date * npix + p] = snow_prob_px(tv);           // keep the cache of this date current
 }
 
 // ------------------------------------------------------------------------------------------------ a9
@@ -571,9 +610,12 @@ __global__ void k_u8_from_bool(const unsigned char* __restrict__ in, int n, unsi
 }
 
 // ---- device-side control of the per-date fit (no host round trips) --------------------------------
-__global__ void k_date_plan(const int* __restrict__ counters, int npix, int T, int date, DatePlan* __restrict__ plan,
+__global__ void k_date_plan(const int* __restrict__ counters, int npix, int T, DatePlan* __restrict__ plans,
                             int* __restrict__ remove_flags) {
-    if (threadIdx.x) return;
+    const int date = threadIdx.x;
+    if (date >= T) return;
+    counters += date * 4;
+    DatePlan* plan = plans + date;
     const int c0 = counters[0], c1 = counters[1], c2 = counters[2];
     DatePlan p;
     p.proceed = c0 > 0 && c1 > 0 && ((double)c2 / npix) > 0.01;                 // CR.py:377-378
@@ -1158,15 +1200,18 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     float* snow = static_cast<float*>(c->scratch_buf("gf_snow", sizeof(float) * (size_t)npix));
     unsigned char* water2 = static_cast<unsigned char*>(c->scratch_buf("gf_water2", (size_t)npix));
     unsigned char* bits = static_cast<unsigned char*>(c->scratch_buf("gf_bits", 4 * (size_t)npix));
-    int* rows = static_cast<int*>(c->scratch_buf("gf_rows", sizeof(int) * 3 * (size_t)npix));
+    int* rows_all = static_cast<int*>(c->scratch_buf("gf_rows", sizeof(int) * 3 * (size_t)npix * T));
+    float* snowp = static_cast<float*>(c->scratch_buf("gf_snowp", sizeof(float) * (size_t)npix * T));
     float* evi = static_cast<float*>(c->scratch_buf("gf_evi", sizeof(float) * 3 * (size_t)npix));
     float* weight = static_cast<float*>(c->scratch_buf("gf_weight", sizeof(float) * 3 * (size_t)npix));
     const int nblk_rows = (3 * npix + 255) / 256;
-    int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * (nblk_rows + 16)));
+    int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * ((size_t)nblk_rows * T + 16 + 4 * kMaxT)));
     const int gram_blocks = 256;
     double* gpart = static_cast<double*>(c->scratch_buf("gf_gram", sizeof(double) * 1024 * (gram_blocks + 1)));
-    if (!mosaic || !snow || !water2 || !bits || !rows || !evi || !weight || !blk || !gpart) return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
-    int* counters = blk + nblk_rows;                                     // [0..2] date counts, [3] total rows, [4] n_only
+    if (!mosaic || !snow || !water2 || !bits || !rows_all || !snowp || !evi || !weight || !blk || !gpart)
+        return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
+    int* counters = blk + (size_t)nblk_rows * T;                         // a9: [3] total rows, [4] n_only
+    int* date_counts = counters + 16;                                    // [T][4]: n(w > 0), n(w == 0), n(w < 1)
     if (n_to_remove) *n_to_remove = 0;
     const dim3 grid((npix + 255) / 256), b256(256);
 
@@ -1175,7 +1220,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     TTC_CHECK(water_mask(c, d_tiles, T, X, Y, true, false, water2, s));                        // CR.py:936-939
     char* ctl = static_cast<char*>(c->scratch_buf("gf_ctl", 65536));
     if (!ctl) return c->fail(TTC_ERR_NOMEM, "gap-fill control block");
-    DatePlan* plan = reinterpret_cast<DatePlan*>(ctl);                     // 32 B
+    DatePlan* plans = reinterpret_cast<DatePlan*>(ctl + 32768);            // [kMaxT]
     Beta* d_beta = reinterpret_cast<Beta*>(ctl + 64);                      // 888 B
     StrataDev* sd = reinterpret_cast<StrataDev*>(ctl + 1024);
     SelState* st = reinterpret_cast<SelState*>(ctl + 2048);                // 12 problems
@@ -1184,21 +1229,26 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     unsigned* hist = reinterpret_cast<unsigned*>(ctl + 4096);              // 12 * 256 * 4 = 12288 B
     double* Zdev = gpart + 1024L * gram_blocks;
     TTC_HIP(c, hipMemsetAsync(ctl, 0, 4096 + 12288, s));
+    TTC_HIP(c, hipMemsetAsync(date_counts, 0, sizeof(int) * 4 * kMaxT, s));
     const PctList pl6{{2, 20, 40, 60, 80, 98, 0, 0}};
     const int nb3 = (int)((3L * npix + 255) / 256);
 
     KTimer kt(c, "gapfill_dates", s);
+    // date-loop invariants, all dates at once: clear-pixel counts -> plans (which dates train which fit) -> row lists
+    hipLaunchKernelGGL(k_date_counts_all, dim3(32, T), b256, 0, s, d_interp, npix, date_counts);
+    hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, date_counts, npix, T, plans, remove_flags);
+    hipLaunchKernelGGL(k_rows_count, dim3(nb3, T), b256, 0, s, d_interp, water2, npix, 0, 0, plans, blk);
+    hipLaunchKernelGGL(k_rows_scan, dim3(T), dim3(1024), 0, s, blk, nb3, &plans->nrows, (int)(sizeof(DatePlan) / sizeof(int)));
+    hipLaunchKernelGGL(k_rows_fill, dim3(nb3, T), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plans, blk, rows_all, (float*)nullptr);
+    hipLaunchKernelGGL(k_snow_prob_all, dim3((unsigned)(((long)T * npix + 255) / 256)), b256, 0, s, d_tiles, T, npix, snowp);
+    TTC_HIP(c, hipGetLastError());
     std::vector<float> h_evi;
     std::vector<int64_t> h_idx;
     for (int date = 0; date < T; ++date) {
-        hipLaunchKernelGGL(k_snow_mean, grid, b256, 0, s, d_tiles, T, npix, snow);            // CR.py:372 (tiles mutate per date)
-        TTC_HIP(c, hipMemsetAsync(counters, 0, sizeof(int) * 4, s));
-        hipLaunchKernelGGL(k_date_counts, dim3(64), b256, 0, s, d_interp, npix, date, counters);
-        hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, counters, npix, T, date, plan, remove_flags);
-        // training rows of the 1 or 3 dates the plan names, in (t, pixel) order
-        hipLaunchKernelGGL(k_rows_count, dim3(nb3), b256, 0, s, d_interp, water2, npix, 0, 0, plan, blk);
-        hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(1024), 0, s, blk, nb3, &plan->nrows);
-        hipLaunchKernelGGL(k_rows_fill, dim3(nb3), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plan, blk, rows, evi);
+        DatePlan* plan = plans + date;
+        const int* rows = rows_all + (size_t)date * 3 * npix;
+        hipLaunchKernelGGL(k_snow_mean_cached, grid, b256, 0, s, snowp, T, npix, snow);       // CR.py:372 (tiles mutate per date)
+        hipLaunchKernelGGL(k_rows_evi, dim3(256), b256, 0, s, rows, plan, d_tiles, npix, evi);
         GramArgs ga{d_tiles, mosaic, snow, rows, nullptr, nullptr, 0, npix, 0, plan};
         if (sampler) {
             // reference replay: host round trip through the callback, which returns row indices
@@ -1235,7 +1285,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
         hipLaunchKernelGGL(k_gram, dim3(gram_blocks), b256, 0, s, ga, gpart);
         hipLaunchKernelGGL(k_gram_reduce, dim3(64), b256, 0, s, gpart, gram_blocks, Zdev);
         hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Zdev, plan, d_beta);               // 10 fits of 11 unknowns
-        hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, d_beta, npix, date);
+        hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, d_beta, npix, date, snowp);
         TTC_HIP(c, hipGetLastError());
     }
     // a9: clouds that survive in the mosaic (CR.py:964-968)
