@@ -477,15 +477,18 @@ struct GramArgs {
     const DatePlan* plan;     // device-controlled launch: nsample = plan->nrows, t0 = plan->t0
 };
 __global__ __launch_bounds__(256) void k_gram(GramArgs a, double* __restrict__ partial) {
-    __shared__ float zs[64][33];
-    __shared__ float ws[64];
+    // 256 rows per step: every thread gathers ONE row (the gather is a chain of dependent scattered loads -- with 64
+    // gathering threads per step it was the whole kernel), then owns Z'Z[r0][c0..c0+3] over the staged rows.
+    constexpr int R = 256;
+    __shared__ float zs[R][33];
+    __shared__ float ws[R];
     double acc[4] = {0, 0, 0, 0};
     if (a.plan) { a.nsample = a.plan->nrows; a.t0 = a.plan->t0; }
     const int tid = threadIdx.x;
-    const int r0 = tid >> 3, c0 = (tid & 7) * 4;          // thread owns Z'Z[r0][c0..c0+3]
-    for (long base = (long)blockIdx.x * 64; base < a.nsample; base += (long)gridDim.x * 64) {
+    const int r0 = tid >> 3, c0 = (tid & 7) * 4;
+    for (long base = (long)blockIdx.x * R; base < a.nsample; base += (long)gridDim.x * R) {
         __syncthreads();
-        if (tid < 64) {
+        {
             const long s = base + tid;
             float wgt = 0.f;
             if (s < a.nsample) {
@@ -495,16 +498,19 @@ __global__ __launch_bounds__(256) void k_gram(GramArgs a, double* __restrict__ p
                 const float* x = a.mosaic + (long)p * 10;
                 const float* y = a.tiles + ((long)t * a.npix + p) * 10;
                 const float sn = a.snow[p];
-                for (int c = 0; c < 10; ++c) { zs[tid][c] = fminf(fmaxf(x[c], 0.005f), 1.0f); zs[tid][11 + c] = x[c]; zs[tid][22 + c] = y[c]; }
+#pragma unroll
+                for (int c = 0; c < 10; ++c) { const float xv = x[c]; zs[tid][c] = fminf(fmaxf(xv, 0.005f), 1.0f); zs[tid][11 + c] = xv; zs[tid][22 + c] = y[c]; }
                 zs[tid][10] = sn; zs[tid][21] = sn;
                 wgt = a.weight ? a.weight[row] : 1.0f;
             } else {
+#pragma unroll
                 for (int c = 0; c < 32; ++c) zs[tid][c] = 0.f;
             }
             ws[tid] = wgt;
         }
         __syncthreads();
-        for (int s = 0; s < 64; ++s) {
+        const int n = (int)min((long)R, a.nsample - base);
+        for (int s = 0; s < n; ++s) {
             const double zr = (double)zs[s][r0] * (double)ws[s];
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] += zr * (double)zs[s][c0 + k];
@@ -1206,7 +1212,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     float* weight = static_cast<float*>(c->scratch_buf("gf_weight", sizeof(float) * 3 * (size_t)npix));
     const int nblk_rows = (3 * npix + 255) / 256;
     int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * ((size_t)nblk_rows * T + 16 + 4 * kMaxT)));
-    const int gram_blocks = 256;
+    const int gram_blocks = 1024;
     double* gpart = static_cast<double*>(c->scratch_buf("gf_gram", sizeof(double) * 1024 * (gram_blocks + 1)));
     if (!mosaic || !snow || !water2 || !bits || !rows_all || !snowp || !evi || !weight || !blk || !gpart)
         return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
