@@ -404,18 +404,23 @@ __global__ __launch_bounds__(1024) void k_bright_dist(const unsigned char* __res
 }
 
 // post-masks + rounding; one workgroup per window
+// number of kept dates whose interpolation weight is < 0.33 (job.py:1355-1362), once per tile pixel: every pixel is
+// visited by up to four windows and twice per window, and k_post runs on 36 workgroups only
+__global__ void k_clear_map(const float* __restrict__ interp, unsigned keep, int T, int npix, unsigned char* __restrict__ cc) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    int c = 0;
+    for (int t = 0; t < T; ++t)
+        if ((keep >> t) & 1u) c += interp[(long)t * npix + p] < 0.33f ? 1 : 0;
+    cc[p] = (unsigned char)c;
+}
 struct PostArgs {
-    const float* probs; const float* interp; const unsigned char* d2;
+    const float* probs; const unsigned char* cc; const unsigned char* d2;
     float* out; float* out_raw;
     WinTable wt; unsigned keep; int T, X, Y, size, n_dates_ok;
 };
 
-__device__ __forceinline__ int clear_count(const PostArgs& a, int tx, int ty) {
-    int c = 0;
-    for (int t = 0; t < a.T; ++t)
-        if ((a.keep >> t) & 1u) c += a.interp[((long)t * a.X + tx) * a.Y + ty] < 0.33f ? 1 : 0;
-    return c;
-}
+__device__ __forceinline__ int clear_count(const PostArgs& a, int tx, int ty) { return a.cc[(long)tx * a.Y + ty]; }
 
 __global__ __launch_bounds__(1024) void k_post(PostArgs a) {
     extern __shared__ unsigned char lds[];
@@ -655,7 +660,10 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
       TTC_HIP(c, hipGetLastError()); }
     TTC_CHECK(model_forward_frames(c, wt.n, probs, s));
     { KTimer kt(c, "post", s);
-      PostArgs pa{probs, d_interp, d2, d_windows, d_windows_raw, wt, wm.keep, T, X, Y, size, n_dates_ok};
+      unsigned char* cc = static_cast<unsigned char*>(c->scratch_buf("tile_clear", (size_t)npix));
+      if (!cc) return c->fail(TTC_ERR_NOMEM, "clear-count map");
+      hipLaunchKernelGGL(k_clear_map, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, d_interp, wm.keep, T, (int)npix, cc);
+      PostArgs pa{probs, cc, d2, d_windows, d_windows_raw, wt, wm.keep, T, X, Y, size, n_dates_ok};
       const size_t lds = 2 * (size_t)(size + 2) * (size + 2);
       hipLaunchKernelGGL(k_post, dim3(wt.n), dim3(1024), lds, s, pa);
       TTC_HIP(c, hipGetLastError()); }
