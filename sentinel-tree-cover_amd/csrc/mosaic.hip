@@ -38,8 +38,16 @@ __global__ void k_mos_ratio(const float* __restrict__ win, MWin mw, int size, co
                             float* __restrict__ ratios) {
     __shared__ double ps[16];
     __shared__ int pc[16];
+    __shared__ int nbr[kMaxWin], n_nbr;
     const int w = blockIdx.x;
     const double thr = (double)size * size * 255.0;
+    if (threadIdx.x == 0) {                                   // windows whose footprint intersects this one, in index order
+        int k = 0;
+        for (int j = 0; j < mw.n; ++j)
+            if (j != w && sums[j] < thr && abs(mw.fx[j] - mw.fx[w]) < size && abs(mw.fy[j] - mw.fy[w]) < size) nbr[k++] = j;
+        n_nbr = k;
+    }
+    __syncthreads();
     double acc = 0.0; int cnt = 0;
     if (sums[w] < thr) {
         for (int i = threadIdx.x; i < size * size; i += blockDim.x) {
@@ -47,8 +55,8 @@ __global__ void k_mos_ratio(const float* __restrict__ win, MWin mw, int size, co
             const float mine = pct(win[(long)w * size * size + (long)c * size + r]);
             const int R = mw.fy[w] + r, C = mw.fx[w] + c;
             float os = 0.f; int on = 0;
-            for (int j = 0; j < mw.n; ++j) {
-                if (j == w || !(sums[j] < thr)) continue;
+            for (int q = 0; q < n_nbr; ++q) {
+                const int j = nbr[q];
                 const int rr = R - mw.fy[j], cc = C - mw.fx[j];
                 if (rr >= 0 && rr < size && cc >= 0 && cc < size) { os += pct(win[(long)j * size * size + (long)cc * size + rr]); ++on; }
             }
