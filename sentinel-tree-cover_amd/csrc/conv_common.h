@@ -65,6 +65,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
             ratio = (ey && ex) ? 2.25f : ((ey || ex) ? 1.5f : 1.0f);
         }
         const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
+        // a.reflect_out: the output plane carries a 1-px REFLECT rim (MirrorPad before the next VALID conv); the pixels one
+        // step inside the edge also write their mirror images, which replaces a separate rim-fill pass over every plane
+        long dup_y = 0, dup_x = 0;
+        bool any_dup = false;
+        if (EPI >= EPI_BIAS && a.reflect_out) {
+            if (valid) {
+                dup_y = (y == 1) ? -2L * a.out_pitch : ((y == Hout - 2) ? 2L * a.out_pitch : 0L);
+                dup_x = (x == 1) ? -2L : ((x == Wout - 2) ? 2L : 0L);
+            }
+            any_dup = __any((dup_y != 0) || (dup_x != 0));
+        }
 #pragma unroll
         for (int g = 0; g < NCG; ++g) {
             float rv[16];
@@ -92,6 +103,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     if (EPI == EPI_BIAS_TANH_ADD) v = rv[r] + tanhf(v);
                 }
                 if (ok) outn[(long)co * a.out_plane + opix] = v;
+                if (EPI >= EPI_BIAS && any_dup && ok) {
+                    float* o = outn + (long)co * a.out_plane + opix;
+                    if (dup_y) o[dup_y] = v;
+                    if (dup_x) o[dup_x] = v;
+                    if (dup_y && dup_x) o[dup_y + dup_x] = v;
+                }
                 if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
             }
         }

@@ -198,10 +198,10 @@ static ttc_status dsen2_core(ttc_ctx* c, const float* xin, const float* bil, int
         a.Cin = Cin; a.Hp = Hp; a.Wp = Wp; a.Cout = kDsCout[l];
         a.w = c->w_ds[l].d_w; a.w_set_stride = 0; a.n_per_set = n;
         a.out = dst; a.res = res; a.aux = c->d_ds_bias + 32 * l;
-        if (padded_out) { a.out_stride_n = 32 * PP; a.out_plane = PP; a.out_pitch = Wp; a.oy = a.ox = 1; }
+        if (padded_out) { a.out_stride_n = 32 * PP; a.out_plane = PP; a.out_pitch = Wp; a.oy = a.ox = 1; a.reflect_out = (H >= 4 && W >= 4); }
         else { a.out_stride_n = 6 * P; a.out_plane = P; a.out_pitch = W; a.oy = a.ox = 0; }
         { KTimer kt(c, "dsen2_conv", s); TTC_HIP(c, conv_launch(a, c->w_ds[l], epi, n, s)); }
-        if (padded_out) {
+        if (padded_out && !a.reflect_out) {                  // degenerate sizes only: the epilogue writes the rim otherwise
             KTimer kt(c, "dsen2_border", s);
             hipLaunchKernelGGL(k_reflect_border, dim3((2 * Wp + 2 * Hp + 255) / 256, n * 32), dim3(256), 0, s, dst, Hp, Wp);
             TTC_HIP(c, hipGetLastError());

@@ -65,6 +65,7 @@ struct ConvArgs {
     long aux_set_stride; // floats between the aux vectors of weight sets
     const float* res;    // EPI_BIAS_RES / _TANH_ADD: residual, same indexing as out
     int same_pad;        // EPI_SWISH: 1 -> multiply by the partial-conv ratio (zero-padded SAME conv)
+    int reflect_out;     // EPI_BIAS*: 1 -> also write the 1-px reflect rim of the (padded) output plane
 };
 
 struct PackedConv {      // device copy of one layer's packed weights
