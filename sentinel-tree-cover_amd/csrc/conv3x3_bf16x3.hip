@@ -201,13 +201,8 @@ hipError_t launch_b3(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t
     const int TL4 = (TL + 3) >> 2;
     const int TLq = ((TL4 + 11) & ~15) + 4;
     const size_t lds = (size_t)(2 * 4 * TLq + 2 * kKB * 2 * 2 * BN) * 16;
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_b3<NCG, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsConfig lds_cfg;
+    if (hipError_t e = lds_cfg.ensure(&conv3x3_b3<NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
     dim3 grid(nblk_q * pw.ncb * n);
     hipLaunchKernelGGL((conv3x3_b3<NCG, EPI>), grid, dim3(kThreads), lds, s, a,

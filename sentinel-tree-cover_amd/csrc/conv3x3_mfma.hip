@@ -178,13 +178,8 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     const int TL = kBQ + 2 * a.Wp + 2;
     const int TLp = (TL + 3) & ~3;
     const size_t lds = (size_t)(CK * TLp + 9 * CK * BN) * sizeof(float);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f32<CK, NCG, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    static LdsConfig lds_cfg;
+    if (hipError_t e = lds_cfg.ensure(&conv3x3_f32<CK, NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
     dim3 grid(nblk_q * pw.ncb * n);
     hipLaunchKernelGGL((conv3x3_f32<CK, NCG, EPI>), grid, dim3(kThreads), lds, s, a, pw.nchunk, nblk_q, pw.ncb);

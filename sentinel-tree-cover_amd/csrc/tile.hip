@@ -632,9 +632,8 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     { KTimer kt(c, "tile_temporal", s);
       const int TM = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
       if (TM == 32) {
-          static bool big_lds = false;
-          if (!big_lds) { TTC_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_temporal<32>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 640 * 4)); big_lds = true; }
+          static LdsConfig cfg32;
+          TTC_HIP(c, cfg32.ensure(&k_tile_temporal<32>, (size_t)32 * 640 * 4));
       }
       LAUNCH_T(k_tile_temporal, T, dim3((unsigned)((npix + 63) / 64)), dim3(64), (size_t)TM * 640 * sizeof(float), s, d_s2, wm, (int)npix, L, sm, med);
       TTC_HIP(c, hipGetLastError()); }
@@ -650,12 +649,8 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
       hipLaunchKernelGGL(k_bright_flags, dim3((W * W + 255) / 256, wt.n), dim3(256), 0, s, sm, med, wt, X, Y, W, L, flags);
       TTC_HIP(c, hipGetLastError());
       const size_t lds = 3 * (size_t)W * W;
-      static size_t cfg_lds = 0;
-      if (lds > cfg_lds) {
-          TTC_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bright_dist),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          cfg_lds = lds;
-      }
+      static LdsConfig cfg_bright;
+      TTC_HIP(c, cfg_bright.ensure(&k_bright_dist, lds));
       hipLaunchKernelGGL(k_bright_dist, dim3(wt.n), dim3(1024), lds, s, flags, W, size, d2);
       TTC_HIP(c, hipGetLastError()); }
     TTC_CHECK(model_forward_frames(c, wt.n, probs, s));

@@ -80,6 +80,25 @@ struct PackedConv {      // device copy of one layer's packed weights
     long set_stride3 = 0;         // 16-byte units between weight sets
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the size configured on each device
+// (one process normally drives one GPU, but two contexts on different devices must both work)
+struct LdsConfig {
+    size_t per_dev[64] = {0};
+    template <class F>
+    hipError_t ensure(F* fn, size_t bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        size_t& cur = per_dev[dev & 63];
+        if (bytes > cur) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) return e;
+            cur = bytes;
+        }
+        return hipSuccess;
+    }
+};
+
 int conv_pick_ck(int Cin);
 int conv_pick_bn(int Cout);
 // packs HWIO host kernels (one per weight set) into the layout above; returns floats per set
