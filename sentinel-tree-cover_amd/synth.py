@@ -125,3 +125,38 @@ def synth_gapfill_scene(seed=31, T=6, H=224, W=224):
     tiles[big, : (6 * H) // 10, :, :] += 0.3
     tiles = np.clip(tiles, 0.001, 0.98).astype(np.float32)
     return tiles, dates, probs, np.zeros((H, W), dtype=bool)
+
+
+def synth_detection_scene(seed=77, T=7, H=120, W=112):
+    """Raw (not yet gap-filled) Sentinel-2 stack for the multi-temporal cloud / shadow detector
+    (cloud_removal.py:1215-1677): bright white cloud blobs with displaced dark shadows, a lake, a built-up patch
+    (high SWIR, low NIR), a sand patch (NIR/SWIR < 0.75), a hazy date when T > 5.
+    -> (img [T,H,W,10] f32, dem [H,W] f32 metres, forest [H,W] f32 in {0,1}, urban_core [H,W] u8, urban_near [H,W] u8)"""
+    s2, dates, _, _, dem = synth_tile(seed=seed, T=T, H=H, W=W)
+    rng = np.random.default_rng(seed + 7)
+    img = s2.copy()
+    yy, xx = np.mgrid[0:H, 0:W]
+    lake = ((yy - 0.75 * H) / (0.13 * H)) ** 2 + ((xx - 0.2 * W) / (0.15 * W)) ** 2 < 1.0
+    img[:, lake, 3] = 0.03; img[:, lake, 1] = 0.08; img[:, lake, 8] = 0.02; img[:, lake, 7] = 0.025
+    town = (np.abs(yy - 0.3 * H) < 0.12 * H) & (np.abs(xx - 0.7 * W) < 0.14 * W)
+    img[:, town, 8] = 0.32; img[:, town, 3] = 0.22; img[:, town, 2] = 0.2
+    sand = ((yy - 0.15 * H) / (0.08 * H)) ** 2 + ((xx - 0.2 * W) / (0.1 * W)) ** 2 < 1.0
+    img[:, sand, 3] = 0.25; img[:, sand, 8] = 0.42; img[:, sand, 0] = 0.2; img[:, sand, 1] = 0.24; img[:, sand, 2] = 0.3
+    for t in range(T):
+        for b in range([2, 0, 1, 3, 1, 2, 0][t % 7]):
+            cy, cx = rng.integers(0, H), rng.integers(0, W)
+            ry, rx = rng.integers(H // 14, H // 5), rng.integers(W // 14, W // 5)
+            cloud = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0
+            shadow = ((yy - cy - ry // 2 - 3) / ry) ** 2 + ((xx - cx - rx // 2 - 3) / rx) ** 2 < 1.0
+            shadow &= ~cloud
+            img[t][shadow] *= 0.35
+            img[t][cloud, :3] = 0.55 + 0.1 * rng.random(int(cloud.sum()))[:, None]
+            img[t][cloud, 3:] = 0.5 + 0.05 * rng.random((int(cloud.sum()), 7))
+    if T > 5:
+        img[5, ..., :3] = img[5, ..., :3] * 0.3 + 0.33          # haze: bright, flat, white
+    img = np.clip(img + rng.normal(0, 0.003, img.shape), 0.001, 0.98).astype(np.float32)
+    demm = (dem * 12.0).astype(np.float32)                        # 0 .. 36 m: both sides of the 9 / 25 / 30 m rules
+    forest = (_smooth_field(np.random.default_rng(seed + 9), H, W, 25) > 0.55).astype(np.float32)
+    core = town.astype(np.uint8)
+    near = (np.abs(yy - 0.3 * H) < 0.25 * H) & (np.abs(xx - 0.7 * W) < 0.3 * W)
+    return img, demm, forest, core, near.astype(np.uint8)

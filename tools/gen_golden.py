@@ -221,6 +221,33 @@ def main():
     np.savez_compressed(os.path.join(OUT, "mosaic_features.npz"), keys=np.array(fk), windows=np.stack(fw), mosaic=fm)
     print("feature mosaic", fm.shape, fm.dtype)
 
+    # ---- multi-temporal cloud / shadow detection (identify_clouds_shadows + detect_pfcp) -------------------------------
+    # the two WorldCover rasters are replaced by synthetic masks through the functions that would read them
+    det = {}
+    for tag, (seed, T_, H_, W_, with_masks) in {"a": (77, 7, 120, 112, True), "b": (78, 2, 64, 72, False), "c": (79, 4, 96, 96, True)}.items():
+        scene = synth.synth_detection_scene(seed, T_, H_, W_)
+        img, dem_d, forest_d, core_d, near_d = scene
+        if with_masks:
+            CR.adjust_cloudmask_in_forests = lambda f, b, d, _m=forest_d: _m.copy()
+
+            def _urban(f, b, pf, _c=core_d, _n=near_d):
+                pf[_c == 1] = 1.
+                pf[_n == 0] = 0.
+                return pf
+            CR.mask_nonurban_areas = _urban
+        else:
+            def _boom(*a, **k):
+                raise IOError("no raster")
+            CR.adjust_cloudmask_in_forests = _boom
+            CR.mask_nonurban_areas = _boom
+        cl, fc = CR.identify_clouds_shadows(img.copy(), dem_d.copy(), [0, 0, 1, 1])
+        det[f"{tag}_cfg"] = np.array([seed, T_, H_, W_, int(with_masks)])
+        det[f"{tag}_clouds"] = np.packbits(cl > 0)
+        det[f"{tag}_clouds_max"] = np.float32(cl.max())
+        det[f"{tag}_fcps"] = np.packbits(fc)
+        print("detection", tag, cl.mean(axis=(1, 2)).round(3), fc.mean().round(4))
+    np.savez_compressed(os.path.join(OUT, "cloud_detection.npz"), **det)
+
     # ---- cloud gap-fill (stdlib RNG pinned: the reference samples with random.shuffle) -----
     tiles, gdates, probs, pf = synth.synth_gapfill_scene(31, 6, 224, 224)
     ia = CR.id_areas_to_interp(tiles.copy(), probs.copy(), probs.copy(), gdates, pfcps=pf)
