@@ -164,6 +164,18 @@ ttc_status ttc_remove_cloud_and_shadows(ttc_ctx* ctx, float* d_tiles, const floa
                                         float* d_interp, float* d_mosaic, int32_t* h_to_remove,
                                         int32_t* n_to_remove, void* stream);
 
+/* ---- cloud / shadow DETECTION (the step before the gap-fill) -----------------------
+ * == identify_clouds_shadows(img, dem, bbx) incl. detect_pfcp (cloud_removal.py:1215-1677, :1109-1212).
+ * d_img [T, X, Y, 10] float32 (10 m stack after the bilinear upsample); d_dem [X, Y] metres.
+ * The two ESA-WorldCover rasters the reference opens with rasterio are passed as full-resolution masks:
+ *   d_forest [X, Y] uint8      == adjust_cloudmask_in_forests(...)             NULL = none (the reference's except branch)
+ *   d_urban_core / d_urban_near [X, Y] uint8 == the two resized masks of mask_nonurban_areas (:735-755); both NULL = none
+ * d_clouds [T, X, Y] float32 in {0, 1} (clouds + shadows), d_fcps [T, X, Y] uint8 (potential false-positive mask).
+ * X and Y must be even when the urban masks are given (2x2 parallax grid).  Waits for the stream once (tiny table upload). */
+ttc_status ttc_identify_clouds_shadows(ttc_ctx* ctx, const float* d_img, int32_t T, int32_t X, int32_t Y, const float* d_dem,
+                                       const uint8_t* d_forest, const uint8_t* d_urban_core, const uint8_t* d_urban_near,
+                                       float* d_clouds, uint8_t* d_fcps, void* stream);
+
 /* ---- Gaussian overlap mosaic --------------------------------------------------------
  * == load_mosaic_predictions(out_folder, depth=1), job.py:1515-1641, from the 36 window
  * arrays (not from .npy files).
@@ -211,6 +223,8 @@ ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t 
  * Returns TTC_ERR_ARG for unknown names; *n_floats is the element count.  Test aid only. */
 /* on != 0: subsequent forwards also write intermediates that the fused kernels otherwise keep in registers ("u"). */
 ttc_status ttc_debug_keep(ttc_ctx* ctx, int32_t on);
+/* stage != 0: ttc_identify_clouds_shadows returns the flag planes after that stage of the detector (bisecting aid). */
+ttc_status ttc_debug_clouds_stage(ttc_ctx* ctx, int32_t stage);
 ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t cap_floats,
                            size_t* n_floats);
 /* average device time (ms) of the named kernel family over the launches since the last

@@ -119,8 +119,12 @@ def detect_pfcp(img, dem, urban=None):
 
 
 # ----------------------------------------------------------------------------------------------- main
-def identify_clouds_shadows(img, dem, forest=None, urban=None):
-    """CR.py:1215-1677 -> (clouds [T,H,W] float32 in {0,1}, fcps [T,H,W] bool)"""
+def identify_clouds_shadows(img, dem, forest=None, urban=None, trace=None):
+    """CR.py:1215-1677 -> (clouds [T,H,W] float32 in {0,1}, fcps [T,H,W] bool).
+    trace: optional dict receiving the state after each stage (numbered like the stages of the HIP driver)."""
+    def keep(name, x):
+        if trace is not None:
+            trace[name] = np.array(x, dtype=np.float32, copy=True)
     T = img.shape[0]
     vis = img[..., :3]
     water = np.nanmedian(_ndwi(img), axis=0)
@@ -131,6 +135,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
         clm = (img[..., 7] > 0.166) * (img[..., 1] > 0.28) * (img[..., 5] / img[..., 8] < 4.292)
     for t in range(T):
         clm[t] = _ero_then_dil(clm[t], 2, 10)
+    keep("1_clm", clm)
 
     # ---- shadows: darker than the cloud-free temporal reference in B8A / B11 / blue ---------------------------------
     ref4 = img[..., [0, 1, 7, 8]]
@@ -166,10 +171,12 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
             wet = ((b - all_med[..., 0]) < -0.05) * ((g - all_med[..., 1]) < -0.05) * (a8 < 0.03) * \
                   ((all_med[..., 1] - g) > 0.02) * (water > 0)
         shadows[t] = s + wet
+    keep("2_shadow_candidates", shadows)
     for t in range(T):
         s = _ero_then_dil(shadows[t], 2, 3)
         d = ndi.distance_transform_edt(1 - s)
         shadows[t] = 1 - (d > 5)
+    keep("3_shadows", shadows)
 
     # ---- clouds: brighter than the darkest shadow-free neighbours ---------------------------------------------------
     clouds = np.zeros_like(shadows)
@@ -215,6 +222,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
         eroded = 1 - _dil(nearc == 0, 2)
         nearc[forest == 0] = eroded[forest == 0]
         clouds[t] = np.maximum(far, nearc)
+    keep("4_cloud_candidates", clouds)
 
     # ---- per-image brightness outliers (z-score of brightness / median brightness) ----------------------------------
     bsum = np.sum(vis, axis=-1)
@@ -239,6 +247,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
     for t in range(T):
         bright[t][repeats > 1] = 0.
     clouds = np.maximum(clouds, bright)
+    keep("5_brightness", clouds)
 
     # clouds are white: drop coloured bright surfaces
     for t in range(T):
@@ -247,9 +256,11 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
         with np.errstate(all='ignore'):
             coloured = (mean_b < 0.4) * ((rng / mean_b) > 0.5)
         clouds[t] = clouds[t] * (1 - coloured)
+    keep("6_white", clouds)
 
     # urban false positives (Fmask 4.0 parallax + built-up index)
     fcps, pfcps = detect_pfcp(img, dem, urban)
+    keep("7_fcps", fcps); keep("7_pfps", pfcps)
 
     def not_much_brighter(t):
         lo, hi = max(t - 1, 0), min(t + 2, T)
@@ -275,6 +286,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
     for t in range(T):
         dark = _dil(np.sum(img[t, ..., :3], axis=-1) < 0.21, 3) * (1 - forest)
         clouds[t][dark.astype(np.uint8)] = 0.
+    keep("8_false_positives", clouds); keep("8_shadows", shadows); keep("8_nsr", nsr)
 
     # ---- shape clean-up: erode / dilate urban and non-urban clouds differently --------------------------------------
     for t in range(T):
@@ -289,6 +301,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
         rest = np.maximum(_dil(big, 5), _dil(small, 1))
         rest = 1 - (ndi.distance_transform_edt(1 - rest) > 3)
         clouds[t] = rest + urban_c
+    keep("9_shape", clouds)
     # implausible shadow amounts: keep only shadows near clouds (or on high ground)
     for t in range(T):
         with np.errstate(all='ignore'):
@@ -297,6 +310,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
                 shadows[t] = shadows[t] * np.logical_or(_dil(np.copy(clouds[t]), 50), dem >= 30)
             if np.mean(clouds[t]) < 0.05 and (np.mean(shadows[t]) / np.mean(clouds[t])) > 3:
                 shadows[t] = shadows[t] * np.logical_or(_dil(np.copy(clouds[t]), 50), dem >= 30)
+    keep("10_shadows", shadows)
     clouds = np.maximum(clouds, shadows)
     fcps = ndi.binary_dilation(np.maximum(fcps, nsr), iterations=2)
 
@@ -311,6 +325,7 @@ def identify_clouds_shadows(img, dem, forest=None, urban=None):
             extra_s[water > 0] = 0.
             clouds[t] = np.maximum(clouds[t], extra_s)
     clouds[clouds > 1] = 1.
+    keep("11_extra_shadows", clouds)
 
     # haze: whole images that are bright, flat and white
     mean_b = np.mean(vis, axis=-1)

@@ -21,7 +21,7 @@ EXPORTS = [
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
-    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep",
+    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -76,6 +76,8 @@ def load():
     lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
     lib.ttc_debug_keep.argtypes = [P, I32]
+    lib.ttc_debug_clouds_stage.argtypes = [P, I32]
+    lib.ttc_identify_clouds_shadows.argtypes = [P, VP, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP]
     lib.ttc_mosaic_features.argtypes = [P, VP, I32, VP, I32, I32, I32, I32, VP, VP]
     lib.ttc_forward_taps.argtypes = [P, VP, I32, VP, VP, VP, VP]
     lib.ttc_float_to_int16.argtypes = [P, VP, C.c_int64, C.c_float, VP, VP]
@@ -308,6 +310,28 @@ class Context:
         self._check(self.lib.ttc_s1_to_db(self._h, C.c_void_p(a.data_ptr()), T, X, Y, C.c_void_p(out.data_ptr()),
                                           self._stream()), "ttc_s1_to_db")
         return out
+
+    # -- cloud / shadow detection --------------------------------------------------------
+    def identify_clouds_shadows(self, img, dem, forest=None, urban=None, debug_stage=0):
+        """img [T,X,Y,10] float32, dem [X,Y]; forest [X,Y] (0/1) or None; urban = (core, near) masks or None
+        -> (clouds cuda float32 [T,X,Y], fcps cuda uint8 [T,X,Y])"""
+        t = self.torch
+        a = self._dev(img, t.float32)
+        T, X, Y = (int(v) for v in a.shape[:3])
+        d = self._dev(dem, t.float32)
+        u8 = lambda m: None if m is None else self._dev(np.ascontiguousarray(np.asarray(m) != 0).astype(np.uint8), t.uint8)
+        f = u8(forest)
+        core, near = (u8(urban[0]), u8(urban[1])) if urban is not None else (None, None)
+        clouds = t.empty((T, X, Y), dtype=t.float32, device=a.device)
+        fcps = t.empty((T, X, Y), dtype=t.uint8, device=a.device)
+        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        self._check(self.lib.ttc_debug_clouds_stage(self._h, int(debug_stage)), "ttc_debug_clouds_stage")
+        try:
+            self._check(self.lib.ttc_identify_clouds_shadows(self._h, ptr(a), T, X, Y, ptr(d), ptr(f), ptr(core), ptr(near), ptr(clouds),
+                                                             ptr(fcps), self._stream()), "ttc_identify_clouds_shadows")
+        finally:
+            self.lib.ttc_debug_clouds_stage(self._h, 0)
+        return clouds, fcps
 
     # -- cloud gap-fill ------------------------------------------------------------------
     def feather(self, mask, closing=20, clip=False):

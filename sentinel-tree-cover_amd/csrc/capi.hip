@@ -29,6 +29,10 @@ ttc_status codec_f32_to_i16(ttc_ctx* c, const float* d_in, int64_t n, float prec
 ttc_status mosaic_features(ttc_ctx* c, const int16_t* d_feats, int n, const int32_t* h_xy, int size, int depth, int rows, int cols,
                            int16_t* d_out, hipStream_t s);
 
+ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, const float* dem, const uint8_t* forest,
+                           const uint8_t* urban_core, const uint8_t* urban_near, float* d_clouds, uint8_t* d_fcps, int debug_stage,
+                           hipStream_t s);
+
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
         float ms = 0.f;
@@ -192,6 +196,20 @@ ttc_status ttc_float_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* 
 ttc_status ttc_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int32_t T, int32_t X, int32_t Y, float* d_out, void* stream) {
     if (!c) return TTC_ERR_ARG;
     return codec_s1_to_db(c, d_u16, T, X, Y, d_out, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_identify_clouds_shadows(ttc_ctx* c, const float* d_img, int32_t T, int32_t X, int32_t Y, const float* d_dem,
+                                       const uint8_t* d_forest, const uint8_t* d_urban_core, const uint8_t* d_urban_near,
+                                       float* d_clouds, uint8_t* d_fcps, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return clouds_identify(c, d_img, T, X, Y, d_dem, d_forest, d_urban_core, d_urban_near, d_clouds, d_fcps, c->clouds_debug_stage,
+                           static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_debug_clouds_stage(ttc_ctx* c, int32_t stage) {
+    if (!c) return TTC_ERR_ARG;
+    c->clouds_debug_stage = stage;
+    return TTC_OK;
 }
 
 ttc_status ttc_debug_keep(ttc_ctx* c, int32_t on) {

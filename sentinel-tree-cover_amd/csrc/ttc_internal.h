@@ -145,6 +145,7 @@ struct ttc_ctx {
           *u3in = nullptr, *y_u3 = nullptr, *oa = nullptr, *y_out = nullptr;
     float *stats = nullptr, *gn = nullptr;      // GN partial sums / (mean, rstd)
     size_t stats_floats = 0;
+    int clouds_debug_stage = 0;   // ttc_debug_clouds_stage: return the flags after that stage of the cloud detector (test aid)
     bool keep_debug = false;      // ttc_debug_keep: also materialise intermediates that the fused kernels never write (test aid)
     // workspace (tile-level), grown on demand
     std::map<std::string, std::pair<void*, size_t>> scratch;
