@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="tiles in flight per GPU per step, each on its own HIP stream + context: one tile's latency-bound "
                          "gap-fill / tile kernels run under another tile's convolutions")
+    ap.add_argument("--detect", action="store_true",
+                    help="also run the multi-temporal cloud/shadow DETECTION (cloud_removal.py:1215-1677, the row after SURVEY 8's "
+                         "a1-a20) inside the step and gap-fill with ITS mask instead of the given one")
     ap.add_argument("--from-host", action="store_true",
                     help="informational: every step uploads the raw tile from pinned host memory first (PCIe-inclusive rate, "
                          "reported in DESIGN.md, never the headline value)")
@@ -181,6 +184,7 @@ def main():
     dev = f"cuda:{local}"
     d10, d20 = torch.from_numpy(s2_10.view(np.int16)).to(dev), torch.from_numpy(s2_20.view(np.int16)).to(dev)
     dprobs, ds1, ddem = torch.from_numpy(probs).to(dev), torch.from_numpy(s1.view(np.int16)).to(dev), torch.from_numpy(dem).to(dev)
+    ddem_m = ddem * 12.0                    # metres for the detector's elevation rules (synthetic DEM is in units of 90 m)
     gather_bufs = [[torch.empty((TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
                    for _ in range(args.inflight)]
 
@@ -207,7 +211,10 @@ def main():
         ctx = sess.ctx
         f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(ds1)   # tof_downloading.py:64-72, job.py:699-708
         s2d = ctx.upsample_20m(f10, f20)                              # job.py:734-782
-        dint, _, _ = ctx.remove_cloud_and_shadows(s2d, dprobs, None, None)   # cloud_removal.py:888-973 (deterministic sampler)
+        mask, pf = dprobs, None
+        if args.detect:                                               # cloud_removal.py:1215-1677 (process_tile: job.py:837)
+            mask, pf = ctx.identify_clouds_shadows(s2d, ddem_m, None, None)
+        dint, _, _ = ctx.remove_cloud_and_shadows(s2d, mask, pf, None)   # cloud_removal.py:888-973 (deterministic sampler)
         ctx.superresolve_tile(s2d, quirks=True)                       # job.py:95-147
         f32, u8 = job.predict_tile(s2d, dates, dint, s1db, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
         if world > 1 and gather:
@@ -271,13 +278,13 @@ def main():
             "config": {
                 "workload": f"{args.inflight} x 618x618 tile per GPU per step, T={args.dates} dates, 36 overlapping {args.win}x{args.win} "
                             f"windows (out {size}), L={args.length}, {args.precision} (BASELINE.json configs[1])",
-                "stages": ["u16_decode+s1_db", "bilinear_20m", "cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
+                "stages": ["u16_decode+s1_db", "bilinear_20m"] + (["cloud_shadow_detection"] if args.detect else []) + [ "cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
                            "dsen2_superresolve(31 windows x T)", "temporal_operator+indices+medians",
                            "window_assembly+normalise", "biConvGRU+UNet forward", "post_masks", "gaussian_mosaic"]
                           + (["rccl_gather_u8"] if world > 1 else []),
                 "not_in_timed_region": [("nothing: the raw tile is uploaded from pinned host memory every step" if args.from_host
                                          else "H2D of the raw tile (inputs resident in HBM)"),
-                                        "cloud/shadow DETECTION (out of scope, SURVEY 8f-1): the mask is an input"],
+                                        ("-" if args.detect else "cloud/shadow DETECTION (SURVEY 8f-1, built: --detect): the mask is an input")],
                 "weights": "synthetic seed 0 (ConvGRU/U-Net weights absent from the reference checkout); DSen2 real",
                 "tiles_per_step_per_gpu": args.inflight, "streams_per_gpu": args.inflight, "win_in": args.win, "length": args.length, "dates": args.dates,
             },

@@ -358,7 +358,14 @@ class Context:
         t = self.torch
         T, X, Y = (int(v) for v in tiles.shape[:3])
         pr = self._dev(probs, t.float32)
-        pf = self._dev(np.ascontiguousarray(pfcps).astype(np.uint8), t.uint8) if pfcps is not None else None
+        pf = None
+        if pfcps is not None:                       # [X, Y] or, like the reference (cloud_removal.py:709-711), [T, X, Y] -> date 0
+            if isinstance(pfcps, t.Tensor):
+                pf = pfcps[0] if pfcps.dim() == 3 else pfcps
+                pf = (pf != 0).to(t.uint8).contiguous()
+            else:
+                a = np.asarray(pfcps)
+                pf = self._dev(np.ascontiguousarray(a[0] if a.ndim == 3 else a).astype(np.uint8), t.uint8)
         interp = t.empty((T, X, Y), dtype=t.float32, device=tiles.device)
         mosaic = t.empty((X, Y, 10), dtype=t.float32, device=tiles.device) if want_mosaic else None
         rem = (C.c_int32 * T)()

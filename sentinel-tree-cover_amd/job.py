@@ -235,6 +235,19 @@ def load_mosaic_predictions(windows, depth=1, sess=None, size=SIZE, return_float
 
 # ------------------------------------------------------------------------------------------
 # cloud / shadow gap-fill (src/preprocessing/cloud_removal.py)
+def identify_clouds_shadows(img, dem, bbx=None, sess=None, forest_mask=None, urban_masks=None):
+    """cloud_removal.py:1215-1677 (+ detect_pfcp, :1109-1212) on the device.  Same positional arguments as the reference;
+    `bbx` is only used there to window the two ESA-WorldCover rasters (forestmask.tif / urbanmask.tif), which the caller
+    passes here already cut and resized: forest_mask [X, Y] == adjust_cloudmask_in_forests(...), urban_masks = (core, near)
+    == the two masks mask_nonurban_areas builds.  None reproduces the reference's behaviour without the rasters.
+    -> (clouds float32 [T, X, Y], fcps bool [T, X, Y])"""
+    if sess is None:
+        raise ValueError("identify_clouds_shadows needs a TTCSession")
+    clouds, fcps = sess.ctx.identify_clouds_shadows(np.asarray(img, dtype=np.float32), np.asarray(dem, dtype=np.float32),
+                                                    forest_mask, urban_masks)
+    return clouds.cpu().numpy(), fcps.cpu().numpy().astype(bool)
+
+
 def reference_sampler(evi, rng=None):
     """The reference's EVI-stratified row sample (cloud_removal.py:453-500), replayed with the stdlib global RNG:
     2 % tails repeated x10, five quintile strata truncated to n//5 after random.shuffle, shuffled again.

@@ -54,3 +54,29 @@ def test_detection_stages_vs_oracle(sess, tag):
         if d > 1e-3:
             bad.append((stage, name, d))
     assert not bad, bad
+
+
+def test_detection_full_tile_and_edge_cases(sess):
+    """BASELINE-size tile (618 x 618, T = 12) and the degenerate inputs: a single date, two dates (the T <= 2 branch),
+    an all-cloud stack, a cloud-free stack (scipy's empty-background distance transform), no masks."""
+    from oracle import restate_clouds as C
+    from ttc import job
+    img, dem, forest, core, near = synth.synth_detection_scene(5, 12, 618, 618)
+    got_c, got_f = job.identify_clouds_shadows(img, dem, None, sess, forest, (core, near))
+    want_c, want_f = C.identify_clouds_shadows(img.copy(), dem.copy(), forest, (core, near))
+    dc, df = ((got_c > 0) != (want_c > 0)).mean(), (got_f != np.asarray(want_f, dtype=bool)).mean()
+    print(f"[parity] detection 618^2 T=12: differing cloud flags {dc:.2e}, fcps {df:.2e}")
+    assert dc < 1e-3 and df < 1e-3
+    small = synth.synth_detection_scene(9, 5, 64, 60)
+    cases = {"T=1": small[0][:1], "T=2": small[0][:2], "T=3": small[0][:3],
+             "all cloud": np.full((4, 64, 60, 10), 0.6, np.float32), "clear": np.full((4, 64, 60, 10), 0.05, np.float32) +
+             np.linspace(0, 0.02, 10, dtype=np.float32)}
+    for name, x in cases.items():
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        gc, gf = job.identify_clouds_shadows(x, small[1], None, sess)
+        wc, wf = C.identify_clouds_shadows(x.copy(), small[1].copy())
+        d1, d2 = ((gc > 0) != (wc > 0)).mean(), (gf != np.asarray(wf, dtype=bool)).mean()
+        print(f"[parity] detection {name}: differing {d1:.2e} / {d2:.2e}")
+        assert d1 < 1e-3 and d2 < 1e-3, name
+    with pytest.raises(RuntimeError, match="even"):
+        sess.ctx.identify_clouds_shadows(small[0][:, :63], small[1][:63], None, (small[3][:63], small[4][:63]))
