@@ -160,3 +160,29 @@ def synth_detection_scene(seed=77, T=7, H=120, W=112):
     core = town.astype(np.uint8)
     near = (np.abs(yy - 0.3 * H) < 0.25 * H) & (np.abs(xx - 0.7 * W) < 0.3 * W)
     return img, demm, forest, core, near.astype(np.uint8)
+
+
+def synth_raw_files(seed=91, T=6, w20=40, h20=44, with_clm=True):
+    """The arrays process_tile (job.py:641-995) loads from temp/raw/*: uint16 Sentinel-2 at 10 m [T, 2*w20, 2*h20, 4] and
+    20 m [T, w20, h20, 6], uint16 Sentinel-1 [12, X, Y, 2], DEM in metres [X, Y], day-of-year dates, the s2cloudless
+    probabilities [T, X, Y] (only sliced / deleted there) and, optionally, the 20 m Sen2Cor cloud mask [T, w20, h20]."""
+    X, Y = 2 * w20, 2 * h20
+    img, dem, _, _, _ = synth_detection_scene(seed, T, X, Y)
+    rng = np.random.default_rng(seed + 3)
+    if T > 3:
+        img[2, : (19 * X) // 20] = np.clip(img[2, : (19 * X) // 20] * 0.2 + 0.55, 0, 0.98)      # one date almost fully clouded
+    q = lambda a: np.trunc(np.clip(a, 0, 1) * 65535).astype(np.uint16)
+    s2_10 = q(img[..., :4])
+    lo = img[..., 4:].reshape(T, w20, 2, h20, 2, 6).mean(axis=(2, 4))
+    s2_20 = q(lo)
+    s2_10[0, 3:5, 4:9, :] = 0                                            # a few missing samples
+    _, dates, _, s1, _ = synth_tile(seed=seed, T=T, H=X, W=Y)
+    s1u = q(s1)
+    s1u[1, :4, :5] = 65535
+    clouds = rng.random((T, X, Y)).astype(np.float32)
+    clm = None
+    if with_clm:
+        clm = np.zeros((T, w20, h20), dtype=np.float32)
+        clm[1, 5:12, 6:15] = 1.0; clm[2, 5:12, 6:15] = 1.0                # "two in a row" -> dropped (job.py:691-697)
+        clm[4, 20:30, 10:22] = 1.0
+    return {"s2_10": s2_10, "s2_20": s2_20, "s1": s1u, "dem": dem.astype(np.float32), "dates": np.asarray(dates), "clouds": clouds, "clm": clm}

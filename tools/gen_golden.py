@@ -248,6 +248,40 @@ def main():
         print("detection", tag, cl.mean(axis=(1, 2)).round(3), fc.mean().round(4))
     np.savez_compressed(os.path.join(OUT, "cloud_detection.npz"), **det)
 
+    # ---- process_tile as a whole (job.py:641-995): the file loader is replaced by a dict of synthetic raw arrays ---------
+    def _boom(*a, **k):
+        raise IOError("no raster")
+    CR.adjust_cloudmask_in_forests = _boom
+    CR.mask_nonurban_areas = _boom
+    pt = {}
+    for tag, (seed, T_, w20, h20, with_clm) in {"a": (91, 6, 80, 88, True), "b": (92, 7, 100, 96, False)}.items():
+        raw = synth.synth_raw_files(seed, T_, w20, h20, with_clm)
+
+        def _key(path):
+            for k, v in {"clouds/clouds_": "clouds", "clouds/cloudmask_": "clm", "raw/s1/": "s1", "raw/s2_10/": "s2_10",
+                         "raw/s2_20/": "s2_20", "misc/dem_": "dem", "misc/s2_dates_": "dates"}.items():
+                if k in path:
+                    return v
+            raise KeyError(path)
+        J.hkl.load = lambda path, _r=raw: np.array(_r[_key(path)], copy=True)
+        folder = os.path.join(scratch, f"pt_{tag}") + "/"
+        os.makedirs(folder + "10/20/raw/clouds/", exist_ok=True)
+        if with_clm:
+            open(folder + "10/20/raw/clouds/cloudmask_10X20Y.hkl", "w").close()
+        random.seed(4)
+        s2o, do, io, s1o, demo, cso, snowo = J.process_tile(10, 20, None, folder, [0, 0, 1, 1], make_shadow=True)
+        pt[f"{tag}_cfg"] = np.array([seed, T_, w20, h20, int(with_clm)])
+        pt[f"{tag}_dates"] = np.asarray(do)
+        pt[f"{tag}_s2_sub"] = s2o[:, ::3, ::3, :].astype(np.float32)
+        pt[f"{tag}_interp_sub"] = io[:, ::2, ::2].astype(np.float32)
+        pt[f"{tag}_s1_sub"] = s1o[:, ::4, ::4, :].astype(np.float32)
+        pt[f"{tag}_dem"] = demo.astype(np.float32)
+        pt[f"{tag}_cloudshad"] = np.packbits(cso > 0)
+        pt[f"{tag}_cloudshad_shape"] = np.array(cso.shape)
+        pt[f"{tag}_snow"] = np.packbits(np.asarray(snowo) > 0)
+        print("process_tile", tag, s2o.shape, do, (cso > 0).mean(axis=(1, 2)).round(3))
+    np.savez_compressed(os.path.join(OUT, "process_tile.npz"), **pt)
+
     # ---- cloud gap-fill (stdlib RNG pinned: the reference samples with random.shuffle) -----
     tiles, gdates, probs, pf = synth.synth_gapfill_scene(31, 6, 224, 224)
     ia = CR.id_areas_to_interp(tiles.copy(), probs.copy(), probs.copy(), gdates, pfcps=pf)
