@@ -176,6 +176,24 @@ ttc_status ttc_identify_clouds_shadows(ttc_ctx* ctx, const float* d_img, int32_t
                                        const uint8_t* d_forest, const uint8_t* d_urban_core, const uint8_t* d_urban_near,
                                        float* d_clouds, uint8_t* d_fcps, void* stream);
 
+/* ---- small raster steps of process_tile between the stages above (job.py:641-995) ------------------
+ * Sen2Cor mask clean-up (:688-697): d_clm20 [T, w20, h20] float32 0/1 -> d_out [T, 2*w20, 2*h20]; walking the dates in order,
+ * two consecutive flagged dates at a pixel are both cleared. */
+ttc_status ttc_sen2cor_clean(ttc_ctx* ctx, const float* d_clm20, int32_t T, int32_t w20, int32_t h20, float* d_out, void* stream);
+/* dem = median_filter(dem, size = 5) (:713; scipy 'reflect' border); not in place. */
+ttc_status ttc_median5(ttc_ctx* ctx, const float* d_in, int32_t X, int32_t Y, float* d_out, void* stream);
+/* snow map (:799-821): d_snow [X, Y] uint8 = 1 - dilate(mean_t(snow_filter) < 0.7, 2); h_per_image [T] (may be NULL) receives
+ * the number of snow pixels per date (the > 25 % rule of :822 is a host decision) -- filling it waits for the stream. */
+ttc_status ttc_snow_map(ttc_ctx* ctx, const float* d_s2, int32_t T, int32_t X, int32_t Y, uint8_t* d_snow, int32_t* h_per_image, void* stream);
+/* cloudshad = max(cloudshad, clm) after clm[fcps] = 0 when d_fcps is given (:843-848 / :880-884); n elements, in place. */
+ttc_status ttc_merge_cloud_masks(ttc_ctx* ctx, float* d_cloudshad, float* d_clm, const uint8_t* d_fcps, int64_t n, void* stream);
+/* h_counts[t] = #(d_a[t] > 0) (np.mean(interp > 0, axis = (1, 2)) of :868 is count / npix); waits for the stream. */
+ttc_status ttc_count_positive(ttc_ctx* ctx, const float* d_a, int32_t T, int32_t npix, int32_t* h_counts, void* stream);
+/* np.clip(x, 0, 1) in place (:994). */
+ttc_status ttc_clip01(ttc_ctx* ctx, float* d_a, int64_t n, void* stream);
+/* x / divisor in place with an IEEE division (dem / 90, :993). */
+ttc_status ttc_divide(ttc_ctx* ctx, float* d_a, int64_t n, float divisor, void* stream);
+
 /* ---- Gaussian overlap mosaic --------------------------------------------------------
  * == load_mosaic_predictions(out_folder, depth=1), job.py:1515-1641, from the 36 window
  * arrays (not from .npy files).

@@ -22,6 +22,7 @@ EXPORTS = [
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
+    "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -75,6 +76,13 @@ def load():
     lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
     lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
                                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
+    lib.ttc_sen2cor_clean.argtypes = [P, VP, I32, I32, I32, VP, VP]
+    lib.ttc_median5.argtypes = [P, VP, I32, I32, VP, VP]
+    lib.ttc_snow_map.argtypes = [P, VP, I32, I32, I32, VP, VP, VP]
+    lib.ttc_merge_cloud_masks.argtypes = [P, VP, VP, VP, C.c_int64, VP]
+    lib.ttc_count_positive.argtypes = [P, VP, I32, I32, VP, VP]
+    lib.ttc_clip01.argtypes = [P, VP, C.c_int64, VP]
+    lib.ttc_divide.argtypes = [P, VP, C.c_int64, C.c_float, VP]
     lib.ttc_debug_keep.argtypes = [P, I32]
     lib.ttc_debug_clouds_stage.argtypes = [P, I32]
     lib.ttc_identify_clouds_shadows.argtypes = [P, VP, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP]
@@ -310,6 +318,54 @@ class Context:
         self._check(self.lib.ttc_s1_to_db(self._h, C.c_void_p(a.data_ptr()), T, X, Y, C.c_void_p(out.data_ptr()),
                                           self._stream()), "ttc_s1_to_db")
         return out
+
+    # -- small raster steps of process_tile ----------------------------------------------
+    def sen2cor_clean(self, clm20):
+        t = self.torch
+        a = self._dev(clm20, t.float32)
+        T, w, h = (int(v) for v in a.shape)
+        out = t.empty((T, 2 * w, 2 * h), dtype=t.float32, device=a.device)
+        self._check(self.lib.ttc_sen2cor_clean(self._h, C.c_void_p(a.data_ptr()), T, w, h, C.c_void_p(out.data_ptr()), self._stream()),
+                    "ttc_sen2cor_clean")
+        return out
+
+    def median5(self, dem):
+        t = self.torch
+        a = self._dev(dem, t.float32)
+        out = t.empty_like(a)
+        self._check(self.lib.ttc_median5(self._h, C.c_void_p(a.data_ptr()), int(a.shape[0]), int(a.shape[1]), C.c_void_p(out.data_ptr()),
+                                         self._stream()), "ttc_median5")
+        return out
+
+    def snow_map(self, s2):
+        """-> (snow cuda uint8 [X, Y], per-image snow fraction numpy float64 [T])"""
+        t = self.torch
+        T, X, Y = (int(v) for v in s2.shape[:3])
+        snow = t.empty((X, Y), dtype=t.uint8, device=s2.device)
+        cnt = (C.c_int32 * T)()
+        self._check(self.lib.ttc_snow_map(self._h, C.c_void_p(s2.data_ptr()), T, X, Y, C.c_void_p(snow.data_ptr()), cnt, self._stream()),
+                    "ttc_snow_map")
+        return snow, np.array([cnt[i] for i in range(T)], dtype=np.float64) / (X * Y)
+
+    def merge_cloud_masks(self, cloudshad, clm, fcps=None):
+        self._check(self.lib.ttc_merge_cloud_masks(self._h, C.c_void_p(cloudshad.data_ptr()), C.c_void_p(clm.data_ptr()),
+                                                   C.c_void_p(fcps.data_ptr()) if fcps is not None else None, cloudshad.numel(),
+                                                   self._stream()), "ttc_merge_cloud_masks")
+
+    def fraction_positive(self, a):
+        """a cuda float32 [T, X, Y] -> numpy float64 [T]: np.mean(a > 0, axis=(1, 2))"""
+        T, npix = int(a.shape[0]), int(a.shape[1] * a.shape[2])
+        cnt = (C.c_int32 * T)()
+        self._check(self.lib.ttc_count_positive(self._h, C.c_void_p(a.data_ptr()), T, npix, cnt, self._stream()), "ttc_count_positive")
+        return np.array([cnt[i] for i in range(T)], dtype=np.float64) / npix
+
+    def divide(self, a, divisor):
+        self._check(self.lib.ttc_divide(self._h, C.c_void_p(a.data_ptr()), a.numel(), float(divisor), self._stream()), "ttc_divide")
+        return a
+
+    def clip01(self, a):
+        self._check(self.lib.ttc_clip01(self._h, C.c_void_p(a.data_ptr()), a.numel(), self._stream()), "ttc_clip01")
+        return a
 
     # -- cloud / shadow detection --------------------------------------------------------
     def identify_clouds_shadows(self, img, dem, forest=None, urban=None, debug_stage=0):

@@ -33,6 +33,14 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
                            const uint8_t* urban_core, const uint8_t* urban_near, float* d_clouds, uint8_t* d_fcps, int debug_stage,
                            hipStream_t s);
 
+ttc_status prep_sen2cor_clean(ttc_ctx* c, const float* d_clm20, int T, int w20, int h20, float* d_out, hipStream_t s);
+ttc_status prep_median5(ttc_ctx* c, const float* d_in, int X, int Y, float* d_out, hipStream_t s);
+ttc_status prep_snow(ttc_ctx* c, const float* d_s2, int T, int X, int Y, uint8_t* d_snow, int32_t* h_per_image, hipStream_t s);
+ttc_status prep_merge_clm(ttc_ctx* c, float* d_cloudshad, float* d_clm, const uint8_t* d_fcps, int64_t n, hipStream_t s);
+ttc_status prep_count_positive(ttc_ctx* c, const float* d_a, int T, int npix, int32_t* h_counts, hipStream_t s);
+ttc_status prep_clip01(ttc_ctx* c, float* d_a, int64_t n, hipStream_t s);
+ttc_status prep_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, hipStream_t s);
+
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
         float ms = 0.f;
@@ -205,6 +213,30 @@ ttc_status ttc_identify_clouds_shadows(ttc_ctx* c, const float* d_img, int32_t T
     return clouds_identify(c, d_img, T, X, Y, d_dem, d_forest, d_urban_core, d_urban_near, d_clouds, d_fcps, c->clouds_debug_stage,
                            static_cast<hipStream_t>(stream));
 }
+
+#define TTC_S(x) static_cast<hipStream_t>(x)
+ttc_status ttc_sen2cor_clean(ttc_ctx* c, const float* d_clm20, int32_t T, int32_t w20, int32_t h20, float* d_out, void* stream) {
+    return c ? prep_sen2cor_clean(c, d_clm20, T, w20, h20, d_out, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_median5(ttc_ctx* c, const float* d_in, int32_t X, int32_t Y, float* d_out, void* stream) {
+    return c ? prep_median5(c, d_in, X, Y, d_out, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_snow_map(ttc_ctx* c, const float* d_s2, int32_t T, int32_t X, int32_t Y, uint8_t* d_snow, int32_t* h_per_image, void* stream) {
+    return c ? prep_snow(c, d_s2, T, X, Y, d_snow, h_per_image, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_merge_cloud_masks(ttc_ctx* c, float* d_cloudshad, float* d_clm, const uint8_t* d_fcps, int64_t n, void* stream) {
+    return c ? prep_merge_clm(c, d_cloudshad, d_clm, d_fcps, n, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_count_positive(ttc_ctx* c, const float* d_a, int32_t T, int32_t npix, int32_t* h_counts, void* stream) {
+    return c ? prep_count_positive(c, d_a, T, npix, h_counts, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_clip01(ttc_ctx* c, float* d_a, int64_t n, void* stream) {
+    return c ? prep_clip01(c, d_a, n, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, void* stream) {
+    return c ? prep_divide(c, d_a, n, divisor, TTC_S(stream)) : TTC_ERR_ARG;
+}
+#undef TTC_S
 
 ttc_status ttc_debug_clouds_stage(ttc_ctx* c, int32_t stage) {
     if (!c) return TTC_ERR_ARG;

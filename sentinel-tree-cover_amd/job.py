@@ -290,6 +290,109 @@ def remove_cloud_and_shadows(tiles, probs, shadows, image_dates, pfcps, sentinel
     return td, interp, to_remove
 
 
+def adjust_shape(arr, width, height):
+    """job.py:260-318: crop / edge-pad the two spatial axes of [T, X, Y(, C)] (or [X, Y]) to width x height (host-side
+    index plumbing on the arrays as stored, before they are uploaded)."""
+    arr = np.asarray(arr)
+    arr = arr[:, :, :, np.newaxis] if arr.ndim == 3 else arr
+    arr = arr[np.newaxis, :, :, np.newaxis] if arr.ndim == 2 else arr
+    for ax, want in ((1, width), (2, height)):
+        n = arr.shape[ax]
+        if n < want:
+            amt = (want - n) // 2
+            pad = [(0, 0)] * 4
+            pad[ax] = ((1, amt) if ax == 1 else (1, 0)) if amt == 0 else (amt, amt)
+            arr = np.pad(arr, pad, "edge")
+    for ax, want in ((1, width), (2, height)):
+        n = arr.shape[ax]
+        if n > want:
+            amt, even = (n - want) // 2, (n - want) % 2 == 0
+            if amt == 0:
+                sl = slice(1, None)
+            elif even:
+                sl = slice(amt, -amt)
+            else:
+                sl = slice(int(np.floor(amt / 2)), -int(np.ceil(amt / 2)))
+            arr = arr[:, sl] if ax == 1 else arr[:, :, sl]
+    return arr.squeeze()
+
+
+def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True, sampler="reference"):
+    """The numeric flow of process_tile (job.py:641-995) on the device, from the arrays it loads from temp/raw/* :
+    raw = {"s2_10": uint16 [T, X, Y, 4], "s2_20": uint16 [T, X/2, Y/2, 6], "s1": uint16 [12, X, Y, 2], "dem": float [X, Y] (m),
+           "dates": int [T], "clouds": float [T, X, Y] (s2cloudless, only kept in step), "clm": 20 m Sen2Cor mask or None}.
+    Host code takes the DECISIONS the reference takes (which dates to drop, when to re-run the detection); every raster
+    operation runs through the C ABI.  -> (sentinel2 cuda [T', X, Y, 10], dates, interp cuda, s1 cuda, dem cuda (/90),
+    cloudshad cuda, snow cuda uint8), T' <= T."""
+    ctx, t = sess.ctx, sess.ctx.torch
+    s2_20 = np.asarray(raw["s2_20"])
+    if s2_20.ndim == 3:
+        s2_20 = s2_20[np.newaxis]
+    width, height = s2_20.shape[1] * 2, s2_20.shape[2] * 2
+    s2_10 = adjust_shape(raw["s2_10"], width, height)
+    if s2_10.ndim == 3:
+        s2_10 = s2_10[np.newaxis]
+    s1 = ctx.s1_to_db(np.ascontiguousarray(adjust_shape(raw["s1"], width, height)))               # :699-708
+    dem = ctx.median5(np.ascontiguousarray(adjust_shape(np.asarray(raw["dem"], dtype=np.float32), width, height)))   # :713
+    clm = ctx.sen2cor_clean(np.asarray(raw["clm"], dtype=np.float32)) if raw.get("clm") is not None else None      # :688-697
+    dates = np.array(raw["dates"], copy=True)
+    clouds = np.array(raw["clouds"], copy=True) if raw.get("clouds") is not None else np.zeros((len(dates), 1, 1), np.float32)
+    s2 = ctx.upsample_20m(ctx.to_float32(np.ascontiguousarray(s2_10)), ctx.to_float32(np.ascontiguousarray(s2_20)))  # :727-782
+    interp = None
+
+    def drop(idx):
+        nonlocal clouds, dates, s2, clm, interp
+        keep = np.setdiff1d(np.arange(len(dates)), idx)
+        sel = t.as_tensor(keep, device=s2.device)
+        if clouds.shape[0] == len(dates):
+            clouds = np.delete(clouds, idx, axis=0)
+        dates = np.delete(dates, idx)
+        s2 = s2.index_select(0, sel).contiguous()
+        if clm is not None:
+            clm = clm.index_select(0, sel).contiguous()
+        if interp is not None:
+            interp = interp.index_select(0, sel).contiguous()
+
+    X = int(s2.shape[1])
+    counts = ctx.tile_missing_counts(s2)                                                       # id_missing_px(., 2), :786
+    missing = np.argwhere(counts >= (X ** 2) / 2).flatten()
+    if len(missing) > 0:
+        drop(missing)
+    snow, snow_frac = ctx.snow_map(s2)                                                         # :799-821
+    snowy = np.argwhere(snow_frac > 0.25).flatten()
+    if len(snowy) > 10:
+        drop(snowy)
+    # interpolate_missing_vals (:833) is the identity in the reference (its guard can never be true)
+    if not make_shadow:
+        z = t.zeros(s2.shape[:3], dtype=t.float32, device=s2.device)
+        return ctx.clip01(s2), dates, z, s1, ctx.divide(dem, 90.0), z.clone(), snow
+
+    def detect(first):
+        cs, fc = ctx.identify_clouds_shadows(s2, dem, forest_mask, urban_masks)               # :839
+        if clm is not None:
+            ctx.merge_cloud_masks(cs, clm, fc if first else None)                             # :841-846 / :880-884
+        return cs, fc
+
+    cloudshad, fcps = detect(True)
+    interp = ctx.feather(cloudshad, closing=15, clip=True)                                     # id_areas_to_interp, :848
+    for rnd in range(3):                                                                       # :866-921
+        heavy = np.argwhere(ctx.fraction_positive(interp) > 0.9).flatten()
+        if len(heavy) > 0:
+            drop(heavy)
+            cloudshad, fcps = detect(False)
+            if rnd < 2:
+                interp = ctx.feather(cloudshad, closing=15, clip=True)
+    interp = ctx.feather(cloudshad, closing=15, clip=True)
+    fn = reference_sampler if sampler == "reference" else None
+    interp, to_remove, _ = ctx.remove_cloud_and_shadows(s2, cloudshad, fcps, fn)               # :935-945
+    if len(to_remove) > 0:                                                                     # :965-983
+        drop(np.asarray(to_remove))
+        cloudshad, fcps = detect(False)
+        interp = ctx.feather(cloudshad, closing=15, clip=True)
+    dem_m = dem.clone()                      # the detector above used metres; the model wants dem / 90 (:993)
+    return ctx.clip01(s2), dates, interp, s1, ctx.divide(dem_m, 90.0), cloudshad, snow
+
+
 def predict_tile(s2, dates, interp, s1, dem, sess, size=SIZE, to_host=True):
     """One call, device-resident between the stages: cloud-free tile stack ->
     (float32 percent raster with NaN no-data, uint8 product), both [Y, X] like load_mosaic_predictions."""

@@ -1,0 +1,49 @@
+"""GPU parity of the process_tile mirror (job.process_tile: raw arrays -> clean stack) against the golden vectors captured
+by running the reference's process_tile with its file loader replaced."""
+import random
+
+import numpy as np
+import pytest
+
+from tests.helpers import golden, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sess():
+    from ttc import job, weights as Wt
+    return job.TTCSession(Wt.synth_weights(0), win_in=44, length=4, dsen2_weights=None)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_process_tile_matches_reference(sess, tag):
+    from ttc import job
+    g = golden("process_tile.npz")
+    seed, T, w20, h20, with_clm = (int(v) for v in g[f"{tag}_cfg"])
+    raw = synth.synth_raw_files(seed, T, w20, h20, bool(with_clm))
+    random.seed(4)                                           # the gap-fill replays the reference's stdlib RNG stream
+    s2, dates, interp, s1, dem, cloudshad, snow = job.process_tile(raw, sess)
+    np.testing.assert_array_equal(dates, g[f"{tag}_dates"])
+    shp = tuple(int(v) for v in g[f"{tag}_cloudshad_shape"])
+    want_cs = np.unpackbits(g[f"{tag}_cloudshad"])[:np.prod(shp)].reshape(shp).astype(bool)
+    np.testing.assert_array_equal(cloudshad.cpu().numpy() > 0, want_cs)
+    np.testing.assert_array_equal(interp.cpu().numpy()[:, ::2, ::2], g[f"{tag}_interp_sub"])
+    np.testing.assert_array_equal(dem.cpu().numpy(), g[f"{tag}_dem"])
+    sn = snow.cpu().numpy()
+    np.testing.assert_array_equal(sn > 0, np.unpackbits(g[f"{tag}_snow"])[:sn.size].reshape(sn.shape).astype(bool))
+    e1 = np.abs(s1.cpu().numpy()[:, ::4, ::4, :] - g[f"{tag}_s1_sub"]).max()
+    e2 = np.abs(s2.cpu().numpy()[:, ::3, ::3, :] - g[f"{tag}_s2_sub"])
+    print(f"[parity] process_tile {tag}: s1 max|d| = {e1:.2e}, s2 max|d| = {e2.max():.2e} (mean {e2.mean():.2e})")
+    assert e1 < 2e-6                                          # log10f vs numpy's log10
+    assert e2.max() < 5e-4 and e2.mean() < 1e-6              # NNLS from Gram matrices vs scipy's nnls (as in test_gpu_gapfill)
+
+
+def test_adjust_shape_matches_reference_rules():
+    from ttc import job
+    a = np.arange(2 * 7 * 9 * 3, dtype=np.float32).reshape(2, 7, 9, 3)
+    assert job.adjust_shape(a, 6, 8).shape == (2, 6, 8, 3)
+    np.testing.assert_array_equal(job.adjust_shape(a, 6, 8), a[:, 1:, 1:])
+    assert job.adjust_shape(a, 8, 10).shape == (2, 8, 10, 3)
+    np.testing.assert_array_equal(job.adjust_shape(a, 8, 10)[:, 1:, 1:], a)
+    np.testing.assert_array_equal(job.adjust_shape(a[0, ..., 0], 3, 5), a[0, 2:-2, 2:-2, 0])
