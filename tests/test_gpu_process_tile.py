@@ -47,3 +47,34 @@ def test_adjust_shape_matches_reference_rules():
     assert job.adjust_shape(a, 8, 10).shape == (2, 8, 10, 3)
     np.testing.assert_array_equal(job.adjust_shape(a, 8, 10)[:, 1:, 1:], a)
     np.testing.assert_array_equal(job.adjust_shape(a[0, ..., 0], 3, 5), a[0, 2:-2, 2:-2, 0])
+
+
+def test_raw_to_raster_end_to_end_vs_oracle():
+    """uint16 raw arrays -> uint8 tree-cover raster, every stage on the device, against the chained CPU oracle:
+    process_tile -> superresolve_large_tile -> process_subtiles -> load_mosaic_predictions (W = 44 windows on a 160 x 176 tile)."""
+    import torch
+    from oracle import restate_model as M, restate_numpy as O, restate_tile as P
+    from ttc import job, weights as Wt
+    W, size, L = 44, 30, 4
+    w = Wt.synth_weights(0)
+    sess = job.TTCSession(w, win_in=W, length=L)
+    raw = synth.synth_raw_files(91, 6, 80, 88, True)
+    random.seed(4)
+    s2, dates, interp, s1, dem, _, _ = P.process_tile_arrays(raw)
+    ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    s2 = O.superresolve_large_tile(s2, ds)
+    net = M.TreeCoverNet(w, dtype=torch.float32)
+    wins = O.process_subtiles(s2.copy(), dates.copy(), interp.copy(), s1.copy(), dem.copy(), lambda x: O.predict_subtile(x, net, size), size=size, length=L)
+    want_u8, want_f = O.mosaic_predictions(wins, size=size, return_float=True)
+    random.seed(4)
+    g_s2, g_dates, g_interp, g_s1, g_dem, _, _ = job.process_tile(raw, sess)
+    sess.ctx.superresolve_tile(g_s2, quirks=True)
+    e = np.abs(g_s2.cpu().numpy() - s2)
+    print(f"[parity] raw -> clean + super-resolved stack: max|d| = {e.max():.2e}")
+    assert e.max() < 5e-4
+    got_f, got_u8 = job.predict_tile(g_s2, g_dates, g_interp, g_s1, g_dem, sess, size=size)
+    assert got_u8.shape == want_u8.shape
+    assert np.array_equal(np.isnan(got_f), np.isnan(want_f))
+    d = np.abs(got_u8.astype(int) - want_u8.astype(int))
+    print(f"[parity] raw -> uint8 raster: > 1 count {np.mean(d > 1):.2e}, == 1 count {np.mean(d == 1):.2e}")
+    assert (d > 1).mean() < 1e-4 and (d > 0).mean() < 3e-2
