@@ -39,22 +39,30 @@ __device__ __forceinline__ float median_sorted(const float* v, int n) {    // nu
 }
 
 // ---------------------------------------------------------------------------------------------- morphology
-// out = OR of in' over the L1 ball of radius r (binary_dilation with the cross, r iterations; border_value 0)
-__global__ void k_dil_l1(const unsigned char* __restrict__ in, int H, int W, int r, int invert, unsigned char* __restrict__ out) {
+// out = OR of in' over the L1 ball of radius r (binary_dilation with the cross, r iterations; border_value 0), in two
+// passes instead of 2r^2 + 2r + 1 probes: (1) distance to the nearest set pixel along the row, capped at r + 1;
+// (2) a pixel is inside the ball iff some row dy away has such a pixel within r - |dy|.
+__global__ void k_rowdist(const unsigned char* __restrict__ in, int H, int W, int r, int invert, unsigned char* __restrict__ hd) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W) return;
-    in += (long)blockIdx.y * H * W; out += (long)blockIdx.y * H * W;
+    in += (long)blockIdx.y * H * W; hd += (long)blockIdx.y * H * W;
+    const int y = p / W, x = p % W;
+    int best = r + 1;
+    for (int d = 0; d <= r && best > r; ++d) {
+        const int xl = x - d, xr = x + d;
+        if ((xl >= 0 && ((in[y * W + xl] != 0) != (invert != 0))) || (xr < W && ((in[y * W + xr] != 0) != (invert != 0)))) best = d;
+    }
+    hd[p] = (unsigned char)best;
+}
+__global__ void k_coldist(const unsigned char* __restrict__ hd, int H, int W, int r, unsigned char* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    hd += (long)blockIdx.y * H * W; out += (long)blockIdx.y * H * W;
     const int y = p / W, x = p % W;
     bool any = false;
-    for (int dy = -r; dy <= r && !any; ++dy) {
+    for (int dy = -r; dy <= r; ++dy) {
         const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        const int rx = r - abs(dy);
-        for (int dx = -rx; dx <= rx; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
-            if ((in[yy * W + xx] != 0) != (invert != 0)) { any = true; break; }
-        }
+        if (yy >= 0 && yy < H && (int)hd[yy * W + x] <= r - abs(dy)) { any = true; break; }
     }
     out[p] = any;
 }
@@ -276,34 +284,42 @@ __global__ void k_cloud_refs(const float* __restrict__ img, const unsigned char*
     kstar[(long)t * npix + p] = (unsigned short)k;             // the pixel is a "close" cloud in iterations 0 .. k-1
     b75[(long)t * npix + p] = ((b + g) + r) < 0.75f;
 }
-// the adaptive loop of CR.py:1425-1441 on the per-iteration counts: one workgroup per date
-__global__ void k_cloud_loop(const unsigned char* __restrict__ far, const unsigned short* __restrict__ kstar, int npix,
-                             int* __restrict__ kfinal) {
-    __shared__ int hist[kKMax + 1];
-    __shared__ int nfar;
-    const int t = blockIdx.x;
-    for (int i = threadIdx.x; i <= kKMax; i += blockDim.x) hist[i] = 0;
-    if (threadIdx.x == 0) nfar = 0;
+// the adaptive loop of CR.py:1425-1441 replayed on per-iteration counts: histogram of the survival counts (many workgroups per
+// date), then one thread per date walks the histogram
+__global__ void k_kstar_hist(const unsigned char* __restrict__ far, const unsigned short* __restrict__ kstar, int npix,
+                             int* __restrict__ hist /*[T][kKMax + 2]: bins, then the far count*/) {
+    __shared__ int h[kKMax + 1];
+    const int t = blockIdx.y;
+    for (int i = threadIdx.x; i <= kKMax; i += blockDim.x) h[i] = 0;
     __syncthreads();
     int f = 0;
-    for (int p = threadIdx.x; p < npix; p += blockDim.x) { atomicAdd(&hist[kstar[(long)t * npix + p]], 1); f += far[(long)t * npix + p] != 0; }
-    for (int k = 32; k >= 1; k >>= 1) f += __shfl_xor(f, k);
-    if ((threadIdx.x & 63) == 0 && f) atomicAdd(&nfar, f);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double fi = 0.0, fc = 1.0;
-        int k = 0, remaining = npix - hist[0];                  // pixels with kstar > 0 are "close" clouds in iteration 0
-        int used = 0;
-        while ((fc - fi) > 0.075) {
-            fi = (double)nfar / (double)npix;
-            fc = (double)remaining / (double)npix;
-            used = k;
-            ++k;
-            if (k > kKMax) break;
-            remaining -= hist[k];                                // pixels that survive iteration k have kstar > k
-        }
-        kfinal[t] = used;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        atomicAdd(&h[kstar[(long)t * npix + p]], 1);
+        f += far[(long)t * npix + p] != 0;
     }
+    for (int k = 32; k >= 1; k >>= 1) f += __shfl_xor(f, k);
+    int* out = hist + (long)t * (kKMax + 2);
+    if ((threadIdx.x & 63) == 0 && f) atomicAdd(&out[kKMax + 1], f);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= kKMax; i += blockDim.x) if (h[i]) atomicAdd(&out[i], h[i]);
+}
+__global__ void k_cloud_loop(const int* __restrict__ hist_all, int T, int npix, int* __restrict__ kfinal) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int* hist = hist_all + (long)t * (kKMax + 2);
+    const int nfar = hist[kKMax + 1];
+    double fi = 0.0, fc = 1.0;
+    int k = 0, remaining = npix - hist[0];                      // pixels with kstar > 0 are "close" clouds in iteration 0
+    int used = 0;
+    while ((fc - fi) > 0.075) {
+        fi = (double)nfar / (double)npix;
+        fc = (double)remaining / (double)npix;
+        used = k;
+        ++k;
+        if (k > kKMax) break;
+        remaining -= hist[k];                                    // pixels that survive iteration k have kstar > k
+    }
+    kfinal[t] = used;
 }
 __global__ void k_cloud_near(const unsigned short* __restrict__ kstar, const int* __restrict__ kfinal, const unsigned char* __restrict__ b75,
                              int npix, unsigned char* __restrict__ nearc) {
@@ -808,10 +824,16 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
         TTC_HIP(c, hipGetLastError());
         return TTC_OK;
     };
+    unsigned char* hd = static_cast<unsigned char*>(c->scratch_buf("cd_rowdist", (size_t)N));
+    if (!hd) return c->fail(TTC_ERR_NOMEM, "cloud detection scratch");
+    auto dil_l1 = [&](const unsigned char* in, int r, int invert, unsigned char* out) {        // out may alias in
+        hipLaunchKernelGGL(k_rowdist, gpt, b256, 0, s, in, H, W, r, invert, hd);
+        hipLaunchKernelGGL(k_coldist, gpt, b256, 0, s, hd, H, W, r, out);
+    };
     // opening idiom of the reference: dilate(1 - dilate(x == 0, a), b)
     auto open_planes = [&](const unsigned char* in, int a, int b, unsigned char* tmp, unsigned char* out) {
-        hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, in, H, W, a, 1, tmp);
-        hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, tmp, H, W, b, 1, out);
+        dil_l1(in, a, 1, tmp);
+        dil_l1(tmp, b, 1, out);
     };
 
     // ---- 0/1: water index, coarse single-date mask
@@ -831,9 +853,13 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     // ---- 4: cloud candidates
     hipLaunchKernelGGL(k_extra_table, dim3(1), dim3(64), 0, s, extra);
     hipLaunchKernelGGL(k_cloud_refs, gpt, b256, 0, s, img, shadows, forest, d_wins, extra, T, npix, far, kstar, b75);
-    hipLaunchKernelGGL(k_cloud_loop, dim3(T), dim3(1024), 0, s, far, kstar, npix, kfinal);
+    int* khist = static_cast<int*>(c->scratch_buf("cd_khist", sizeof(int) * (size_t)kMaxT * (kKMax + 2)));
+    if (!khist) return c->fail(TTC_ERR_NOMEM, "cloud detection scratch");
+    TTC_HIP(c, hipMemsetAsync(khist, 0, sizeof(int) * (size_t)kMaxT * (kKMax + 2), s));
+    hipLaunchKernelGGL(k_kstar_hist, gred, b256, 0, s, far, kstar, npix, khist);
+    hipLaunchKernelGGL(k_cloud_loop, dim3(1), dim3(64), 0, s, khist, T, npix, kfinal);
     hipLaunchKernelGGL(k_cloud_near, gpt, b256, 0, s, kstar, kfinal, b75, npix, t1);
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, t1, H, W, 2, 1, t2);
+    dil_l1(t1, 2, 1, t2);
     hipLaunchKernelGGL(k_cloud_merge, gpt, b256, 0, s, far, t1, t2, forest, npix, clouds);
     if (debug_stage == 4) return finish(clouds);
     // ---- 5: brightness outliers
@@ -877,11 +903,11 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     hipLaunchKernelGGL(k_dil_l1_3d, gpt, b256, 0, s, t1, T, H, W, 3, nsr);
     hipLaunchKernelGGL(k_fp_nsr, gpt, b256, 0, s, img, water, T, npix, nsr, clouds);
     hipLaunchKernelGGL(k_water_dark, gpt, b256, 0, s, img, water, npix, t1);
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, t1, H, W, 10, 0, t2);
+    dil_l1(t1, 10, 0, t2);
     hipLaunchKernelGGL(k_clear_where, gn, b256, 0, s, t2, N, clouds);
     hipLaunchKernelGGL(k_lone, gpt, b256, 0, s, clouds, H, W, 5, t1);
     hipLaunchKernelGGL(k_dark_px, gpt, b256, 0, s, img, npix, t2);
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, t2, H, W, 3, 0, t3);
+    dil_l1(t2, 3, 0, t3);
     TTC_HIP(c, hipMemsetAsync(has01, 0, sizeof(int) * 2 * kMaxT, s));
     hipLaunchKernelGGL(k_dark_rows_flags, gred, b256, 0, s, t3, forest, npix, has01);
     hipLaunchKernelGGL(k_dark_rows_apply, dim3((W + 255) / 256, T), b256, 0, s, has01, H, W, t1);
@@ -890,16 +916,16 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     if (debug_stage == 80) return finish(shadows);
     if (debug_stage == 81) return finish(nsr);
     // ---- 9: shape clean-up
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, clouds, H, W, 1, 1, t1);          // dilate(clouds == 0, 1)
+    dil_l1(clouds, 1, 1, t1);          // dilate(clouds == 0, 1)
     hipLaunchKernelGGL(k_u8_not, gn, b256, 0, s, t1, N, clouds);                     // eroded clouds
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, pfps, H, W, 5, 0, t1);
+    dil_l1(pfps, 5, 0, t1);
     TTC_HIP(c, hipMemcpyAsync(pfps, t1, N, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_split_urban, gn, b256, 0, s, clouds, pfps, N, t1 /*urban*/, t2 /*rest*/);
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, t1, H, W, 3, 1, t3);               // dilate(urban == 0, 3)
+    dil_l1(t1, 3, 1, t3);               // dilate(urban == 0, 3)
     hipLaunchKernelGGL(k_u8_not, gn, b256, 0, s, t3, N, t1);                          // urban clouds, eroded by 3
     hipLaunchKernelGGL(k_big_small, gpt, b256, 0, s, t2, H, W, t3 /*big*/, far /*small*/);
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, t3, H, W, 5, 0, t2);
-    hipLaunchKernelGGL(k_dil_l1, gpt, b256, 0, s, far, H, W, 1, 0, t3);
+    dil_l1(t3, 5, 0, t2);
+    dil_l1(far, 1, 0, t3);
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, t2, t3, N, far);
     TTC_HIP(c, zero_counts(cnt_a));
     hipLaunchKernelGGL(k_plane_count, gred, b256, 0, s, far, npix, cnt_a);
