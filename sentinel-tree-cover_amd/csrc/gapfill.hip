@@ -353,14 +353,6 @@ __device__ __forceinline__ float snow_prob_px(const float* v) {           // CR.
     if ((v[0] / v[2]) < 0.75f) p = 0.f;
     return p;
 }
-__global__ void k_snow_mean(const float* __restrict__ tiles, int T, int npix, float* __restrict__ snow) {
-#pragma clang fp contract(off)
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += snow_prob_px(tiles + ((long)t * npix + p) * 10);
-    snow[p] = s / (float)T;
-}
 // The mean snow probability is re-evaluated for every date because the stack is blended in place (CR.py:372); only ONE
 // date changes between evaluations, so the per-date probabilities are cached and the mean re-sums T floats per pixel
 // (same values, same order) instead of re-reading the whole stack.
@@ -381,16 +373,6 @@ __device__ __forceinline__ float evi_unclipped(const float* v) {          // CR.
 #pragma clang fp contract(off)
     const float e = 2.5f * ((v[3] - v[2]) / (((v[3] + (6.0f * v[2])) - (7.5f * v[0])) + 1.0f));
     return fminf(fmaxf(e, -1.5f), 1.5f);
-}
-// per-date clear statistics: n(w > 0), n(w == 0), n(w < 1)
-__global__ void k_date_counts(const float* __restrict__ w, int npix, int date, int* __restrict__ out) {
-    int a = 0, b = 0, c = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
-        const float v = w[(long)date * npix + p];
-        a += v > 0.f; b += v == 0.f; c += v < 1.f;
-    }
-    for (int k = 32; k >= 1; k >>= 1) { a += __shfl_xor(a, k); b += __shfl_xor(b, k); c += __shfl_xor(c, k); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], a); atomicAdd(&out[1], b); atomicAdd(&out[2], c); }
 }
 // all dates at once (the feather weights and the water mask do not change inside the date loop)
 __global__ void k_date_counts_all(const float* __restrict__ w, int npix, int* __restrict__ out /*[T][4]*/) {
@@ -534,18 +516,6 @@ __global__ void k_gram_reduce(const double* __restrict__ partial, int nblk, doub
         out[i] = t;
     }
 }
-// expected multiplicity of a row under the reference's stratified sampling (CR.py:453-496), from EVI thresholds
-struct Strata { float b2, b20, b40, b60, b80, b98; float wq[5]; };
-__global__ void k_row_weights(const float* __restrict__ evi, int n, Strata st, float* __restrict__ weight) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float e = evi[i];
-    float w = e < st.b20 ? st.wq[0] : (e < st.b40 ? st.wq[1] : (e < st.b60 ? st.wq[2] : (e < st.b80 ? st.wq[3] : st.wq[4])));
-    if (e < st.b2) w += 10.f;
-    if (e >= st.b98) w += 10.f;
-    weight[i] = w;
-}
-
 // prediction + blend (CR.py:561-569, :954-955): pixels with w_d > 0 get [fill, snow] . beta, then
 // tile = tile * (1 - w) + pred * w
 struct Beta { double b[10][11]; int fitted; };
@@ -590,10 +560,6 @@ __global__ void k_only1(const float* __restrict__ w, const unsigned char* __rest
     for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_only, c);
 }
-__global__ void k_not(const unsigned char* __restrict__ in, int n, unsigned char* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) out[p] = !in[p];
-}
 __global__ void k_cloud_flags(const float* __restrict__ mosaic, const unsigned char* __restrict__ only1,
                               const unsigned char* __restrict__ pf_dil, const float* __restrict__ thr, int npix,
                               unsigned char* __restrict__ out) {
@@ -610,11 +576,6 @@ __global__ void k_add_clouds(float* __restrict__ w, const unsigned char* __restr
     if (p >= npix || !clouds[p]) return;
     for (int t = 0; t < T; ++t) { float v = w[(long)t * npix + p] + 1.0f; w[(long)t * npix + p] = v > 1.f ? 1.f : v; }
 }
-__global__ void k_u8_from_bool(const unsigned char* __restrict__ in, int n, unsigned char* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) out[p] = in[p] != 0;
-}
-
 // ---- device-side control of the per-date fit (no host round trips) --------------------------------
 __global__ void k_date_plan(const int* __restrict__ counters, int npix, int T, DatePlan* __restrict__ plans,
                             int* __restrict__ remove_flags) {
@@ -670,11 +631,9 @@ __global__ void k_row_weights_dev(const float* __restrict__ evi, const DatePlan*
         weight[i] = w;
     }
 }
-__host__ __device__ void nnls_gram(const double G[11][11], const double g[11], double x[11]);
 // Lawson-Hanson NNLS on the normal equations, ONE WAVE per band: lane r owns row r of the active system.  The
-// arithmetic per matrix element is the same as the serial nnls_gram below (row operations of the Gauss-Jordan
-// elimination are independent per row), so both produce identical results; the serial single-lane version took
-// 170-340 us per date (fp64 arrays in scratch), this one ~15 us.
+// arithmetic per matrix element is the same as a serial active-set solver's (row operations of the Gauss-Jordan elimination
+// are independent per row); a single-lane version with fp64 arrays in scratch took 170-340 us per date, this one ~15 us.
 __device__ __forceinline__ int wave_argmax_first(double v, bool eligible) {
     // lowest lane index among the eligible lanes holding the maximum; -1 if none
     double m = eligible ? v : -INFINITY;
@@ -768,60 +727,6 @@ __global__ void k_cloud_thresholds(const SelState* __restrict__ st, const int* _
         const double a = fkey_inv(st[2 * k].prefix), b = fkey_inv(st[2 * k + 1].prefix);
         thr[k] = (float)(a + (b - a) * fr);
     }
-}
-
-// ---- Lawson-Hanson NNLS on the normal equations (n = 11), host and device ----------------------
-__host__ __device__ void nnls_gram(const double G[11][11], const double g[11], double x[11]) {
-    const int n = 11;
-    bool P[11] = {false};
-    for (int i = 0; i < n; ++i) x[i] = 0.0;
-    double wv[11];
-    for (int iter = 0; iter < 3 * n; ++iter) {
-        for (int i = 0; i < n; ++i) { double s = g[i]; for (int j = 0; j < n; ++j) s -= G[i][j] * x[j]; wv[i] = s; }
-        int best = -1; double bw = 0.0;
-        const double tol = 1e-12 * fabs(g[0] + 1e-300) + 1e-15;
-        for (int i = 0; i < n; ++i) if (!P[i] && wv[i] > tol && wv[i] > bw) { bw = wv[i]; best = i; }
-        if (best < 0) break;
-        P[best] = true;
-        for (int inner = 0; inner < 3 * n; ++inner) {
-            // solve G_PP s_P = g_P (Cholesky-free Gaussian elimination with partial pivoting, tiny system)
-            int idx[11], m = 0;
-            for (int i = 0; i < n; ++i) if (P[i]) idx[m++] = i;
-            double A[11][12];
-            for (int r = 0; r < m; ++r) { for (int c2 = 0; c2 < m; ++c2) A[r][c2] = G[idx[r]][idx[c2]]; A[r][m] = g[idx[r]]; }
-            for (int c2 = 0; c2 < m; ++c2) {
-                int piv = c2;
-                for (int r = c2 + 1; r < m; ++r) if (fabs(A[r][c2]) > fabs(A[piv][c2])) piv = r;
-                if (piv != c2) for (int k = 0; k <= m; ++k) { const double tv = A[piv][k]; A[piv][k] = A[c2][k]; A[c2][k] = tv; }
-                const double d = A[c2][c2];
-                if (fabs(d) < 1e-300) continue;
-                for (int r = 0; r < m; ++r) {
-                    if (r == c2) continue;
-                    const double f = A[r][c2] / d;
-                    if (f != 0.0) for (int k = c2; k <= m; ++k) A[r][k] -= f * A[c2][k];
-                }
-            }
-            double sfull[11] = {0};
-            bool allpos = true;
-            for (int r = 0; r < m; ++r) { const double d = A[r][r]; sfull[idx[r]] = fabs(d) < 1e-300 ? 0.0 : A[r][m] / d; if (sfull[idx[r]] <= 0.0) allpos = false; }
-            if (allpos) { for (int i = 0; i < n; ++i) x[i] = P[i] ? sfull[i] : 0.0; break; }
-            double alpha = 1.0;
-            for (int r = 0; r < m; ++r) { const int i = idx[r]; if (sfull[i] <= 0.0) { const double a = x[i] / (x[i] - sfull[i]); if (a < alpha) alpha = a; } }
-            for (int i = 0; i < n; ++i) if (P[i]) x[i] += alpha * (sfull[i] - x[i]);
-            for (int i = 0; i < n; ++i) if (P[i] && x[i] <= 1e-15) { x[i] = 0.0; P[i] = false; }
-        }
-    }
-}
-
-float percentile_host(std::vector<float>& v, double q) {        // numpy 'linear' method
-    if (v.empty()) return NAN;
-    const double pos = q / 100.0 * (double)(v.size() - 1);
-    const size_t lo = (size_t)std::floor(pos), hi = std::min(lo + 1, v.size() - 1);
-    std::nth_element(v.begin(), v.begin() + lo, v.end());
-    const float a = v[lo];
-    float b = a;
-    if (hi != lo) b = *std::min_element(v.begin() + lo + 1, v.end());
-    return (float)((double)a + ((double)b - (double)a) * (pos - (double)lo));
 }
 
 }  // namespace

@@ -66,7 +66,6 @@ __global__ void k_gn_finalize(const float* __restrict__ stats, float* __restrict
 //   is consumed (k_gru_apply2) instead of making a round trip through HBM.
 struct GruParams { const float* base; long dir_stride; };   // per-direction parameter block
 // parameter block layout (floats): gr[32] br[32] gu[32] bu[32] k1[32] gy[32] by[32]
-constexpr int kGruParamFloats = 7 * 32;
 
 __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm,
                              const float* __restrict__ hcur, float* __restrict__ rh, int W, int N) {
