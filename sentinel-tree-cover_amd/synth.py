@@ -184,5 +184,5 @@ def synth_raw_files(seed=91, T=6, w20=40, h20=44, with_clm=True):
     if with_clm:
         clm = np.zeros((T, w20, h20), dtype=np.float32)
         clm[1, 5:12, 6:15] = 1.0; clm[2, 5:12, 6:15] = 1.0                # "two in a row" -> dropped (job.py:691-697)
-        clm[4, 20:30, 10:22] = 1.0
+        clm[min(4, T - 1), 20:30, 10:22] = 1.0
     return {"s2_10": s2_10, "s2_20": s2_20, "s1": s1u, "dem": dem.astype(np.float32), "dates": np.asarray(dates), "clouds": clouds, "clm": clm}

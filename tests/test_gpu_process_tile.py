@@ -39,6 +39,44 @@ def test_process_tile_matches_reference(sess, tag):
     assert e2.max() < 5e-4 and e2.mean() < 1e-6              # NNLS from Gram matrices vs scipy's nnls (as in test_gpu_gapfill)
 
 
+@pytest.mark.parametrize("case", ["missing_date", "three_dates", "odd_20m_grid", "no_shadow"])
+def test_process_tile_edge_cases_vs_oracle(sess, case):
+    """dropped dates (more than half of a date missing), a short stack, an odd 20 m grid (the 40 m bands take the
+    reference's odd-grid branches), and make_shadow=False -- against the oracle of the same flow"""
+    from oracle import restate_tile as P
+    from ttc import job
+    if case == "missing_date":
+        raw = synth.synth_raw_files(93, 6, 60, 56, False)
+        raw["s2_10"][4, : 100] = 0                              # > 50 % of date 4 is missing -> id_missing_px drops it
+    elif case == "three_dates":
+        raw = synth.synth_raw_files(94, 3, 60, 56, True)
+    elif case == "odd_20m_grid":
+        raw = synth.synth_raw_files(95, 5, 61, 57, False)
+    else:
+        raw = synth.synth_raw_files(96, 5, 60, 56, True)
+    if case == "no_shadow":
+        got = job.process_tile(raw, sess, make_shadow=False)
+        s2 = O_upsampled(raw)
+        assert np.abs(got[0].cpu().numpy() - np.clip(s2, 0, 1)).max() < 1e-6 and float(got[2].abs().max()) == 0.0
+        return
+    random.seed(7)
+    want = P.process_tile_arrays(raw)
+    random.seed(7)
+    got = job.process_tile(raw, sess)
+    np.testing.assert_array_equal(got[1], want[1])
+    assert len(got[1]) < len(raw["dates"]) or case != "missing_date"
+    np.testing.assert_array_equal(got[5].cpu().numpy() > 0, want[5] > 0)
+    np.testing.assert_array_equal(got[2].cpu().numpy(), want[2])
+    e = np.abs(got[0].cpu().numpy() - want[0])
+    print(f"[parity] process_tile {case}: dates {list(got[1])}, s2 max|d| = {e.max():.2e}")
+    assert e.max() < 5e-4 and e.mean() < 1e-6
+
+
+def O_upsampled(raw):
+    from oracle import restate_numpy as R
+    return R.upsample_20m(R.to_float32(raw["s2_10"]), R.to_float32(raw["s2_20"]))
+
+
 def test_adjust_shape_matches_reference_rules():
     from ttc import job
     a = np.arange(2 * 7 * 9 * 3, dtype=np.float32).reshape(2, 7, 9, 3)
