@@ -34,7 +34,8 @@ FP32_MFMA_PEAK_TF = 157.3        # v_mfma_f32_32x32x2_f32, dense
 def pmc_traffic(args):
     """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the
     timed process).  Only valid for the configuration the counters were collected on."""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_conv_gates.json")
+    name = "r01_c_pmc_conv_gates.json" if args.precision == "fp32" else "r01_f_pmc_conv_b3_gates.json"
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
     if args.win != 172 or not os.path.exists(p):
         return None
     with open(p) as f:
@@ -55,7 +56,7 @@ def roofline(args, gates_ms, gates_n):
     ach = nbytes / (gates_ms * 1e-3) / 1e9 if gates_ms > 0 else 0.0
     return {"kernel": "conv3x3_b3<NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions, split-bf16 MFMA)",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None, "launch_ms": gates_ms, "launches_timed": gates_n, "bytes_per_launch": nbytes,
+            "traffic": pmc_traffic(args), "launch_ms": gates_ms, "launches_timed": gates_n, "bytes_per_launch": nbytes,
             "mfma_bf16_frac": 3.0 * flops * (56.0 / 49) * (10.0 / 9) / (gates_ms * 1e-3) / 2.5e15 if gates_ms > 0 else 0.0}
 
 
