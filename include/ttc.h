@@ -52,6 +52,9 @@ typedef struct {
     int32_t base_filters;  /* 64                                                        */
     float   zoneout;       /* 0.75: state' = z*state + (1-z)*new  (model.py:571-574)    */
     int32_t precision;     /* 0 = fp32 MFMA (exact fp32 FMA chains)                     */
+    int32_t win_rows;      /* H: window rows for the non-square border graph of
+                            * src/resegment_tiles_wide.py:478 ([L+1, SIZE_Y+14, SIZE+14, 17] = 220 x 684);
+                            * 0 = square (win_in).  The per-tile core needs square windows. */
 } ttc_config;
 
 /* A named host tensor in TensorFlow layout (conv kernels HWIO). */
@@ -82,13 +85,13 @@ ttc_status ttc_load_dsen2_weights(ttc_ctx* ctx, const ttc_tensor* tensors, int32
 /* ---- model forward ------------------------------------------------------------------
  * == sess.run(predict_logits, {predict_inp: x, predict_length: L}) inside
  * predict_subtile, src/download_and_predict_job.py:353-357, batched over windows.
- * d_in : [n, L+1, W, W, 17] float32 (already normalised, job.py:316-325)
- * d_out: [n, W-14, W-14]    float32 probabilities                                      */
+ * d_in : [n, L+1, H, W, 17] float32 (already normalised, job.py:316-325); H = win_rows or W
+ * d_out: [n, H-14, W-14]    float32 probabilities                                      */
 ttc_status ttc_forward_windows(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, void* stream);
 
 /* Forward + the two feature tensors of --gen_feats (job.py:1429-1445; tensors named at :1808-1809):
- * d_early [n, W, W, 64]       == sess.run("predict/gru_drop/drop_block2d/cond/Merge:0")  (bi-ConvGRU output)
- * d_late  [n, W-14, W-14, 64] == sess.run("predict/csse_out_mul/mul:0")                  (last block after its sSE gate)
+ * d_early [n, H, W, 64]       == sess.run("predict/gru_drop/drop_block2d/cond/Merge:0")  (bi-ConvGRU output)
+ * d_late  [n, H-14, W-14, 64] == sess.run("predict/csse_out_mul/mul:0")                  (last block after its sSE gate)
  * either may be NULL. */
 ttc_status ttc_forward_taps(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, float* d_early, float* d_late,
                             void* stream);

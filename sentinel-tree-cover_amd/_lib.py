@@ -31,7 +31,7 @@ SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C
 class TTCConfig(C.Structure):
     _fields_ = [("win_in", C.c_int32), ("length", C.c_int32), ("max_windows", C.c_int32),
                 ("n_bands", C.c_int32), ("hidden", C.c_int32), ("base_filters", C.c_int32),
-                ("zoneout", C.c_float), ("precision", C.c_int32)]
+                ("zoneout", C.c_float), ("precision", C.c_int32), ("win_rows", C.c_int32)]
 
 
 class TTCTensor(C.Structure):
@@ -129,10 +129,10 @@ def pack_tensors(weights: dict):
 class Context:
     """One libttc context: (device, window geometry, weights, workspace)."""
 
-    def __init__(self, win_in=172, length=4, max_windows=36, device=0, zoneout=0.75, precision=0):
+    def __init__(self, win_in=172, length=4, max_windows=36, device=0, zoneout=0.75, precision=0, win_rows=0):
         self.lib = load()
         self.torch = _torch()
-        self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision)
+        self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision, win_rows)
         self.device = device
         self._h = C.c_void_p()
         st = self.lib.ttc_create(C.byref(self._h), device, C.byref(self.cfg))
@@ -189,13 +189,14 @@ class Context:
 
     # -- model ----------------------------------------------------------------------------
     def forward_windows(self, x, out=None):
-        """x [n, L+1, W, W, 17] float32 (numpy or cuda tensor) -> cuda tensor [n, W-14, W-14]."""
+        """x [n, L+1, H, W, 17] float32 (numpy or cuda tensor) -> cuda tensor [n, H-14, W-14]; H = win_rows or W."""
         t = self.torch
         xd = self._dev(x, t.float32)
         n, W = xd.shape[0], self.cfg.win_in
-        assert tuple(xd.shape[1:]) == (self.cfg.length + 1, W, W, 17), xd.shape
+        H = self.cfg.win_rows or W
+        assert tuple(xd.shape[1:]) == (self.cfg.length + 1, H, W, 17), xd.shape
         if out is None:
-            out = t.empty((n, W - 14, W - 14), dtype=t.float32, device=xd.device)
+            out = t.empty((n, H - 14, W - 14), dtype=t.float32, device=xd.device)
         self._check(self.lib.ttc_forward_windows(self._h, C.c_void_p(xd.data_ptr()), n,
                                                  C.c_void_p(out.data_ptr()), self._stream()),
                     "ttc_forward_windows")
@@ -266,14 +267,16 @@ class Context:
         return out
 
     def forward_taps(self, x, early=True, late=True):
-        """forward + feature taps: -> (probs [n, o, o], early [n, W, W, 64] | None, late [n, o, o, 64] | None), cuda float32"""
+        """forward + feature taps: -> (probs [n, oh, ow], early [n, H, W, 64] | None, late [n, oh, ow, 64] | None), cuda float32"""
         t = self.torch
         a = self._dev(x, t.float32)
         n, W = int(a.shape[0]), self.cfg.win_in
-        o = W - 14
-        out = t.empty((n, o, o), dtype=t.float32, device=a.device)
-        e = t.empty((n, W, W, 64), dtype=t.float32, device=a.device) if early else None
-        l = t.empty((n, o, o, 64), dtype=t.float32, device=a.device) if late else None
+        H = self.cfg.win_rows or W
+        assert tuple(a.shape[1:]) == (self.cfg.length + 1, H, W, 17), a.shape
+        oh, ow = H - 14, W - 14
+        out = t.empty((n, oh, ow), dtype=t.float32, device=a.device)
+        e = t.empty((n, H, W, 64), dtype=t.float32, device=a.device) if early else None
+        l = t.empty((n, oh, ow, 64), dtype=t.float32, device=a.device) if late else None
         self._check(self.lib.ttc_forward_taps(self._h, C.c_void_p(a.data_ptr()), n, C.c_void_p(out.data_ptr()),
                                               C.c_void_p(e.data_ptr()) if early else None,
                                               C.c_void_p(l.data_ptr()) if late else None, self._stream()), "ttc_forward_taps")

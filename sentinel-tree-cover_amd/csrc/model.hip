@@ -25,21 +25,21 @@ __device__ __forceinline__ float tanh_fast(float v) { return 1.0f - 2.0f * __bui
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // ---------------------------------------------------------------------------------------
-// [n][L+1][W][W][C] (reference feed layout) -> padded planar frames [n][L+1][C][W+2][W+2];
+// [n][L+1][H][W][C] (reference feed layout) -> padded planar frames [n][L+1][C][H+2][W+2];
 // frames < L reflect-padded (ConvGRU, model.py:250), frame L zero-padded (SAME conv).
-__global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict__ frames, int L1, int W, int C) {
-    const int Wp = W + 2;
+__global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict__ frames, int L1, int H, int W, int C) {
+    const int Wp = W + 2, PP = (H + 2) * Wp;
     const int f = blockIdx.y, n = blockIdx.z;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= Wp * Wp) return;
+    if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
     const bool last = (f == L1 - 1);
     int sy = py - 1, sx = px - 1;
-    const bool border = sy < 0 || sy >= W || sx < 0 || sx >= W;
-    sy = reflect_idx(sy, W); sx = reflect_idx(sx, W);
-    const float* src = in + ((((long)n * L1 + f) * W + sy) * W + sx) * C;
-    float* dst = frames + (((long)n * L1 + f) * C) * (Wp * Wp) + p;
-    for (int c = 0; c < C; ++c) dst[(long)c * Wp * Wp] = (last && border) ? 0.0f : src[c];
+    const bool border = sy < 0 || sy >= H || sx < 0 || sx >= W;
+    sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
+    const float* src = in + ((((long)n * L1 + f) * H + sy) * W + sx) * C;
+    float* dst = frames + (((long)n * L1 + f) * C) * PP + p;
+    for (int c = 0; c < C; ++c) dst[(long)c * PP] = (last && border) ? 0.0f : src[c];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -68,13 +68,13 @@ struct GruParams { const float* base; long dir_stride; };   // per-direction par
 // parameter block layout (floats): gr[32] br[32] gu[32] bu[32] k1[32] gy[32] by[32]
 
 __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm,
-                             const float* __restrict__ hcur, float* __restrict__ rh, int W, int N) {
-    const int Wp = W + 2, PP = Wp * Wp, P = W * W;
+                             const float* __restrict__ hcur, float* __restrict__ rh, int H, int W, int N) {
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
-    const int s = reflect_idx(py - 1, W) * W + reflect_idx(px - 1, W);
+    const int s = reflect_idx(py - 1, H) * W + reflect_idx(px - 1, W);
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yg + (long)n * 64 * P + s;
     const float* g = gn + (long)n * 32;      // 16 groups x (mean, rstd): 0-7 r, 8-15 u
@@ -95,15 +95,15 @@ __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restri
 __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
                              const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
                              const float* __restrict__ hcur, float* __restrict__ hnext,
-                             float* __restrict__ gru_out, int W, int N, float z) {
-    const int Wp = W + 2, PP = Wp * Wp, P = W * W;
+                             float* __restrict__ gru_out, int H, int W, int N, float z) {
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
     const int sy0 = py - 1, sx0 = px - 1;
-    const bool interior = sy0 >= 0 && sy0 < W && sx0 >= 0 && sx0 < W;
-    const int s = reflect_idx(sy0, W) * W + reflect_idx(sx0, W);
+    const bool interior = sy0 >= 0 && sy0 < H && sx0 >= 0 && sx0 < W;
+    const int s = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yc + (long)n * 32 * P + s;
     const float* g = gn + (long)n * 16;      // 8 groups x (mean, rstd)
@@ -214,15 +214,15 @@ __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__
 }
 
 // ---- feature taps (--gen_feats, job.py:1429-1445, tensors named at :1808-1809) -------------------------
-// early = the bi-ConvGRU output (`gru_drop/.../Merge:0`, inference: identity), [n, W, W, 64] NHWC
-__global__ void k_tap_early(const float* __restrict__ gru_out, int W, int N, float* __restrict__ out) {
+// early = the bi-ConvGRU output (`gru_drop/.../Merge:0`, inference: identity), [n, H, W, 64] NHWC
+__global__ void k_tap_early(const float* __restrict__ gru_out, int H, int W, int N, float* __restrict__ out) {
     const int Wp = W + 2;
-    const long PP = (long)Wp * Wp, total = (long)N * W * W * 64;
+    const long PP = (long)(H + 2) * Wp, total = (long)N * H * W * 64;
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
     const int ch = (int)(id & 63);
     const long pix = id >> 6;
-    const int n = (int)(pix / ((long)W * W)), r = (int)(pix - (long)n * W * W);
+    const int n = (int)(pix / ((long)H * W)), r = (int)(pix - (long)n * H * W);
     const int y = r / W, x = r - y * W;
     out[id] = gru_out[((long)n * 64 + ch) * PP + (long)(y + 1) * Wp + (x + 1)];
 }
@@ -247,11 +247,15 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
     for (int c = 0; c < C; ++c) o[c] = (y[(long)c * P] * sm[c] + sm[C + c]) * gate;
 }
 
+// U-Net geometry of one axis (train-model.py:140-231): pool, VALID conv, pool, VALID conv, x2, x2, VALID conv
+struct Axis {
+    int n, np, c1, c2, u2, u3, o;
+    explicit Axis(int n_) : n(n_), np(n_ + 2) { c1 = n / 2 - 2; c2 = c1 / 2 - 2; u2 = 2 * c2; u3 = 2 * u2; o = u3 - 2; }
+};
 struct Geo {
-    int W, Wp, L, c1, c2, u2, u3, o;
-    explicit Geo(const ttc_config& c) : W(c.win_in), Wp(c.win_in + 2), L(c.length) {
-        c1 = W / 2 - 2; c2 = c1 / 2 - 2; u2 = 2 * c2; u3 = 2 * u2; o = u3 - 2;
-    }
+    Axis y, x;      // rows (win_rows, or win_in when 0) and columns (win_in)
+    int L;
+    explicit Geo(const ttc_config& c) : y(c.win_rows > 0 ? c.win_rows : c.win_in), x(c.win_in), L(c.length) {}
 };
 
 const char* kBlockNames[8] = {"conv_median", "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out"};
@@ -283,10 +287,15 @@ void* ttc_ctx::scratch_buf(const std::string& key, size_t bytes) {
 ttc_status model_alloc(ttc_ctx* c) {
     const Geo g(c->cfg);
     const size_t N = c->cfg.max_windows, N2 = 2 * N;
-    const size_t PP = (size_t)g.Wp * g.Wp, P = (size_t)g.W * g.W;
+    const size_t PP = (size_t)g.y.np * g.x.np, P = (size_t)g.y.n * g.x.n;
     const int F = c->cfg.base_filters, Hd = c->cfg.hidden, C = c->cfg.n_bands;
-    if (g.W % 4 != 0 || g.W < 28) return c->fail(TTC_ERR_ARG, "win_in must be a multiple of 4 and >= 28");
+    if (g.x.n % 4 != 0 || g.x.n < 28) return c->fail(TTC_ERR_ARG, "win_in must be a multiple of 4 and >= 28");
+    if (g.y.n % 4 != 0 || g.y.n < 28) return c->fail(TTC_ERR_ARG, "win_rows must be a multiple of 4 and >= 28 (or 0)");
     if (F != 64 || Hd != 32 || C != 17) return c->fail(TTC_ERR_ARG, "only base_filters=64, hidden=32, n_bands=17 are built");
+    auto area = [&](int Axis::*m, int pad) { return (size_t)(g.y.*m + pad) * (g.x.*m + pad); };
+    const size_t Pc1 = area(&Axis::c1, 0), Pc2 = area(&Axis::c2, 0), Pu2 = area(&Axis::u2, 0), Pu2p = area(&Axis::u2, 2);
+    const size_t Pu3 = area(&Axis::u3, 0), Pu3p = area(&Axis::u3, 2), Po = area(&Axis::o, 0);
+    const size_t Ph2 = (size_t)(g.y.c1 / 2) * (g.x.c1 / 2);
 #define A(field, count, name)                                                        \
     if (!(c->field = c->alloc_f((count), name))) return c->fail(TTC_ERR_NOMEM, "hipMalloc " name)
     A(frames, N * (g.L + 1) * C * PP, "frames");
@@ -294,15 +303,15 @@ ttc_status model_alloc(ttc_ctx* c) {
     A(yg, N2 * 2 * Hd * P, "yg"); A(ug, N2 * Hd * P, "u"); A(yc, N2 * Hd * P, "yc");
     A(gru_out, N * F * PP, "gru_out");
     A(y_med, N * F * P, "y_med"); A(z_med, N * F * PP, "z_med"); A(y_cat, N * F * P, "y_cat");
-    A(p1, N * F * (P / 4), "p1"); A(y_c1, N * 2 * F * g.c1 * g.c1, "y_c1");
-    A(p2, N * 2 * F * (g.c1 / 2) * (g.c1 / 2), "p2"); A(y_c2, N * 4 * F * g.c2 * g.c2, "y_c2");
-    A(u2in, N * 4 * F * (g.u2 + 2) * (g.u2 + 2), "u2in"); A(y_u2, N * 2 * F * g.u2 * g.u2, "y_u2");
-    A(u2a, N * 4 * F * (g.u2 + 2) * (g.u2 + 2), "u2cat");     // [up2 | crop(conv1)] concat buffer
-    A(y_u2o, N * 2 * F * g.u2 * g.u2, "y_u2o");
-    A(u3in, N * 2 * F * (g.u3 + 2) * (g.u3 + 2), "u3in"); A(y_u3, N * F * g.u3 * g.u3, "y_u3");
-    A(oa, N * 2 * F * g.u3 * g.u3, "ocat");                    // [up3 | crop(concat)] concat buffer
-    A(y_out, N * F * g.o * g.o, "y_out");
-    c->stats_floats = N2 * 16 * (size_t)conv_stat_slots(g.Wp, g.Wp) * 2 + 1024;
+    A(p1, N * F * (P / 4), "p1"); A(y_c1, N * 2 * F * Pc1, "y_c1");
+    A(p2, N * 2 * F * Ph2, "p2"); A(y_c2, N * 4 * F * Pc2, "y_c2");
+    A(u2in, N * 4 * F * Pu2p, "u2in"); A(y_u2, N * 2 * F * Pu2, "y_u2");
+    A(u2a, N * 4 * F * Pu2p, "u2cat");                         // [up2 | crop(conv1)] concat buffer
+    A(y_u2o, N * 2 * F * Pu2, "y_u2o");
+    A(u3in, N * 2 * F * Pu3p, "u3in"); A(y_u3, N * F * Pu3, "y_u3");
+    A(oa, N * 2 * F * Pu3, "ocat");                            // [up3 | crop(concat)] concat buffer
+    A(y_out, N * F * Po, "y_out");
+    c->stats_floats = N2 * 16 * (size_t)conv_stat_slots(g.y.np, g.x.np) * 2 + 1024;
     A(stats, c->stats_floats, "stats");
     A(gn, 10 * N2 * 32, "gn");
 #undef A
@@ -386,8 +395,8 @@ ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
 ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStream_t s) {
     const Geo g(c->cfg);
     KTimer kt(c, "frames_from_nhwc", s);
-    dim3 grid((g.Wp * g.Wp + 255) / 256, g.L + 1, n);
-    hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.W, c->cfg.n_bands);
+    dim3 grid((g.y.np * g.x.np + 255) / 256, g.L + 1, n);
+    hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.y.n, g.x.n, c->cfg.n_bands);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }
@@ -417,11 +426,12 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
-    const long PP = (long)g.Wp * g.Wp, P = (long)g.W * g.W;
+    const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
+    const long PP = (long)Hp * Wp, P = (long)H * W;
     const float* sm = c->d_small;
     float* gn_slot[10];
     for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
-    const int nblk_full = conv_stat_slots(g.Wp, g.Wp);
+    const int nblk_full = conv_stat_slots(Hp, Wp);
 
     // ---------------- bi-directional ConvGRU ----------------
     TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
@@ -431,16 +441,16 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         ConvArgs a{};
         a.seg[0] = {c->frames, (long)(g.L + 1) * Cx * PP, {(long)st * Cx * PP, (long)(g.L - 1 - st) * Cx * PP}, Cx};
         a.seg[1] = {c->h[cur], (long)Hd * PP, {0, (long)N * Hd * PP}, Hd};
-        a.Cin = Cx + Hd; a.Hp = g.Wp; a.Wp = g.Wp; a.Cout = 2 * Hd;
+        a.Cin = Cx + Hd; a.Hp = Hp; a.Wp = Wp; a.Cout = 2 * Hd;
         a.w = c->w_gates.d_w; a.w_set_stride = c->w_gates.set_stride; a.n_per_set = N;
-        a.out = c->yg; a.out_stride_n = 2L * Hd * P; a.out_plane = P; a.out_pitch = g.W; a.oy = a.ox = 0;
+        a.out = c->yg; a.out_stride_n = 2L * Hd * P; a.out_plane = P; a.out_pitch = W; a.oy = a.ox = 0;
         a.stats = c->stats;
         { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply1", s);
             hipLaunchKernelGGL(k_gru_apply1, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
-                               c->h[cur], c->rh, g.W, N);
+                               c->h[cur], c->rh, H, W, N);
             TTC_HIP(c, hipGetLastError());
         }
         a.seg[1].base = c->rh;
@@ -452,63 +462,67 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         {
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
-                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h[cur], c->h[cur ^ 1], st == g.L - 1 ? c->gru_out : nullptr, g.W, N,
-                               c->cfg.zoneout);
+                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h[cur], c->h[cur ^ 1],
+                               st == g.L - 1 ? c->gru_out : nullptr, H, W, N, c->cfg.zoneout);
             TTC_HIP(c, hipGetLastError());
         }
         cur ^= 1;
     }
 
     // ---------------- U-Net ----------------
-    auto block_conv = [&](int b, ConvSeg s0, ConvSeg s1, int Hp, int Wp, int same, float* out, const char* tname) -> ttc_status {
+    struct Dim { int h, w; long area() const { return (long)h * w; } };
+    auto dim = [&](int Axis::*m, int pad) { return Dim{g.y.*m + pad, g.x.*m + pad}; };
+    auto block_conv = [&](int b, ConvSeg s0, ConvSeg s1, Dim in, int same, float* out, const char* tname) -> ttc_status {
         ConvArgs a{};
-        a.seg[0] = s0; a.seg[1] = s1; a.Cin = s0.C + s1.C; a.Hp = Hp; a.Wp = Wp; a.Cout = kBlockCout[b];
+        a.seg[0] = s0; a.seg[1] = s1; a.Cin = s0.C + s1.C; a.Hp = in.h; a.Wp = in.w; a.Cout = kBlockCout[b];
         a.w = c->w_block[b].d_w; a.w_set_stride = 0; a.n_per_set = N;
-        const long Po = (long)(Hp - 2) * (Wp - 2);
-        a.out = out; a.out_stride_n = (long)a.Cout * Po; a.out_plane = Po; a.out_pitch = Wp - 2; a.oy = a.ox = 0;
+        const long Po = (long)(in.h - 2) * (in.w - 2);
+        a.out = out; a.out_stride_n = (long)a.Cout * Po; a.out_plane = Po; a.out_pitch = in.w - 2; a.oy = a.ox = 0;
         a.stats = c->stats; a.same_pad = same;
         { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
-        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots(Hp, Wp), (double)(a.Cout / 8) * Po, s);
+        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
-    auto fin = [&](int b, int mode, const float* y, int Hs, float* dst, int Hd_, int pad, int crop, long dst_stride_n,
+    // src: raw conv output dims; dst: destination dims INCLUDING pad
+    auto fin = [&](int b, int mode, const float* y, Dim src, float* dst, Dim d, int pad, int crop, long dst_stride_n,
                    int coff) -> ttc_status {
-        FinArgs f{y, gn_slot[b], prm(b), dst, kBlockCout[b], Hs, Hs, Hd_, Hd_, pad, crop, mode, dst_stride_n, coff};
+        FinArgs f{y, gn_slot[b], prm(b), dst, kBlockCout[b], src.h, src.w, d.h, d.w, pad, crop, mode, dst_stride_n, coff};
         return finalize(c, mode, f, N, s);
     };
     const ConvSeg none{nullptr, 0, {0, 0}, 0};
+    const Dim full{H, W}, fullp{Hp, Wp}, half{H / 2, W / 2};
+    const Dim c1 = dim(&Axis::c1, 0), c2 = dim(&Axis::c2, 0), u2 = dim(&Axis::u2, 0), u2p = dim(&Axis::u2, 2);
+    const Dim u3 = dim(&Axis::u3, 0), u3p = dim(&Axis::u3, 2), o = dim(&Axis::o, 0);
+    const Dim h2{c1.h / 2, c1.w / 2};
     // conv_median on the median frame (zero-padded SAME)
-    TTC_CHECK(block_conv(0, {c->frames + (long)g.L * Cx * PP, (long)(g.L + 1) * Cx * PP, {0, 0}, Cx}, none, g.Wp, g.Wp, 1,
+    TTC_CHECK(block_conv(0, {c->frames + (long)g.L * Cx * PP, (long)(g.L + 1) * Cx * PP, {0, 0}, Cx}, none, fullp, 1,
                          c->y_med, "conv_median"));
-    TTC_CHECK(fin(0, G_COPY, c->y_med, g.W, c->z_med, g.Wp, 1, 0, (long)F * PP, 0));
+    TTC_CHECK(fin(0, G_COPY, c->y_med, full, c->z_med, fullp, 1, 0, (long)F * PP, 0));
     // conv_concat([gru, median_conv])
-    TTC_CHECK(block_conv(1, {c->gru_out, (long)F * PP, {0, 0}, F}, {c->z_med, (long)F * PP, {0, 0}, F}, g.Wp, g.Wp, 1,
+    TTC_CHECK(block_conv(1, {c->gru_out, (long)F * PP, {0, 0}, F}, {c->z_med, (long)F * PP, {0, 0}, F}, fullp, 1,
                          c->y_cat, "conv_concat"));
-    TTC_CHECK(fin(1, G_POOL, c->y_cat, g.W, c->p1, g.W / 2, 0, 0, (long)F * (P / 4), 0));
+    TTC_CHECK(fin(1, G_POOL, c->y_cat, full, c->p1, half, 0, 0, (long)F * half.area(), 0));
     // conv1 (VALID) on pool1
-    TTC_CHECK(block_conv(2, {c->p1, (long)F * (P / 4), {0, 0}, F}, none, g.W / 2, g.W / 2, 0, c->y_c1, "conv1"));
-    const int h2 = g.c1 / 2;
-    TTC_CHECK(fin(2, G_POOL, c->y_c1, g.c1, c->p2, h2, 0, 0, 2L * F * h2 * h2, 0));
+    TTC_CHECK(block_conv(2, {c->p1, (long)F * half.area(), {0, 0}, F}, none, half, 0, c->y_c1, "conv1"));
+    TTC_CHECK(fin(2, G_POOL, c->y_c1, c1, c->p2, h2, 0, 0, 2L * F * h2.area(), 0));
     // conv2 (VALID) on pool2
-    TTC_CHECK(block_conv(3, {c->p2, 2L * F * h2 * h2, {0, 0}, 2 * F}, none, h2, h2, 0, c->y_c2, "conv2"));
-    const int u2p = g.u2 + 2;
-    TTC_CHECK(fin(3, G_UP, c->y_c2, g.c2, c->u2in, u2p, 1, 0, 4L * F * u2p * u2p, 0));
+    TTC_CHECK(block_conv(3, {c->p2, 2L * F * h2.area(), {0, 0}, 2 * F}, none, h2, 0, c->y_c2, "conv2"));
+    TTC_CHECK(fin(3, G_UP, c->y_c2, c2, c->u2in, u2p, 1, 0, 4L * F * u2p.area(), 0));
     // up2 (SAME) on nearest x2
-    TTC_CHECK(block_conv(4, {c->u2in, 4L * F * u2p * u2p, {0, 0}, 4 * F}, none, u2p, u2p, 1, c->y_u2, "up2"));
-    TTC_CHECK(fin(4, G_COPY, c->y_u2, g.u2, c->u2a, u2p, 1, 0, 4L * F * u2p * u2p, 0));
-    TTC_CHECK(fin(2, G_COPY, c->y_c1, g.c1, c->u2a, u2p, 1, 2, 4L * F * u2p * u2p, 2 * F));   // crop(conv1, 2)
-    TTC_CHECK(block_conv(5, {c->u2a, 4L * F * u2p * u2p, {0, 0}, 4 * F}, none, u2p, u2p, 1, c->y_u2o, "up2_out"));
-    const int u3p = g.u3 + 2;
-    TTC_CHECK(fin(5, G_UP, c->y_u2o, g.u2, c->u3in, u3p, 1, 0, 2L * F * u3p * u3p, 0));
+    TTC_CHECK(block_conv(4, {c->u2in, 4L * F * u2p.area(), {0, 0}, 4 * F}, none, u2p, 1, c->y_u2, "up2"));
+    TTC_CHECK(fin(4, G_COPY, c->y_u2, u2, c->u2a, u2p, 1, 0, 4L * F * u2p.area(), 0));
+    TTC_CHECK(fin(2, G_COPY, c->y_c1, c1, c->u2a, u2p, 1, 2, 4L * F * u2p.area(), 2 * F));   // crop(conv1, 2)
+    TTC_CHECK(block_conv(5, {c->u2a, 4L * F * u2p.area(), {0, 0}, 4 * F}, none, u2p, 1, c->y_u2o, "up2_out"));
+    TTC_CHECK(fin(5, G_UP, c->y_u2o, u2, c->u3in, u3p, 1, 0, 2L * F * u3p.area(), 0));
     // up3 (SAME)
-    TTC_CHECK(block_conv(6, {c->u3in, 2L * F * u3p * u3p, {0, 0}, 2 * F}, none, u3p, u3p, 1, c->y_u3, "up3"));
-    TTC_CHECK(fin(6, G_COPY, c->y_u3, g.u3, c->oa, g.u3, 0, 0, 2L * F * g.u3 * g.u3, 0));
-    TTC_CHECK(fin(1, G_COPY, c->y_cat, g.W, c->oa, g.u3, 0, 6, 2L * F * g.u3 * g.u3, F));     // crop(concat, 6)
+    TTC_CHECK(block_conv(6, {c->u3in, 2L * F * u3p.area(), {0, 0}, 2 * F}, none, u3p, 1, c->y_u3, "up3"));
+    TTC_CHECK(fin(6, G_COPY, c->y_u3, u3, c->oa, u3, 0, 0, 2L * F * u3.area(), 0));
+    TTC_CHECK(fin(1, G_COPY, c->y_cat, full, c->oa, u3, 0, 6, 2L * F * u3.area(), F));     // crop(concat, 6)
     // out (VALID)
-    TTC_CHECK(block_conv(7, {c->oa, 2L * F * g.u3 * g.u3, {0, 0}, 2 * F}, none, g.u3, g.u3, 0, c->y_out, "out_conv"));
+    TTC_CHECK(block_conv(7, {c->oa, 2L * F * u3.area(), {0, 0}, 2 * F}, none, u3, 0, c->y_out, "out_conv"));
     {
         KTimer kt(c, "head", s);
-        const int Po = g.o * g.o;
+        const int Po = (int)o.area();
         hipLaunchKernelGGL(k_head, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
                            prm(7), sm + c->small_off["head/"], d_out, F, Po);
         TTC_HIP(c, hipGetLastError());
@@ -523,11 +537,12 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
     const int F = c->cfg.base_filters;
     KTimer kt(c, "taps", s);
     if (d_early) {
-        const long total = (long)n * g.W * g.W * 64;
-        hipLaunchKernelGGL(k_tap_early, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru_out, g.W, n, d_early);
+        const long total = (long)n * g.y.n * g.x.n * 64;
+        hipLaunchKernelGGL(k_tap_early, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru_out, g.y.n, g.x.n, n,
+                           d_early);
     }
     if (d_late) {
-        const int Po = g.o * g.o;
+        const int Po = g.y.o * g.x.o;
         const float* gn7 = c->gn + (size_t)7 * c->cfg.max_windows * 2 * 32;
         hipLaunchKernelGGL(k_tap_late, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
                            c->d_small + c->small_off["out/"], d_late, F, Po);

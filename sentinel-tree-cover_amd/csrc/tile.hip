@@ -598,6 +598,7 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     if (T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "process_subtiles: T must be in [1, 32]");
     const int W = c->cfg.win_in, L = c->cfg.length;
     if (size != W - 14) return c->fail(TTC_ERR_ARG, "process_subtiles: size must equal win_in - 14");
+    if (c->cfg.win_rows != 0 && c->cfg.win_rows != W) return c->fail(TTC_ERR_ARG, "process_subtiles: needs square windows (win_rows = 0)");
     if (L != 4 && L != 12) return c->fail(TTC_ERR_ARG, "process_subtiles: length must be 4 or 12");
     WinTable wt{};
     if (!build_windows(X, Y, size, wt)) return c->fail(TTC_ERR_ARG, "process_subtiles: tile too small for a 6x6 window grid");

@@ -41,3 +41,71 @@ def e2e_inputs(fx):
     for (a, b, c, d) in fx["interp_boxes"]:
         interp[:, a:b, c:d] = 1.0
     return s2, dates, interp, s1, dem
+
+
+def synth_border_strip(seed, X, W, offset=0.06, water=True):
+    """Synthetic inputs of the border re-prediction (resegment_tiles_wide.py:360): a 12-step strip whose two halves
+    (tile | neighbour) differ by a radiometric offset, with a water body and a few NaNs.
+    -> s2 [12, X, W, 14], dates [T], interp [T, X, W], s1 [12, X, W, 2], dem [X, W], left_all / right_all [X, W//2 - 7],
+       min_clear [X, W]"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(X), np.arange(W), indexing="ij")
+    base = 0.12 + 0.08 * np.sin(yy / 17.0)[..., None] * np.cos(xx / 23.0)[..., None] + 0.02 * np.arange(10)
+    s2 = np.empty((12, X, W, 14), np.float32)
+    for t in range(12):
+        s2[t, ..., :10] = base * (1 + 0.1 * np.sin(t / 12 * 2 * np.pi)) + rng.normal(0, 0.01, (X, W, 10))
+    s2[:, :, W // 2:, :10] = s2[:, :, W // 2:, :10] * 1.15 + offset
+    if water:
+        wm = (yy - X * 0.3) ** 2 + (xx - W * 0.7) ** 2 < (min(X, W) * 0.12) ** 2
+        s2[:, wm, 1] = 0.2
+        s2[:, wm, 3] = 0.05
+    s2[..., 10:] = rng.uniform(-0.3, 0.6, (12, X, W, 4))
+    s2[3, 5, 7, 2] = np.nan
+    T = 7
+    dates = np.sort(rng.choice(np.arange(0, 360, 5), T, replace=False))
+    interp = (rng.random((T, X, W)) < 0.1).astype(np.float32)
+    s1 = rng.uniform(0.0, 0.9, (12, X, W, 2)).astype(np.float32)
+    dem = (rng.random((X, W)) * 0.4).astype(np.float32)
+    half = W // 2 - 7
+    left_all = np.clip(40 + 30 * np.sin(yy[:, :half] / 9.0) + rng.normal(0, 5, (X, half)), 0, 100).astype(np.float32)
+    right_all = np.clip(left_all[:, ::-1] + 10, 0, 100).astype(np.float32)
+    left_all[2:5, 3:9] = np.nan
+    min_clear = np.sum(interp != 1, axis=0)
+    return s2, dates, interp, s1, dem, left_all, right_all, min_clear
+
+
+def synth_reseg_windows(seed, shape, size, size_y, with_updown=False):
+    """Synthetic window predictions of a tile folder for recreate_resegmented_tifs (resegment_tiles_wide.py:1240):
+    a list of (kind, x_tile, y_tile, prediction).  shape = (Y, X) as the reference passes s2.shape[1:-1]."""
+    rng = np.random.default_rng(seed)
+    Y, X = shape
+    wins = []
+    n = 158 if min(X, Y) >= 400 else 48
+    step = n - 14
+    xs = list(range(0, X - n, step)) + [X - n]
+    ys = list(range(0, Y - n, step)) + [Y - n]
+    for xi, xt in enumerate(xs):
+        for yi, yt in enumerate(ys):
+            p = np.clip(0.5 + 0.4 * np.sin((xt + np.arange(n))[None, :] / 31.0) * np.cos((yt + np.arange(n))[:, None] / 27.0)
+                        + rng.normal(0, 0.03, (n, n)), 0, 1).astype(np.float32)
+            if (xi, yi) == (1, 1):
+                p = np.full((n, n), 255.0)
+            if (xi, yi) == (0, 2 % len(ys)):
+                p[4:9, 6:20] = 255.0
+            wins.append(("n", xt, yt, p))
+    gy = int(np.ceil((Y - size_y) / 3))
+    fy = list(range(0, Y - size_y, gy)) + [Y - size_y]
+    for k, yt in enumerate(fy):
+        p = np.clip(rng.random((size_y, size)) * 0.8 + 0.1, 0, 1).astype(np.float32)
+        if k == 1:
+            p[3:6, :] = 255.0
+        wins.append(("r", X - size // 2, yt, p))
+    for k, yt in enumerate(fy[:-1]):
+        wins.append(("l", 0, yt, np.clip(rng.random((size_y, size)) * 0.8, 0, 1).astype(np.float32)))
+    if with_updown:
+        gx = int(np.ceil((X - size_y) / 3))
+        fx = list(range(0, X - size_y, gx)) + [X - size_y]
+        for xt in fx:
+            wins.append(("u", xt, 0, np.clip(rng.random((size, size_y)) * 0.9, 0, 1).astype(np.float32)))
+            wins.append(("d", xt, Y - size // 2, np.clip(rng.random((size, size_y)) * 0.9, 0, 1).astype(np.float32)))
+    return wins

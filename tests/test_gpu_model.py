@@ -124,6 +124,28 @@ def test_feature_taps_match_oracle():
     np.testing.assert_array_equal(p1, gp.cpu().numpy()[0])
 
 
+@pytest.mark.parametrize("H,W,L,N", [(44, 76, 2, 2), (60, 44, 1, 1), (220, 684, 4, 1)])
+def test_rectangular_windows_match_oracle(H, W, L, N):
+    """the border graph of src/resegment_tiles_wide.py:478 is fed [L+1, SIZE_Y+14, SIZE+14, 17] = 220 x 684 windows"""
+    import torch
+    from oracle import restate_model as M
+    from ttc import _lib, weights as Wt
+    w = Wt.synth_weights(5)
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-1, 1, (N, L + 1, H, W, 17)).astype(np.float32)
+    probs, early, late = M.TreeCoverNet(w, dtype=torch.float32).features(x)
+    ctx = _lib.Context(win_in=W, win_rows=H, length=L, max_windows=N)
+    ctx.load_weights(w)
+    gp, ge, gl = ctx.forward_taps(x)
+    assert tuple(gp.shape) == (N, H - 14, W - 14) and tuple(ge.shape) == (N, H, W, 64) and tuple(gl.shape) == (N, H - 14, W - 14, 64)
+    fails = []
+    for name, got, ref, tol in [("probs", gp.cpu().numpy(), probs[..., 0], PROB_TOL), ("early", ge.cpu().numpy(), early, 2e-5),
+                                ("late", gl.cpu().numpy(), late, 1e-4)]:
+        ok, m = _cmp(name, got, ref, tol); ok or fails.append(m)
+    assert not fails, "\n".join(fails)
+    np.testing.assert_array_equal(ctx.forward_windows(x).cpu().numpy(), gp.cpu().numpy())
+
+
 def test_errors_are_loud():
     from ttc import _lib, weights as Wt
     ctx = _lib.Context(win_in=44, length=1, max_windows=1)
@@ -136,5 +158,7 @@ def test_errors_are_loud():
         ctx.load_weights(w)
     with pytest.raises(RuntimeError):
         _lib.Context(win_in=46, length=1, max_windows=1)     # W % 4 != 0
+    with pytest.raises(RuntimeError, match="win_rows"):
+        _lib.Context(win_in=44, win_rows=50, length=1, max_windows=1)
     with pytest.raises(RuntimeError, match="precision"):
         _lib.Context(win_in=44, length=1, max_windows=1, precision=7)
