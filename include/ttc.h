@@ -213,6 +213,53 @@ ttc_status ttc_mosaic(ttc_ctx* ctx, const float* d_windows, int32_t n, const int
 ttc_status ttc_mosaic_features(ttc_ctx* ctx, const int16_t* d_feats, int32_t n, const int32_t* h_xy, int32_t size,
                                int32_t depth, int32_t out_rows, int32_t out_cols, int16_t* d_out, void* stream);
 
+/* ---- tile-border resegmentation ---------------------------
+ * == process_subtiles of src/resegment_tiles_wide.py:360-616 for one border strip, up to the window predictions that
+ * the reference np.save()s: NaN fix, median / quarterly medians of the 12 steps, per-window histogram alignment of
+ * the two halves (align_subtile_histograms, :284-343), 7-row reflect pad of the first / last window, 17-channel
+ * assembly + float32 normalisation (:199-200), forward with the non-square graph, seam adjustment (:518-531).
+ * The context must have win_in = SIZE+14 (strip width), win_rows = SIZE_Y+14, length 4.
+ *
+ * d_s2   [12, X, W, 14]  smoothed + super-resolved bands (10) and smoothed indices (4) of the strip
+ * d_s1   [12, X, W, 2]   d_dem [X, W]
+ * h_rows [n, 4] int32    per window: first strip row, rows taken, reflect-pad rows before / after
+ *                        (tiles_array of make_tiles_right_neighb, :267-281, with the padding rule of :463-472)
+ * h_min / h_max [17]     float32 normalisation vectors (:1664-1685)
+ * hist_align             != 0: align the halves (the reference's hist_align flag, :1140-1145)
+ * n_dates_ok             len(dates); < 2 -> every window is the 255 fill (:505-508)
+ * d_preds [n, H-14, W-14] what the reference saves per window (all-zero window -> 255 fill, :196-220)
+ * h_stats [n, 4] float32 host: max, mean of the window prediction, 1 if the seam adjustment fired, 1 if 255-filled
+ *                        (inputs of the keep / skip rule, :534-613, which stays on the host)
+ * h_applied [n, 5] int32 host, may be NULL: 1 where the alignment of frame f (4 = median frame) was kept
+ * Synchronises the stream before returning. */
+ttc_status ttc_border_subtiles(ttc_ctx* ctx, const float* d_s2, const float* d_s1, const float* d_dem, int32_t X,
+                               const int32_t* h_rows, int32_t n, const float* h_min, const float* h_max, int32_t hist_align,
+                               int32_t n_dates_ok, float* d_preds, float* h_stats, int32_t* h_applied, void* stream);
+
+/* The seam adjustment of ttc_border_subtiles on its own (resegment_tiles_wide.py:518-531), in place on
+ * d_preds [n, rows, cols]: when the means of the 4 columns either side of cols/2 differ by more than 0.15, the values
+ * > 0.05 of each half move by half the difference of the halves' means (over values > 0.05), then clip to [0, 1].
+ * h_stats [n, 4] as above.  Synchronises the stream. */
+ttc_status ttc_seam_adjust(ttc_ctx* ctx, float* d_preds, int32_t n, int32_t rows, int32_t cols, float* h_stats, void* stream);
+
+/* One saved window of a tile folder, as recreate_resegmented_tifs (resegment_tiles_wide.py:1240-1549) finds it. */
+typedef struct {
+    int32_t kind;        /* 0 `{x}/{y}.npy`, 1 `{x}/left{y}.npy`, 2 `right{x}/{y}.npy`, 3 `{x}/up{y}.npy`, 4 `{x}/down{y}.npy` */
+    int32_t x, y;        /* the x / y encoded in the path */
+    int32_t rows, cols;  /* shape of the saved array */
+    int64_t pred_off;    /* offset (floats) of the array in d_preds */
+    int64_t weight_off;  /* offset (floats) in d_weights of its weight table [sx, sy]: fspecial_gauss (kind 0, :1303-1318) or
+                          * the resized half Gaussian (:1338-1349 and siblings); sx, sy = the part kept (half for kinds 1-4) */
+} ttc_reseg_window;
+
+/* == recreate_resegmented_tifs + mosaic_subtiles (:1169-1549) with the directory walk replaced by a table.
+ * d_ramps [5, X, Y] float64: the stack-vs-stack weights `m` of mosaic_subtiles for kinds n, l, r, u, d (planes of
+ * absent kinds are not read); X = shape[1], Y = shape[0].  d_out [X, Y] float32 0..100, 255 = no data; d_sums [X, Y] may be
+ * NULL.  Plain windows that do not fit the tile are dropped by the caller (:1315). */
+ttc_status ttc_reseg_mosaic(ttc_ctx* ctx, const float* d_preds, const ttc_reseg_window* h_wins, int32_t n,
+                            const float* d_weights, const double* d_ramps, int32_t X, int32_t Y, float* d_out, float* d_sums,
+                            void* stream);
+
 /* ---- 20 m -> 10 m -------------------------------------------------------------------
  * DSen2-lite on one padded window batch: == sess.run(superresolve_logits, ...) in
  * superresolve_large_tile._worker_fn, job.py:112-118.

@@ -23,6 +23,7 @@ EXPORTS = [
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
+    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -32,6 +33,11 @@ class TTCConfig(C.Structure):
     _fields_ = [("win_in", C.c_int32), ("length", C.c_int32), ("max_windows", C.c_int32),
                 ("n_bands", C.c_int32), ("hidden", C.c_int32), ("base_filters", C.c_int32),
                 ("zoneout", C.c_float), ("precision", C.c_int32), ("win_rows", C.c_int32)]
+
+
+class TTCResegWindow(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("pred_off", C.c_int64), ("weight_off", C.c_int64)]
 
 
 class TTCTensor(C.Structure):
@@ -281,6 +287,56 @@ class Context:
                                               C.c_void_p(e.data_ptr()) if early else None,
                                               C.c_void_p(l.data_ptr()) if late else None, self._stream()), "ttc_forward_taps")
         return out, e, l
+
+    def border_subtiles(self, s2, s1, dem, rows, min_all, max_all, hist_align, n_dates_ok):
+        """resegment_tiles_wide.py:360-616 on the device (see ttc_border_subtiles).
+        s2 [12, X, W, 14], s1 [12, X, W, 2], dem [X, W]; rows [n, 4] int32 (start, rows, pad before, pad after)
+        -> (preds cuda [n, H-14, W-14], stats np [n, 4], applied np [n, 5])"""
+        t = self.torch
+        a, b, d = self._dev(s2, t.float32), self._dev(s1, t.float32), self._dev(dem, t.float32)
+        X, W = int(a.shape[1]), int(a.shape[2])
+        H = self.cfg.win_rows or self.cfg.win_in
+        assert W == self.cfg.win_in and tuple(a.shape) == (12, X, W, 14) and tuple(b.shape) == (12, X, W, 2) and tuple(d.shape) == (X, W)
+        rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 4)
+        n = rows.shape[0]
+        mn, mx = (np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(17)) for v in (min_all, max_all))
+        preds = t.empty((n, H - 14, W - 14), dtype=t.float32, device=a.device)
+        stats = np.zeros((n, 4), np.float32)
+        applied = np.zeros((n, 5), np.int32)
+        FP = C.POINTER(C.c_float)
+        self._check(self.lib.ttc_border_subtiles(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(d.data_ptr()),
+                                                 X, rows.ctypes.data_as(C.POINTER(C.c_int32)), n, mn.ctypes.data_as(FP),
+                                                 mx.ctypes.data_as(FP), int(bool(hist_align)), int(n_dates_ok),
+                                                 C.c_void_p(preds.data_ptr()), stats.ctypes.data_as(FP),
+                                                 applied.ctypes.data_as(C.POINTER(C.c_int32)), self._stream()), "ttc_border_subtiles")
+        return preds, stats, applied
+
+    def reseg_mosaic(self, preds, table, weights, ramps, X, Y, want_sums=False):
+        """ttc_reseg_mosaic: preds / weights flat float32 (numpy or cuda), table = [(kind, x, y, rows, cols, pred_off,
+        weight_off)], ramps float64 [5, X, Y] -> cuda float32 [X, Y] (and the weight sums)"""
+        t = self.torch
+        p, w = self._dev(preds, t.float32), self._dev(weights, t.float32)
+        r = self._dev(ramps, t.float64)
+        assert tuple(r.shape) == (5, X, Y)
+        arr = (TTCResegWindow * len(table))()
+        for i, row in enumerate(table):
+            arr[i] = TTCResegWindow(*[int(v) for v in row])
+        out = t.empty((X, Y), dtype=t.float32, device=p.device)
+        sums = t.empty((X, Y), dtype=t.float32, device=p.device) if want_sums else None
+        self._check(self.lib.ttc_reseg_mosaic(self._h, C.c_void_p(p.data_ptr()), arr, len(table), C.c_void_p(w.data_ptr()),
+                                              C.c_void_p(r.data_ptr()), int(X), int(Y), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(sums.data_ptr()) if want_sums else None, self._stream()), "ttc_reseg_mosaic")
+        return (out, sums) if want_sums else out
+
+    def seam_adjust(self, preds):
+        """resegment_tiles_wide.py:518-531 on [n, rows, cols] (a copy is adjusted) -> (cuda tensor, stats np [n, 4])"""
+        t = self.torch
+        a = self._dev(preds, t.float32).clone()
+        n, rows, cols = (int(v) for v in a.shape)
+        stats = np.zeros((n, 4), np.float32)
+        self._check(self.lib.ttc_seam_adjust(self._h, C.c_void_p(a.data_ptr()), n, rows, cols,
+                                             stats.ctypes.data_as(C.POINTER(C.c_float)), self._stream()), "ttc_seam_adjust")
+        return a, stats
 
     def float_to_int16(self, x, precision=1000):
         """job.py:174-180 on the device -> cuda int16"""

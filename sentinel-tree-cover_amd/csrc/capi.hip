@@ -122,6 +122,25 @@ ttc_status ttc_mosaic_features(ttc_ctx* c, const int16_t* d_feats, int32_t n, co
     return mosaic_features(c, d_feats, n, h_xy, size, depth, out_rows, out_cols, d_out, static_cast<hipStream_t>(stream));
 }
 
+ttc_status ttc_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s1, const float* d_dem, int32_t X,
+                               const int32_t* h_rows, int32_t n, const float* h_min, const float* h_max, int32_t hist_align,
+                               int32_t n_dates_ok, float* d_preds, float* h_stats, int32_t* h_applied, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return reseg_border_subtiles(c, d_s2, d_s1, d_dem, X, h_rows, n, h_min, h_max, hist_align, n_dates_ok, d_preds, h_stats,
+                                 h_applied, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_reseg_mosaic(ttc_ctx* c, const float* d_preds, const ttc_reseg_window* h_wins, int32_t n, const float* d_weights,
+                            const double* d_ramps, int32_t X, int32_t Y, float* d_out, float* d_sums, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return reseg_mosaic(c, d_preds, h_wins, n, d_weights, d_ramps, X, Y, d_out, d_sums, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_seam_adjust(ttc_ctx* c, float* d_preds, int32_t n, int32_t rows, int32_t cols, float* h_stats, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return reseg_seam_adjust(c, d_preds, n, rows, cols, h_stats, static_cast<hipStream_t>(stream));
+}
+
 ttc_status ttc_float_to_int16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, void* stream) {
     if (!c) return TTC_ERR_ARG;
     return codec_f32_to_i16(c, d_in, n, precision, d_out, static_cast<hipStream_t>(stream));

@@ -163,6 +163,13 @@ ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n);
 ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s);
 ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStream_t s);
 ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStream_t s);
+// reseg.hip
+ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s1, const float* d_dem, int X,
+                                 const int32_t* h_rows, int n, const float* h_min, const float* h_max, int hist_align,
+                                 int n_dates_ok, float* d_preds, float* h_stats, int32_t* h_applied, hipStream_t s);
+ttc_status reseg_mosaic(ttc_ctx* c, const float* d_preds, const ttc_reseg_window* h_wins, int n, const float* d_weights,
+                        const double* d_ramps, int X, int Y, float* d_out, float* d_sums, hipStream_t s);
+ttc_status reseg_seam_adjust(ttc_ctx* c, float* d_preds, int n, int oh, int ow, float* h_stats, hipStream_t s);
 // dsen2.hip
 ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n);
 

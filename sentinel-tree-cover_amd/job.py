@@ -57,12 +57,13 @@ class TTCSession:
     """
 
     def __init__(self, weights=None, win_in=SIZE + 14, length=LEN, max_windows=36, device=0, zoneout=0.75,
-                 dsen2_weights="package", precision="fp32"):
+                 dsen2_weights="package", precision="fp32", win_rows=0):
         """precision: "fp32" = exact fp32 MFMA chains (default); "bf16x3" = split-bf16 MFMA (3 products per
         term, fp32 accumulate; ~2^-17 operand error, max |dprob| ~5e-5 vs fp32, 3-5x faster convolutions)."""
         prec = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}[precision]
+        # win_rows: rows of a non-square window (the 220 x 684 border graph of resegment_tiles_wide.py); 0 = square
         self.ctx = _lib.Context(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout,
-                                precision=prec)
+                                precision=prec, win_rows=win_rows)
         self.win_in, self.length = win_in, length
         if weights is not None:
             self.ctx.load_weights(_weights.validate(dict(weights)))

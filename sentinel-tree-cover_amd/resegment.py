@@ -1,0 +1,271 @@
+"""Host-side mirror of the tile-border resegmentation (src/resegment_tiles_wide.py): same function names and argument
+meaning as the reference, arrays in / arrays out (S3, hickle and GeoTIFF IO stay with the caller), arithmetic in
+libttc_hip.so on an MI355X.  There is no CPU fallback.
+
+  align_dates, split_fn, split_to_border, make_tiles_right_neighb   <->  :238-257, :84-115, :267-281 (host bookkeeping)
+  check_if_artifact(tile, neighb)                                   <->  :675-710 (host decision on two 618-pixel columns)
+  process_subtiles(...)                                             <->  :360-616, returns {path: window} instead of np.save
+  recreate_resegmented_tifs(windows, shape, sess)                   <->  :1240-1549 incl. mosaic_subtiles (:1169-1237); takes the
+                                                                         {path: window} dict instead of a folder
+  border_session(weights)                                           ==   the 684 x 220 graph import, :1644-1656
+
+The keep / skip rule of a re-predicted window (:534-613) is evaluated here from four scalars the device returns.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import job
+
+SIZE = 670        # resegment_tiles_wide.py:1598
+SIZE_Y = 206      # :1599
+LEN = 4           # :41
+
+
+def border_session(weights, size=SIZE, size_y=SIZE_Y, device=0, precision="fp32", max_windows=4, dsen2_weights="package"):
+    """A session for the non-square border graph ([L+1, size_y+14, size+14, 17] windows)."""
+    return job.TTCSession(weights, win_in=size + 14, win_rows=size_y + 14, length=LEN, max_windows=max_windows, device=device,
+                          precision=precision, dsen2_weights=dsen2_weights)
+
+
+def normalisation_vectors():
+    """:1664-1685 -- float32 copies of the job's min / max (the 11th maximum differs from job.py:1839)."""
+    mx = list(job.max_all)
+    mx[10] = 0.509269855802243
+    return np.asarray(job.min_all, dtype=np.float32), np.asarray(mx, dtype=np.float32)
+
+
+def align_dates(tile_date, neighb_date):
+    """:238-257 -> (indices to drop from the tile, from the neighbour, images left)"""
+    a, b = np.asarray(tile_date), np.asarray(neighb_date)
+
+    def drop(own, other):
+        far = [i for i, d in enumerate(own) if np.min(np.abs(d - other)) > 1]
+        repeated = np.flatnonzero(np.diff(own, prepend=0) == 0)
+        return far + list(repeated)
+    rm_a, rm_b = drop(a, b), drop(b, a)
+    return rm_a, rm_b, np.minimum(len(a) - len(rm_a), len(b) - len(rm_b))
+
+
+def split_fn(item, form, size=SIZE):
+    """:84-93 -- columns (axis 2) of the border strip this tile contributes, and where they start in the tile"""
+    keep = size // 2 + 7
+    if form == 'tile':
+        first = item.shape[2] - keep
+        return item[:, :, first:], first + 7
+    if form == 'neighbor':
+        return item[:, :, :keep], None
+    return item, None
+
+
+def split_to_border(s2, interp, s1, dem, fname, edge="right", size=SIZE):
+    """:105-115"""
+    if edge != "right":
+        raise ValueError("only the right-hand border is built (as in the reference)")
+    s1, _ = split_fn(s1, fname, size)
+    interp, _ = split_fn(interp, fname, size)
+    s2, _ = split_fn(s2, fname, size)
+    dem, tiles_x = split_fn(dem[np.newaxis], fname, size)
+    return s2, interp, s1, dem.squeeze(), tiles_x
+
+
+def make_tiles_right_neighb(tiles_folder_x, tiles_folder_y, size=SIZE, size_y=SIZE_Y):
+    """:267-281 -> (tiles_array [n, 4] = x0, y0, width, height in the strip; tiles_folder [n, 4] = output names)"""
+    ys = np.unique(np.asarray(tiles_folder_y))
+    n = len(ys)
+    folder = np.empty((n, 4), dtype=np.int64)
+    folder[:, 0], folder[:, 1], folder[:, 2:] = int(tiles_folder_x), ys, size + 7
+    arr = folder.copy()
+    arr[1:, 1] -= 7
+    arr[:, 0], arr[:, 2], arr[:, 3] = 0, size + 14, size_y + 7
+    arr[1:-1, 3] += 7
+    return arr, folder
+
+
+def border_windows(n_rows, tiles_folder_x, size=SIZE, size_y=SIZE_Y):
+    """:1135-1138 -- the four windows of a strip with n_rows rows"""
+    gap = int(np.ceil((n_rows - size_y) / 3))
+    ys = np.hstack([np.arange(0, n_rows - size_y, gap), np.array(n_rows - size_y)])
+    return make_tiles_right_neighb(tiles_folder_x, ys, size, size_y)
+
+
+def check_if_artifact(tile, neighb):
+    """:675-710 -- 1 when the existing rasters (0-100, NaN = no data) show a seam between `tile`'s last column and
+    `neighb`'s first"""
+    tile, neighb = np.asarray(tile, dtype=np.float32), np.asarray(neighb, dtype=np.float32)
+    with np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            gap = abs(np.nanmean(neighb[:, :3]) - np.nanmean(tile[:, -3:]))
+
+            def decimate(col):
+                pad = (10 - col.shape[0] % 10) // 2
+                col = np.pad(col, pad, constant_values=np.nan)
+                return np.nanmean(col.reshape(-1, 10), axis=1)
+            step = np.abs(decimate(neighb[:, 0]) - decimate(tile[:, -1]))
+            frac = lambda v, thr: np.nanmean(v > thr)          # noqa: E731
+            wide = frac(step, 12.5) > 0.5
+            local = frac(step, 20) > 0.3 or frac(step[:15], 17.5) > 0.5 or frac(step[-15:], 17.5) > 0.5
+    return int(bool(gap > 6 or (wide and gap > 1) or (local and gap > 1)))
+
+
+def _keep_window(stats, left_all, right_all, start_y, size_y):
+    """:534-613 from the device scalars (max, mean of the window prediction)"""
+    if not stats[0] < 255:
+        return True
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        ls = np.nanmean(left_all[start_y:start_y + size_y, :100])
+        rs = np.nanmean(right_all[start_y:start_y + size_y, -100:])
+    lo, hi = np.minimum(ls, rs), np.maximum(ls, rs)
+    src = 100 * stats[1]
+    return bool(src <= lo - 15 or src >= hi + 15 or (lo - 15 <= src <= hi + 15) or (np.isnan(lo) and np.isnan(hi)))
+
+
+def process_subtiles(x, y, s2=None, dates=None, interp=None, s1=None, dem=None, sess=None, gap_sess=None, tiles_folder=None,
+                     tiles_array=None, right_all=None, left_all=None, hist_align=True, min_clear_images_per_date=None,
+                     size=SIZE, size_y=SIZE_Y, return_device=False):
+    """:360-616.  s2 [12, X, size+14, 14], s1 [12, X, size+14, 2], dem [X, size+14] (numpy or cuda tensors), `sess` a
+    border_session.  Returns {"right{fy}/{fx}.npy": window, "left{fx}.npy": window} for the windows the reference would
+    save under {x}/{y}/processed/ and {x+1}/{y}/processed/0/ -- float32 [size_y, size], or the 255 fill."""
+    ta, tf = np.asarray(tiles_array), np.asarray(tiles_folder)
+    rows = np.zeros((len(ta), 4), np.int32)
+    for t, (x0, y0, w, h) in enumerate(ta):
+        if int(x0) != 0 or int(w) != size + 14:
+            raise ValueError("border windows span the whole strip width")
+        short = int(h) == size_y + 7
+        rows[t] = [y0, h, 7 if (short and y0 == 0) else 0, 7 if (short and y0 != 0) else 0]
+    mn, mx = normalisation_vectors()
+    preds, stats, applied = sess.ctx.border_subtiles(s2, s1, dem, rows, mn, mx, hist_align, len(dates))
+    out = {}
+    host = None if return_device else preds.cpu().numpy()
+    for t in range(len(ta)):
+        if not _keep_window(stats[t], np.asarray(left_all), np.asarray(right_all), int(ta[t][1]), size_y):
+            continue
+        fx, fy = int(tf[t][1]), int(tf[t][0])
+        win = preds[t] if return_device else host[t]
+        out[f"right{fy}/{fx}.npy"] = win
+        out[f"left{fx}.npy"] = win
+    return out
+
+
+# ---- border-aware mosaic ------------------------------------------------------------------------------------------------
+_KINDS = {"n": 0, "l": 1, "r": 2, "u": 3, "d": 4}
+
+
+def _resize(img, shape):
+    """What the reference asks of skimage.transform.resize(img, shape, order=1): bilinear, pixel-centre aligned, edge
+    samples mirrored (skimage >= 0.19 hands this to scipy.ndimage.zoom(grid_mode=True, mode='mirror')).  Host-side table
+    preparation only -- the tables are uploaded once per tile shape."""
+    from scipy import ndimage
+    img = np.asarray(img, dtype=np.float64)
+    return ndimage.zoom(img, [o / i for o, i in zip(shape, img.shape)], order=1, mode="mirror", grid_mode=True)
+
+
+def _gauss(n, sigma):
+    ax = np.arange(-n // 2 + 1, n // 2 + 1, dtype=np.float64)          # job.py:1499
+    return np.exp(-(ax[:, None] ** 2 + ax[None, :] ** 2) / (2.0 * sigma ** 2))
+
+
+def _sigma(extent, border):
+    """:1303-1313 / :1338-1347 -- Gaussian width by window extent"""
+    table = {208: 44, 216: 44, 348: 85, 412: 95}
+    if extent in table:
+        return table[extent]
+    if not border:
+        return 38 if extent == 168 else 28
+    return 150 if (extent == 588 or extent >= 620) else 28
+
+
+def parse_window_path(path):
+    """`{x}/{y}.npy`, `{x}/left{y}.npy`, `right{x}/{y}.npy`, `{x}/up{y}.npy`, `{x}/down{y}.npy` -> (kind, x, y)"""
+    folder, name = path.replace("\\", "/").strip("/").split("/")[-2:]
+    stem = name[:-4] if name.endswith(".npy") else name
+    if folder.startswith("right"):
+        return "r", int(folder[5:]), int(stem)
+    for tag, kind in (("left", "l"), ("down", "d"), ("up", "u")):
+        if stem.startswith(tag):
+            return kind, int(folder), int(stem[len(tag):])
+    return "n", int(folder), int(stem)
+
+
+def stack_ramps(X, Y, present, size=SIZE):
+    """The `m` maps of mosaic_subtiles (:1176-1236), float64 [5, X, Y]: how much each stack (n, l, r, u, d) counts
+    against the others.  `present`: kinds that have windows (the reference's left / right / up / down flags)."""
+    half = size // 2
+    fade = np.tile((np.arange(300) / 300.0) ** 1.33, (half, 1))
+    lin = ((np.ones((half, Y)) * (np.arange(half) / half)[:, None])) ** 1.2
+    zeros = np.zeros((X - half, Y))
+    ramps = np.zeros((5, X, Y))
+    ramps[0] = _resize(_gauss(X, X / 5.25), (X, Y))
+
+    def faded(m, first, last):
+        if first:
+            m[:, :300] *= fade
+        if last:
+            m[:, -300:] *= np.fliplr(fade)
+        return _resize(m, (half, Y))
+    if "r" in present:
+        m = faded(lin.copy(), "u" in present, "d" in present)
+        ramps[2] = _resize(np.concatenate([zeros, m], axis=0), (X, Y))
+    if "l" in present:
+        m = faded(np.flipud(lin.copy()), "u" in present, "d" in present)
+        ramps[1] = _resize(np.concatenate([m, zeros], axis=0), (X, Y))
+    if "u" in present:
+        m = faded(np.flipud(lin.copy()), "l" in present, "r" in present)
+        ramps[3] = _resize(np.concatenate([m, zeros], axis=0).T, (X, Y))
+    if "d" in present:
+        m = faded(lin.copy(), "r" in present, "l" in present)
+        ramps[4] = _resize(np.flipud(np.concatenate([zeros, m], axis=0).T), (X, Y))
+    return ramps
+
+
+def _window_weights(kind, rows, cols):
+    """the per-window blend weights (:1316-1318, :1347-1349 and siblings) for the part of the window that is used"""
+    if kind == "n":
+        ext = max(rows, cols)
+        return _gauss(ext, _sigma(ext, False))
+    if kind in "lr":
+        sx, sy = cols // 2, rows
+        ext = max(2 * sx, sy)
+        g = _gauss(ext, _sigma(ext, True))
+        return _resize(g[sx:, :] if kind == "l" else g[:sx, :], (sx, sy))
+    sx, sy = cols, rows // 2
+    ext = max(sx, 2 * sy)
+    g = _gauss(ext, _sigma(ext, True))
+    return _resize(g[:, sy:] if kind == "u" else g[:, :sy], (sx, sy))
+
+
+def recreate_resegmented_tifs(windows, shape, sess, size=SIZE, return_sums=True):
+    """:1240-1549.  `windows`: {path: array} laid out like a tile's processed/ folder (see parse_window_path); `shape` =
+    s2.shape[1:-1] of the tile, as the reference passes it.  -> (predictions float32 [shape[1], shape[0]] 0-100 with 255 =
+    no data, sums) as numpy arrays."""
+    X, Y = int(shape[1]), int(shape[0])
+    table, chunks, wts, wt_index = [], [], [], {}
+    poff = woff = 0
+    present = set()
+    for path, arr in windows.items():
+        kind, xt, yt = parse_window_path(path)
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+        rows, cols = a.shape
+        if kind == "n" and not ((xt + cols - 1) < X and (yt + rows - 1) < Y):
+            continue                                             # :1315 -- does not fit, skipped
+        present.add(kind)
+        key = (kind, rows, cols)
+        if key not in wt_index:
+            w = np.ascontiguousarray(_window_weights(kind, rows, cols), dtype=np.float32)
+            wt_index[key] = woff
+            wts.append(w.ravel())
+            woff += w.size
+        table.append((_KINDS[kind], xt, yt, rows, cols, poff, wt_index[key]))
+        chunks.append(a.ravel())
+        poff += a.size
+    if not table:
+        raise ValueError("no windows")
+    ramps = stack_ramps(X, Y, present - {"n"}, size)
+    out = sess.ctx.reseg_mosaic(np.concatenate(chunks), table, np.concatenate(wts), ramps, X, Y, want_sums=return_sums)
+    if return_sums:
+        return out[0].cpu().numpy(), out[1].cpu().numpy()
+    return out.cpu().numpy()

@@ -65,7 +65,7 @@ def synth_border_strip(seed, X, W, offset=0.06, water=True):
     dates = np.sort(rng.choice(np.arange(0, 360, 5), T, replace=False))
     interp = (rng.random((T, X, W)) < 0.1).astype(np.float32)
     s1 = rng.uniform(0.0, 0.9, (12, X, W, 2)).astype(np.float32)
-    dem = (rng.random((X, W)) * 0.4).astype(np.float32)
+    dem = (rng.random((X, W)) * 0.6).astype(np.float32)
     half = W // 2 - 7
     left_all = np.clip(40 + 30 * np.sin(yy[:, :half] / 9.0) + rng.normal(0, 5, (X, half)), 0, 100).astype(np.float32)
     right_all = np.clip(left_all[:, ::-1] + 10, 0, 100).astype(np.float32)

@@ -1,0 +1,215 @@
+"""HIP border re-prediction (ttc_border_subtiles / ttc_seam_adjust, sentinel-tree-cover_amd/resegment.py) against the
+CPU oracle and the golden vectors captured from src/resegment_tiles_wide.py."""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests.helpers import golden, synth_border_strip
+from tests.test_oracle_reseg import subtile_inputs, hist_input, artifact_cases
+
+pytestmark = pytest.mark.gpu
+
+RSG = importlib.import_module("sentinel-tree-cover_amd.resegment")
+# normalised model inputs (values / half-range, i.e. x3-x8).  Without histogram alignment the device path is the same float32
+# arithmetic as numpy; with it, the band means / stds come from double sums here and from float32 pairwise sums in numpy
+# (~1e-7 relative on 75 k-pixel halves), which the 1 / std_ref rescale and the normalisation amplify.
+FEED_TOL = {False: 3e-6, True: 2e-5}
+_SESS = {}
+
+
+def session(size, size_y, seed=0):
+    from ttc import weights as Wt
+    key = (size, size_y, seed)
+    if key not in _SESS:
+        _SESS[key] = RSG.border_session(Wt.synth_weights(seed), size=size, size_y=size_y, dsen2_weights=None)
+    return _SESS[key]
+
+
+def oracle_model(seed=0):
+    import torch
+    from oracle import restate_model as M
+    from ttc import weights as Wt
+    net = M.TreeCoverNet(Wt.synth_weights(seed), dtype=torch.float32)
+    return lambda x: net.forward(x)[..., 0]
+
+
+def device_feeds(sess, n, H, W):
+    fr = sess.ctx.debug_fetch("frames", (n, 5, 17, H + 2, W + 2))
+    return np.transpose(fr[:, :, :, 1:-1, 1:-1], (0, 1, 3, 4, 2))
+
+
+def test_host_bookkeeping_matches_reference():
+    g = golden("reseg_small.npz")
+    for i in range(4):
+        ra, rb, left = RSG.align_dates(g[f"dates{i}_a"], g[f"dates{i}_b"])
+        assert list(ra) == list(g[f"dates{i}_rm_a"]) and list(rb) == list(g[f"dates{i}_rm_b"]) and int(left) == int(g[f"dates{i}_left"])
+    for tag in ("real", "small", "odd"):
+        n, s, sy = (int(v) for v in g[f"table_{tag}_cfg"])
+        ta, tf = RSG.border_windows(n, n - s // 2, s, sy)
+        np.testing.assert_array_equal(ta, g[f"table_{tag}_array"])
+        np.testing.assert_array_equal(tf, g[f"table_{tag}_folder"])
+    np.testing.assert_array_equal([RSG.check_if_artifact(a, b) for a, b in artifact_cases()], g["artifact_flags"])
+    a = np.arange(2 * 5 * 700, dtype=np.float32).reshape(2, 5, 700)
+    t, x0 = RSG.split_fn(a, "tile")
+    nb, _ = RSG.split_fn(a, "neighbor")
+    assert t.shape[2] == nb.shape[2] == 342 and x0 == 700 - 335 and t[0, 0, 0] == 700 - 342 and nb[0, 0, -1] == 341
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_border_subtiles_match_reference_feeds_and_oracle(tag):
+    """model feeds bit-compatible with what the reference hands to Session.run; predictions against the oracle net"""
+    from oracle import restate_reseg as O
+    g = golden("reseg_subtiles.npz")
+    k = subtile_inputs(g, tag)
+    size, size_y = k["size"], k["size_y"]
+    sess = session(size, size_y)
+    trace = {}
+    ref = O.process_border_subtiles(k["s2"].copy(), k["dates"], k["interp"], k["s1"].copy(), k["dem"], oracle_model(), k["tiles_folder"],
+                                    k["tiles_array"], k["right_all"], k["left_all"], k["hist_align"], k["min_clear"],
+                                    size=size, size_y=size_y, trace=trace)
+    out = RSG.process_subtiles(10, 20, k["s2"].copy(), k["dates"], k["interp"], k["s1"].copy(), k["dem"], sess, None, k["tiles_folder"],
+                               k["tiles_array"], k["right_all"], k["left_all"], k["hist_align"], k["min_clear"], size=size, size_y=size_y)
+    feeds = device_feeds(sess, len(ref), size_y + 14, size + 14)
+    gi = 0
+    for t in range(len(ref)):
+        if t in trace:
+            np.testing.assert_allclose(feeds[t], trace[t], rtol=0, atol=FEED_TOL[k["hist_align"]], err_msg=f"feed {t} vs oracle")
+            np.testing.assert_allclose(feeds[t][:, ::5, ::7, :], g[f"{tag}_feed{gi}"], rtol=0, atol=FEED_TOL[k["hist_align"]],
+                                       err_msg=f"feed {t} vs reference")
+            gi += 1
+    assert gi == int(g[f"{tag}_n_feeds"])
+    for t, o in enumerate(ref):
+        name = f"right{o['folder_y']}/{o['folder_x']}.npy"
+        assert (name in out) == o["saved"] == bool(g[f"{tag}_saved{t}"])
+        if o["saved"]:
+            got = out[name]
+            assert got.shape == (size_y, size)
+            np.testing.assert_array_equal(got, out[f"left{o['folder_x']}.npy"])
+            if np.max(o["preds"]) == 255:
+                assert (got == 255).all()
+            else:
+                np.testing.assert_allclose(got, o["preds"], rtol=0, atol=1.5e-4)
+
+
+@pytest.mark.parametrize("tag", ["h0", "h1", "h2"])
+def test_histogram_alignment_decisions(tag):
+    """align_subtile_histograms (:284-343) through the device path: one window covering the whole strip"""
+    from oracle import restate_reseg as O
+    g = golden("reseg_small.npz")
+    seed, X, W = (int(v) for v in g[f"{tag}_cfg"])
+    s2 = synth_border_strip(seed, X, W, offset=float(g[f"{tag}_off"]))[0]
+    s2 = np.nan_to_num(s2)
+    size, size_y = W - 14, X - 14
+    sess = session(size, size_y)
+    rows = np.array([[0, X, 0, 0]], np.int32)
+    mn, mx = np.full(17, -1e30, np.float32), np.full(17, 1e30, np.float32)      # no clipping: look at the aligned values
+    s1 = np.zeros((12, X, W, 2), np.float32)
+    dem = np.zeros((X, W), np.float32)
+    _, _, applied = sess.ctx.border_subtiles(s2, s1, dem, rows, mn, mx, True, 5)
+    np.testing.assert_array_equal(applied[0, :4].astype(bool), g[f"{tag}_changed"])
+    q = hist_input(g, tag)
+    want = O.align_subtile_histograms(q.copy(), size=size)
+    med = O.align_subtile_histograms(np.median(s2, axis=0)[np.newaxis].copy(), size=size)
+    feeds = device_feeds(sess, 1, X, W)[0]
+    # with lo = -1e30, hi = 1e30 the normalisation is (v - 0) / 1e30
+    got = feeds[..., list(range(10)) + [13, 14, 15, 16]].astype(np.float64) * 1e30
+    np.testing.assert_allclose(got[:4], want, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got[4], med[0], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got[:4, ::3, ::4, :], g[f"{tag}_out"], rtol=2e-5, atol=2e-6)
+
+
+def test_seam_adjust_matches_oracle():
+    from oracle import restate_reseg as O
+    rng = np.random.default_rng(3)
+    size, size_y = 90, 46
+    sess = session(90, 134)
+    cases = []
+    for off in (0.0, 0.1, 0.3, -0.4):
+        p = np.clip(rng.random((size_y, size)) * 0.5 + 0.1, 0, 1).astype(np.float32)
+        p[:, size // 2:] = np.clip(p[:, size // 2:] + off, 0, 1)
+        p[3:9, 2:30] = 0.01
+        cases.append(p)
+    got, stats = sess.ctx.seam_adjust(np.stack(cases))
+    fired = []
+    for i, p in enumerate(cases):
+        want = O.seam_adjust(p.copy(), size=size)
+        fired.append(not np.array_equal(want, p))
+        np.testing.assert_allclose(got[i].cpu().numpy(), want, rtol=0, atol=2e-7)
+        assert bool(stats[i, 2]) == fired[-1]
+        assert abs(stats[i, 0] - want.max()) < 1e-7 and abs(stats[i, 1] - want.mean()) < 1e-6
+    assert fired == [False, False, True, True]
+
+
+def test_full_size_border_windows():
+    """684 x 220 windows on a 618-row strip (SIZE = 670, SIZE_Y = 206) against the oracle"""
+    from oracle import restate_reseg as O
+    size, size_y, X = 670, 206, 618
+    s2, dates, interp, s1, dem, left_all, right_all, min_clear = synth_border_strip(71, X, size + 14, offset=0.05)
+    ta, tf = O.border_window_table(X, size, size_y, tiles_folder_x=X - size // 2)
+    sess = session(size, size_y)
+    trace = {}
+    ref = O.process_border_subtiles(s2.copy(), dates, interp, s1.copy(), dem, oracle_model(), tf, ta, right_all, left_all, True, min_clear,
+                                    size=size, size_y=size_y, trace=trace)
+    out = RSG.process_subtiles(10, 20, s2.copy(), dates, interp, s1.copy(), dem, sess, None, tf, ta, right_all, left_all, True, min_clear)
+    feeds = device_feeds(sess, 4, size_y + 14, size + 14)
+    for t in range(4):
+        np.testing.assert_allclose(feeds[t], trace[t], rtol=0, atol=FEED_TOL[True])
+        # float32 oracle: on 220 x 684 windows it is itself ~5e-5 from the float64 one (tests/test_gpu_model.py), plus the feeds
+        np.testing.assert_allclose(out[f"right{ref[t]['folder_y']}/{ref[t]['folder_x']}.npy"], ref[t]["preds"], rtol=0, atol=4e-4)
+
+
+def test_border_errors_are_loud():
+    sess = session(90, 134)
+    s2 = np.zeros((12, 200, 104, 14), np.float32); s1 = np.zeros((12, 200, 104, 2), np.float32); dem = np.zeros((200, 104), np.float32)
+    mn, mx = RSG.normalisation_vectors()
+    with pytest.raises(RuntimeError, match="window rows"):
+        sess.ctx.border_subtiles(s2, s1, dem, np.array([[0, 140, 0, 0]], np.int32), mn, mx, False, 5)     # 140 != 148
+    with pytest.raises(RuntimeError, match="window rows"):
+        sess.ctx.border_subtiles(s2, s1, dem, np.array([[100, 148, 0, 0]], np.int32), mn, mx, False, 5)   # runs off the strip
+    with pytest.raises(RuntimeError, match="window count"):
+        sess.ctx.border_subtiles(s2, s1, dem, np.tile(np.array([[0, 148, 0, 0]], np.int32), (9, 1)), mn, mx, False, 5)
+    preds, stats, _ = sess.ctx.border_subtiles(s2, s1, dem, np.array([[0, 148, 0, 0]], np.int32), mn, mx, False, 5)
+    assert (preds.cpu().numpy() == 255).all() and stats[0, 3] == 1          # all-zero window -> 255 fill
+    nz = s2.copy(); nz[...] = 0.1
+    preds, stats, _ = sess.ctx.border_subtiles(nz, s1, dem, np.array([[0, 148, 0, 0]], np.int32), mn, mx, False, 1)
+    assert (preds.cpu().numpy() == 255).all()                               # fewer than 2 dates -> 255 fill
+
+
+def _paths(wins):
+    fmt = {"n": "{x}/{y}.npy", "l": "{x}/left{y}.npy", "r": "right{x}/{y}.npy", "u": "{x}/up{y}.npy", "d": "{x}/down{y}.npy"}
+    return {fmt[k].format(x=x, y=y): p for k, x, y, p in wins}
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_border_mosaic_matches_reference(tag):
+    """recreate_resegmented_tifs + mosaic_subtiles (:1169-1549) on the device against the reference's output"""
+    from oracle import restate_reseg as O
+    from tests.test_oracle_reseg import ordered_windows
+    g = golden("reseg_mosaic.npz")
+    wins, shape, size = ordered_windows(g, tag)
+    sess = session(90, 134)
+    preds, sums = RSG.recreate_resegmented_tifs(_paths(wins), shape, sess, size=size)
+    want, want_sums = O.recreate_resegmented([(k, x, y, p.copy()) for k, x, y, p in wins], shape, size=size)
+    assert preds.shape == (shape[1], shape[0]) and preds.dtype == np.float32
+    np.testing.assert_array_equal(preds == 255, want == 255)
+    np.testing.assert_allclose(preds, want, rtol=0, atol=2e-4)
+    ok = want != 255
+    np.testing.assert_allclose(sums[ok], want_sums[ok], rtol=1e-5, atol=1e-7)
+    if f"{tag}_preds" in g:
+        np.testing.assert_allclose(preds, g[f"{tag}_preds"], rtol=0, atol=2e-4)
+    else:
+        np.testing.assert_array_equal(np.packbits(preds == 255), g[f"{tag}_nodata"])
+        np.testing.assert_allclose(preds[::2, ::2], g[f"{tag}_preds_sub"], rtol=0, atol=2e-4)
+    assert 0.001 < (preds == 255).mean() < 0.2
+
+
+def test_border_mosaic_errors_are_loud():
+    sess = session(90, 134)
+    p = np.full((48, 48), 0.5, np.float32)
+    with pytest.raises(RuntimeError, match="outside the tile"):
+        RSG.recreate_resegmented_tifs({"0/0.npy": p, "right190/0.npy": np.zeros((46, 90), np.float32)}, (100, 200), sess, size=90)
+    with pytest.raises(RuntimeError, match="even width"):
+        RSG.recreate_resegmented_tifs({"0/0.npy": p, "right100/0.npy": np.zeros((46, 91), np.float32)}, (100, 200), sess, size=90)
+    out, _ = RSG.recreate_resegmented_tifs({"0/0.npy": p, "60/0.npy": np.full((48, 48), 255.0, np.float32)}, (100, 200), sess, size=90)
+    assert (out[:48, :48] == 50).all() and (out[48:] == 255).all()

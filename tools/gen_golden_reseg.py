@@ -30,8 +30,8 @@ def set_geometry(RS, size, size_y):
     RS.rng = (RS.max_all - RS.min_all).astype(np.float32)
 
 
-# resegment_tiles_wide.py:1664-1678 (data constants of the reference's normalisation)
-from oracle.restate_numpy import MIN_ALL, MAX_ALL  # noqa: E402
+# resegment_tiles_wide.py:1664-1678 (data constants of the reference's normalisation; they live under `__main__` there)
+from oracle.restate_reseg import MIN_ALL32 as MIN_ALL, MAX_ALL32 as MAX_ALL  # noqa: E402
 
 
 def write_folder(folder, wins):
