@@ -236,6 +236,18 @@ ttc_status ttc_border_subtiles(ttc_ctx* ctx, const float* d_s2, const float* d_s
                                const int32_t* h_rows, int32_t n, const float* h_min, const float* h_max, int32_t hist_align,
                                int32_t n_dates_ok, float* d_preds, float* h_stats, int32_t* h_applied, void* stream);
 
+/* regularize_and_smooth (resegment_tiles_wide.py:772-790) + make_and_smooth_indices (job.py:1009-1028) for a border strip:
+ * d_s2 [T, X, Y, 10] (gap-filled, deal_w_missing_px applied) -> d_out [12, X, Y, 14] = 12 monthly steps of the 10 bands and
+ * of evi / bi / msavi2 / grndvi computed per date; h_wmat [12, T] as for ttc_process_subtiles. */
+ttc_status ttc_smooth_strip(ttc_ctx* ctx, const float* d_s2, int32_t T, int32_t X, int32_t Y, const float* h_wmat, float* d_out,
+                            void* stream);
+
+/* superresolve_large_tile with the window edge and pixel stride as parameters: wsize = 125 and channels = 14 reproduce
+ * resegment_tiles_wide.py:144-179 on the array above (bands 4..9 of every pixel are replaced; channels >= 10 untouched);
+ * wsize = 110, channels = 10 is ttc_superresolve_tile.  quirks as there. */
+ttc_status ttc_superresolve_windows(ttc_ctx* ctx, float* d_arr, int32_t T, int32_t X, int32_t Y, int32_t channels, int32_t wsize,
+                                    int32_t quirks, void* stream);
+
 /* The seam adjustment of ttc_border_subtiles on its own (resegment_tiles_wide.py:518-531), in place on
  * d_preds [n, rows, cols]: when the means of the 4 columns either side of cols/2 differ by more than 0.15, the values
  * > 0.05 of each half move by half the difference of the halves' means (over values > 0.05), then clip to [0, 1].

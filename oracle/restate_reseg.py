@@ -417,3 +417,129 @@ def recreate_resegmented(windows, shape, size=SIZE):
     preds[np.isnan(preds)] = 255.
     preds[isnan.squeeze() == 1.] = 255.
     return preds, sums
+
+
+# ---- strip preparation: resegment_border, :847-1161 ---------------------------------------------------------------------
+def preprocess_tile(arr, dates, interp, clm, dem, sampler=G.reference_sampler):
+    """:619-672 -> (arr, interp, dates).  `interp` is ignored, as in the reference (it is recomputed)."""
+    missing = R.id_missing_px(arr, 20)
+    if len(missing) > 0:
+        dates = np.delete(dates, missing)
+        arr = np.delete(arr, missing, 0)
+    cld, fcps = C.identify_clouds_shadows(arr, dem)
+    if clm is not None:
+        if len(missing) > 0:
+            clm = np.delete(clm, missing, 0)
+        try:
+            clm[fcps] = 0.
+            cld = np.maximum(clm, cld)
+        except Exception:           # date mismatch between the Sen2Cor mask and the stack: the reference carries on
+            pass
+    interp = G.id_areas_to_interp(cld)
+    to_remove = np.argwhere(np.mean(interp == 1, axis=(1, 2)) > 0.95)
+    if len(to_remove) > 0:
+        cld = np.delete(cld, to_remove, axis=0)
+        dates = np.delete(dates, to_remove)
+        arr = np.delete(arr, to_remove, axis=0)
+        cld, fcps = C.identify_clouds_shadows(arr, dem)
+    arr, interp2, _ = G.remove_cloud_and_shadows(arr, cld, fcps, sampler=sampler)
+    return arr, interp2, dates
+
+
+def regularize_and_smooth(arr, dates):
+    """:772-790 -- date regrid + Whittaker per band pair -> 12 monthly steps"""
+    n = arr.shape[0]
+    if n < 12:
+        arr = np.concatenate([arr, np.zeros((12 - n,) + arr.shape[1:], dtype=np.float32)], axis=0)
+    for j in range(0, 10, 2):
+        arr[:12, ..., j:j + 2] = R.whittaker_interpolate(R.regrid(arr[:n, ..., j:j + 2], dates))
+    return arr[:12]
+
+
+def make_and_smooth_indices(arr, dates):
+    """job.py:1009-1028"""
+    try:
+        ind = R.regrid(R.make_indices(arr), dates)
+    except Exception:
+        ind = np.zeros((24, arr.shape[1], arr.shape[2], 4), dtype=np.float32)
+    return R.whittaker_interpolate(ind)
+
+
+def resegment_border_arrays(tile, neighb, tile_tif, neighbor_tif, model_fn, dsen2_fn, min_dates=2, size=SIZE, size_y=SIZE_Y,
+                            sampler=G.reference_sampler, trace=None):
+    """The array flow of resegment_border (:847-1161, edge == "right") once both tiles are known to be processed and an
+    artifact was found: `tile` / `neighb` = dicts with the outputs of process_tile (s2 [T, X, Y, 10], dates, interp, s1
+    [12, X, Y, 2], dem [X, Y]) and optionally clm (Sen2Cor mask at 10 m, [T, X, Y]).  tile_tif / neighbor_tif: the existing
+    rasters (float, NaN above 100).  -> (windows of process_border_subtiles, info dict)"""
+    cp = lambda d: {k: (np.array(v, copy=True) if v is not None else None) for k, v in d.items()}        # noqa: E731
+    a, b = cp(tile), cp(neighb)
+    _, _, min_images = align_dates(a["dates"], b["dates"])
+    if min_images >= 3:
+        s2, interp, s1, dem, tiles_x = split_to_border(a["s2"], a["interp"], a["s1"], a["dem"], "tile", size)
+        s2n, interp_n, s1n, dem_n, _ = split_to_border(b["s2"], b["interp"], b["s1"], b["dem"], "neighbor", size)
+        dates, dates_n = a["dates"], b["dates"]
+        clm = split_fn(a["clm"], 'tile', size)[0] if a.get("clm") is not None else None
+        clm_n = split_fn(b["clm"], 'neighbor', size)[0] if b.get("clm") is not None else None
+        rm_t, rm_n, _ = align_dates(dates, dates_n)
+        if len(rm_t) > 0:
+            s2, dates = np.delete(s2, rm_t, 0), np.delete(dates, rm_t)
+            if clm is not None and clm.shape[0] > 0:
+                clm = np.delete(clm, rm_t, 0)
+        if len(rm_n) > 0:
+            s2n, dates_n = np.delete(s2n, rm_n, 0), np.delete(dates_n, rm_n)
+            if clm_n is not None and clm_n.shape[0] > 0:
+                clm_n = np.delete(clm_n, rm_n, 0)
+        if clm is not None and clm_n is not None:
+            try:
+                clm = np.float32(np.concatenate([clm_n, clm], axis=2))      # neighbour first, as coded (:971)
+                clm[np.isnan(clm)] = 0.
+            except Exception:
+                clm = None
+        else:
+            clm = None
+        s2 = np.concatenate([s2, s2n], axis=2).astype(np.float32)
+        dem = np.concatenate([dem, dem_n], axis=1)
+        s2, interp, dates = preprocess_tile(s2, dates, None, clm, dem, sampler)
+        s2, dates, interp = R.deal_w_missing_px(s2, dates, interp)
+        dates_n = dates
+        indices = make_and_smooth_indices(s2, dates)
+        s2 = regularize_and_smooth(s2, dates)
+        min_clear = np.sum(interp != 1, axis=0)
+    else:
+        s2, interp, dates = preprocess_tile(a["s2"], a["dates"], a["interp"], a.get("clm"), a["dem"], sampler)
+        s2, interp, s1, dem, tiles_x = split_to_border(s2, interp, a["s1"], a["dem"], "tile", size)
+        s2n, interp_n, dates_n = preprocess_tile(b["s2"], b["dates"], b["interp"], b.get("clm"), b["dem"], sampler)
+        s2n, interp_n, s1n, dem_n, _ = split_to_border(s2n, interp_n, b["s1"], b["dem"], "neighbor", size)
+        rm_t, rm_n, min_images = align_dates(dates, dates_n)
+        half = (size + 14) // 2
+        min_clear = np.concatenate([np.sum(interp[..., -half:] != 1, axis=0), np.sum(interp_n[..., :half] != 1, axis=0)], axis=1)
+        if min_images >= min_dates:
+            if len(rm_t) > 0:
+                s2, interp, dates = np.delete(s2, rm_t, 0), np.delete(interp, rm_t, 0), np.delete(dates, rm_t)
+            if len(rm_n) > 0:
+                s2n, interp_n, dates_n = np.delete(s2n, rm_n, 0), np.delete(interp_n, rm_n, 0), np.delete(dates_n, rm_n)
+        s2, dates, interp = R.deal_w_missing_px(s2, dates, interp)
+        ind = make_and_smooth_indices(s2, dates)
+        s2 = regularize_and_smooth(s2, dates)
+        s2n, dates_n, interp_n = R.deal_w_missing_px(s2n, dates_n, interp_n)
+        ind_n = make_and_smooth_indices(s2n, dates_n)
+        s2n = regularize_and_smooth(s2n, dates_n)
+        s2 = np.concatenate([s2, s2n], axis=2).astype(np.float32)
+        indices = np.concatenate([ind, ind_n], axis=2)
+        dem = np.concatenate([dem, dem_n], axis=1)
+        interp = np.concatenate([interp[:interp_n.shape[0]], interp_n[:interp.shape[0]]], axis=2)
+    s1 = np.concatenate([s1, s1n], axis=2)
+    s2 = R.superresolve_large_tile(s2, dsen2_fn, wsize=125)                   # :144-179
+    out = np.empty(s2.shape[:3] + (14,), dtype=np.float32)
+    out[..., :10] = s2
+    out[..., 10:] = indices
+    ta, tf = border_window_table(s1.shape[1], size, size_y, tiles_folder_x=tiles_x)
+    hist_align = not np.array_equal(np.array(dates), np.array(dates_n))
+    right_all = neighbor_tif[:, :size // 2]
+    left_all = tile_tif[:, -(size // 2):]
+    if trace is not None:
+        trace.update(strip=out.copy(), dates=np.array(dates), dates_n=np.array(dates_n), hist_align=hist_align, interp=interp.copy(),
+                     min_clear=min_clear.copy(), s1=s1.copy(), dem=dem.copy())
+    wins = process_border_subtiles(out, dates, interp, s1, dem, model_fn, tf, ta, right_all, left_all, hist_align, min_clear,
+                                   size=size, size_y=size_y)
+    return wins, dict(min_images=int(min_images), hist_align=hist_align, tiles_array=ta, tiles_folder=tf)

@@ -23,7 +23,7 @@ EXPORTS = [
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
-    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic",
+    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -327,6 +327,26 @@ class Context:
                                               C.c_void_p(r.data_ptr()), int(X), int(Y), C.c_void_p(out.data_ptr()),
                                               C.c_void_p(sums.data_ptr()) if want_sums else None, self._stream()), "ttc_reseg_mosaic")
         return (out, sums) if want_sums else out
+
+    def smooth_strip(self, s2, wmat):
+        """s2 [T, X, Y, 10] + operator [12, T] -> cuda [12, X, Y, 14] (bands | indices), see ttc_smooth_strip"""
+        t = self.torch
+        a = self._dev(s2, t.float32)
+        T, X, Y = (int(v) for v in a.shape[:3])
+        w = np.ascontiguousarray(wmat, dtype=np.float32)
+        assert w.shape == (12, T) and a.shape[3] == 10
+        out = t.empty((12, X, Y, 14), dtype=t.float32, device=a.device)
+        self._check(self.lib.ttc_smooth_strip(self._h, C.c_void_p(a.data_ptr()), T, X, Y, w.ctypes.data_as(C.POINTER(C.c_float)),
+                                              C.c_void_p(out.data_ptr()), self._stream()), "ttc_smooth_strip")
+        return out
+
+    def superresolve_windows(self, arr, wsize=125, quirks=1):
+        """in place on a cuda tensor [T, X, Y, C >= 10]: DSen2 over wsize windows (resegment_tiles_wide.py:144-179)"""
+        T, X, Y, Cc = (int(v) for v in arr.shape)
+        assert arr.is_cuda and arr.is_contiguous() and arr.dtype == self.torch.float32
+        self._check(self.lib.ttc_superresolve_windows(self._h, C.c_void_p(arr.data_ptr()), T, X, Y, Cc, int(wsize), int(quirks),
+                                                      self._stream()), "ttc_superresolve_windows")
+        return arr
 
     def seam_adjust(self, preds):
         """resegment_tiles_wide.py:518-531 on [n, rows, cols] (a copy is adjusted) -> (cuda tensor, stats np [n, 4])"""

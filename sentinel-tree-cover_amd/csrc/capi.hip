@@ -12,7 +12,8 @@ ttc_status mosaic_run(ttc_ctx* c, const float* d_windows, int n, const int32_t* 
                       uint8_t* d_u8, float* d_f32, hipStream_t s);
 ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int n, int H, int W, float* d_out,
                          hipStream_t s);
-ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, hipStream_t s);
+ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, int ws, int cs, hipStream_t s);
+ttc_status tile_smooth_strip(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat, float* d_out, hipStream_t s);
 ttc_status upsample_20m(ttc_ctx* c, const float* d10, const float* d20, int T, int h, int w, float* d_out, hipStream_t s);
 
 ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y, int closing, int clip, float* d_w, hipStream_t s);
@@ -130,6 +131,18 @@ ttc_status ttc_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s1,
                                  h_applied, static_cast<hipStream_t>(stream));
 }
 
+ttc_status ttc_superresolve_windows(ttc_ctx* c, float* d_arr, int32_t T, int32_t X, int32_t Y, int32_t channels, int32_t wsize,
+                                    int32_t quirks, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return dsen2_tile(c, d_arr, T, X, Y, quirks, wsize, channels, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_smooth_strip(ttc_ctx* c, const float* d_s2, int32_t T, int32_t X, int32_t Y, const float* h_wmat, float* d_out,
+                            void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return tile_smooth_strip(c, d_s2, T, X, Y, h_wmat, d_out, static_cast<hipStream_t>(stream));
+}
+
 ttc_status ttc_reseg_mosaic(ttc_ctx* c, const float* d_preds, const ttc_reseg_window* h_wins, int32_t n, const float* d_weights,
                             const double* d_ramps, int32_t X, int32_t Y, float* d_out, float* d_sums, void* stream) {
     if (!c) return TTC_ERR_ARG;
@@ -203,7 +216,7 @@ ttc_status ttc_dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bilin
 ttc_status ttc_superresolve_tile(ttc_ctx* c, float* d_s2, int32_t T, int32_t X, int32_t Y, int32_t quirks,
                                  void* stream) {
     if (!c) return TTC_ERR_ARG;
-    return dsen2_tile(c, d_s2, T, X, Y, quirks, static_cast<hipStream_t>(stream));
+    return dsen2_tile(c, d_s2, T, X, Y, quirks, 110, 10, static_cast<hipStream_t>(stream));
 }
 
 ttc_status ttc_upsample_20m(ttc_ctx* c, const float* d_s2_10, const float* d_s2_20, int32_t T, int32_t h, int32_t w,

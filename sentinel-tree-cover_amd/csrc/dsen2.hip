@@ -50,14 +50,14 @@ struct SRWin { int n; int x0[40], y0[40]; };
 
 // tile [T][X][Y][10] -> padded planar window batch [(t*nw + w)][10][ws+10][ws+10]: window reflect-padded by 4
 // (job.py:112) then by the first conv's 1 (MirrorPad)
-__global__ void k_sr_gather(const float* __restrict__ tile, int X, int Y, SRWin sw, int ws, float* __restrict__ out) {
+__global__ void k_sr_gather(const float* __restrict__ tile, int X, int Y, SRWin sw, int ws, int cs, float* __restrict__ out) {
     const int E = ws + 8, Ep = E + 2;
     const int w = blockIdx.y, t = blockIdx.z;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= Ep * Ep) return;
     const int qy = reflect_idx(p / Ep - 1, E), qx = reflect_idx(p % Ep - 1, E);
     const int lx = reflect_idx(qy - 4, ws), ly = reflect_idx(qx - 4, ws);
-    const float* src = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * 10;
+    const float* src = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * cs;      // cs: floats per pixel (>= 10)
     float* dst = out + ((long)(t * sw.n + w) * 10) * Ep * Ep + p;
     for (int c = 0; c < 10; ++c) dst[(long)c * Ep * Ep] = src[c];
 }
@@ -74,7 +74,7 @@ __global__ void k_sr_bil(const float* __restrict__ xin, int E, float* __restrict
 }
 
 // planar result [(t*nw + w)][6][E][E] -> centre crop [4:-4] into channels 4..9 of the tile (job.py:118-119)
-__global__ void k_sr_scatter(const float* __restrict__ res, int X, int Y, SRWin sw, int ws, int w_lo, int w_hi,
+__global__ void k_sr_scatter(const float* __restrict__ res, int X, int Y, SRWin sw, int ws, int cs, int w_lo, int w_hi,
                              float* __restrict__ tile) {
     const int E = ws + 8;
     const int w = w_lo + blockIdx.y, t = blockIdx.z;
@@ -83,7 +83,7 @@ __global__ void k_sr_scatter(const float* __restrict__ res, int X, int Y, SRWin 
     if (p >= ws * ws) return;
     const int lx = p / ws, ly = p % ws;
     const float* src = res + ((long)(t * sw.n + w) * 6) * E * E + (long)(lx + 4) * E + (ly + 4);
-    float* dst = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * 10 + 4;
+    float* dst = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * cs + 4;
     for (int c = 0; c < 6; ++c) dst[c] = src[(long)c * E * E];
 }
 
@@ -235,10 +235,12 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
     return TTC_OK;
 }
 
-ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, hipStream_t s) {
+// ws: window edge (110 in job.py:121, 125 in resegment_tiles_wide.py:157); cs: floats per pixel of d_s2 (the border strip
+// keeps its 4 smoothed indices behind the 10 bands)
+ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, int ws, int cs, hipStream_t s) {
     if (!c->have_dsen2) return c->fail(TTC_ERR_STATE, "ttc_load_dsen2_weights has not been called");
-    const int ws = 110;
-    if (!d_s2 || T < 1 || X < ws || Y < ws) return c->fail(TTC_ERR_ARG, "superresolve_tile: tile smaller than a 110-px window");
+    if (ws < 8 || ws > 256 || cs < 10) return c->fail(TTC_ERR_ARG, "superresolve_tile: window edge must be in [8, 256], >= 10 floats per pixel");
+    if (!d_s2 || T < 1 || X < ws || Y < ws) return c->fail(TTC_ERR_ARG, "superresolve_tile: tile smaller than one window");
     std::vector<int> xr, yr;
     for (int v = 0; v < X - ws; v += ws) xr.push_back(v);
     xr.push_back(X - ws);
@@ -276,7 +278,7 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
         float* res = static_cast<float*>(c->scratch_buf("ds_out", sizeof(float) * (size_t)n * 6 * E * E));
         if (!xin || !bil || !res) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
         { KTimer kt(c, "dsen2_gather", s);
-          hipLaunchKernelGGL(k_sr_gather, dim3((Ep * Ep + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, xin);
+          hipLaunchKernelGGL(k_sr_gather, dim3((Ep * Ep + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, xin);
           TTC_HIP(c, hipGetLastError()); }
         hipLaunchKernelGGL(k_sr_bil, dim3((E * E + 255) / 256, n), dim3(256), 0, s, xin, E, bil);
         TTC_HIP(c, hipGetLastError());
@@ -286,9 +288,9 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
               for (int g = 0; g < 4; ++g)
                   if (grp[g + 1] > grp[g])
                       hipLaunchKernelGGL(k_sr_scatter, dim3((ws * ws + 255) / 256, grp[g + 1] - grp[g], T), dim3(256), 0, s,
-                                         res, X, Y, sw, ws, grp[g], grp[g + 1], d_s2);
+                                         res, X, Y, sw, ws, cs, grp[g], grp[g + 1], d_s2);
           } else {
-              hipLaunchKernelGGL(k_sr_scatter, dim3((ws * ws + 255) / 256, sw.n, T), dim3(256), 0, s, res, X, Y, sw, ws, 0,
+              hipLaunchKernelGGL(k_sr_scatter, dim3((ws * ws + 255) / 256, sw.n, T), dim3(256), 0, s, res, X, Y, sw, ws, cs, 0,
                                  sw.n, d_s2);
           }
           TTC_HIP(c, hipGetLastError()); }

@@ -564,12 +564,65 @@ bool build_windows(int X, int Y, int size, WinTable& wt) {
 
 }  // namespace
 
+
+// Border strip (src/resegment_tiles_wide.py:997-1000, :1058-1066): regularize_and_smooth (:772-790) on the 10 bands and
+// make_and_smooth_indices (job.py:1009-1028) on the indices of the same dates, both = the 12 x T operator of
+// k_tile_temporal, kept as 12 monthly steps in one [12][npix][14] array (bands | indices) that the super-resolution and
+// ttc_border_subtiles then work on.  One thread per pixel; the strip is ~0.4 Mpx, this is not a hot kernel.
+__global__ __launch_bounds__(256) void k_strip_smooth(const float* __restrict__ s2, WMat wm, int npix, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const int T = wm.T;
+    float acc[12][14];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+#pragma unroll
+        for (int c = 0; c < 14; ++c) acc[k][c] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        float v[14];
+        const float* src = s2 + ((long)t * npix + p) * 10;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) v[c] = src[c];
+        v[10] = idx_evi(v[0], v[2], v[3]);
+        v[11] = idx_bi(v[0], v[2], v[3], v[8]);
+        v[12] = idx_msavi2(v[2], v[3]);
+        v[13] = idx_grndvi(v[1], v[2], v[3]);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const float w = wm.w[k * kMaxT + t];
+#pragma unroll
+            for (int c = 0; c < 14; ++c) acc[k][c] = fmaf(w, v[c], acc[k][c]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float* dst = out + ((long)k * npix + p) * 14;
+#pragma unroll
+        for (int c = 0; c < 14; ++c) dst[c] = acc[k][c];
+    }
+}
+
 #define LAUNCH_T(kern, T, ...)                                                        \
     do {                                                                              \
         if ((T) <= 8) hipLaunchKernelGGL((kern<8>), __VA_ARGS__);                     \
         else if ((T) <= 16) hipLaunchKernelGGL((kern<16>), __VA_ARGS__);              \
         else hipLaunchKernelGGL((kern<32>), __VA_ARGS__);                             \
     } while (0)
+
+ttc_status tile_smooth_strip(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat, float* d_out, hipStream_t s) {
+    if (!d_s2 || !h_wmat || !d_out || X < 1 || Y < 1) return c->fail(TTC_ERR_ARG, "smooth_strip: bad argument");
+    if (T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "smooth_strip: T must be in [1, 32]");
+    WMat wm{};
+    wm.T = T; wm.keep = T >= 32 ? 0xffffffffu : ((1u << T) - 1u); wm.Tk = T;
+    for (int k = 0; k < 12; ++k)
+        for (int t = 0; t < T; ++t) wm.w[k * kMaxT + t] = h_wmat[k * T + t];
+    const long npix = (long)X * Y;
+    KTimer kt(c, "strip_smooth", s);
+    hipLaunchKernelGGL(k_strip_smooth, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, d_s2, wm, (int)npix, d_out);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
 
 ttc_status tile_missing_counts(ttc_ctx* c, const float* d_s2, int T, int X, int Y, int32_t* d_counts, hipStream_t s) {
     if (!d_s2 || !d_counts || T < 1) return c->fail(TTC_ERR_ARG, "tile_missing_counts: bad argument");

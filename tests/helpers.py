@@ -109,3 +109,26 @@ def synth_reseg_windows(seed, shape, size, size_y, with_updown=False):
             wins.append(("u", xt, 0, np.clip(rng.random((size, size_y)) * 0.9, 0, 1).astype(np.float32)))
             wins.append(("d", xt, Y - size // 2, np.clip(rng.random((size, size_y)) * 0.9, 0, 1).astype(np.float32)))
     return wins
+
+
+def synth_border_pair(seed, T, X, Y, same_dates=True):
+    """Two neighbouring tiles as process_tile (job.py:641-995) returns them, plus their existing rasters, for
+    resegment_border (resegment_tiles_wide.py:847): dicts {s2 [T, X, Y, 10], dates, interp, s1 [12, X, Y, 2], dem [X, Y]},
+    tile_tif / neighbor_tif uint8 [X, Y] (0-100, 255 = no data)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(2):
+        img, dem, _, _, _ = synth.synth_detection_scene(seed + 3 * k, T, X, Y)
+        dates = np.array(sorted(rng.choice(np.arange(5, 360, 7), T, replace=False)))
+        s1 = rng.uniform(0.05, 0.9, (12, X, Y, 2)).astype(np.float32)
+        out.append(dict(s2=img, dates=dates, interp=np.zeros((T, X, Y), np.float32), s1=s1, dem=(dem / 90.0).astype(np.float32)))
+    if same_dates:
+        out[1]["dates"] = out[0]["dates"].copy()
+        out[1]["dates"][2] += 1                      # within the one-day grace of align_dates
+    yy = np.arange(X)[:, None]
+    tifs = []
+    for k in range(2):
+        r = np.clip(45 + 35 * np.sin(yy / 23.0 + k) + rng.normal(0, 6, (X, Y)), 0, 100).astype(np.uint8)
+        r[5:9, -30:] = 255
+        tifs.append(r)
+    return out[0], out[1], tifs[0], tifs[1]

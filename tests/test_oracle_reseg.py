@@ -107,3 +107,38 @@ def test_recreate_resegmented(tag):
     else:
         np.testing.assert_array_equal(np.packbits(preds == 255), g[f"{tag}_nodata"])
         np.testing.assert_allclose(preds[::2, ::2], g[f"{tag}_preds_sub"], rtol=0, atol=2e-4)
+
+
+def border_case(g, tag):
+    from tests.helpers import synth_border_pair
+    seed, T, X, Y, size, size_y, same = (int(v) for v in g[f"{tag}_cfg"])
+    tile, neighb, tif_t, tif_n = synth_border_pair(seed, T, X, Y, bool(same))
+    tt, tn = tif_t.astype(np.float32), tif_n.astype(np.float32)
+    tt[tt > 100] = np.nan
+    tn[tn > 100] = np.nan
+    return tile, neighb, tt, tn, size, size_y
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_resegment_border_arrays(tag):
+    """resegment_border (:847-1161): shared preprocessing of the strip ("s", dates agree) and per-tile preprocessing with
+    histogram alignment ("d"), against the arguments the reference hands to process_subtiles and the windows it saves"""
+    import random
+    from tests.helpers import fake_dsen2
+    g = golden("reseg_border.npz")
+    tile, neighb, tt, tn, size, size_y = border_case(g, tag)
+    random.seed(11)
+    trace = {}
+    wins, info = RS.resegment_border_arrays(tile, neighb, tt, tn, fake_model, fake_dsen2, min_dates=2, size=size, size_y=size_y, trace=trace)
+    assert info["min_images"] == int(g[f"{tag}_result"][1]) and info["hist_align"] == bool(g[f"{tag}_hist_align"])
+    np.testing.assert_array_equal(trace["dates"], g[f"{tag}_dates"])
+    np.testing.assert_array_equal(info["tiles_array"], g[f"{tag}_ta"])
+    np.testing.assert_array_equal(info["tiles_folder"], g[f"{tag}_tf"])
+    np.testing.assert_array_equal(trace["min_clear"], g[f"{tag}_min_clear"])
+    np.testing.assert_allclose(trace["interp"][:, ::4, ::4], g[f"{tag}_interp_sub"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(trace["strip"][:, ::9, ::5, :], g[f"{tag}_strip_sub"], rtol=0, atol=1e-4)
+    assert abs(trace["strip"].astype(np.float64).sum() - float(g[f"{tag}_strip_sum"])) < 2e-6 * trace["strip"].size
+    for t, o in enumerate(wins):
+        assert o["saved"] == bool(g[f"{tag}_saved{t}"])
+        if o["saved"]:
+            np.testing.assert_allclose(np.asarray(o["preds"], dtype=np.float32), g[f"{tag}_preds{t}"], rtol=0, atol=2e-4)

@@ -182,5 +182,90 @@ def main():
             print(fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KB")
 
 
+
+def gen_border(tags=("s", "d")):
+    """resegment_border (:847-1161) end to end on two synthetic neighbours, with every IO function of the reference
+    replaced by the arrays it would have loaded; the arguments of its process_subtiles call are captured."""
+    import random
+    import pandas as pd
+    from tests.helpers import synth_border_pair
+    J, CR = ref_harness.load()
+    import resegment_tiles_wide as RS
+    scratch = tempfile.mkdtemp(prefix="ttc_resegb_") + "/"
+    RS.args = types.SimpleNamespace(local_path=scratch, year=2020, process_all=True, resmooth=False, s3_bucket="none")
+    RS.x, RS.y = "10", "20"
+    RS.predict_logits, RS.predict_inp, RS.predict_length = "logits", "inp", "len"
+    RS.superresolve_logits, RS.superresolve_inp, RS.superresolve_inp_bilinear = "sl", "si", "sb"
+    RS.data = pd.DataFrame({"X_tile": [10, 11], "Y_tile": [20, 20]})
+    RS.AWSKEY = RS.AWSSECRET = None
+
+    def _boom(*a, **k):
+        raise IOError("no raster")
+    CR.adjust_cloudmask_in_forests = _boom
+    CR.mask_nonurban_areas = _boom
+
+    class PSess:
+        def run(self, op, feed_dict):
+            return fake_model(feed_dict["inp"])
+
+    class SRSess:
+        def run(self, op, feed_dict):
+            return fake_dsen2(feed_dict["si"], feed_dict["sb"])
+    RS.predict_sess, RS.gap_sess, RS.superresolve_sess = PSess(), None, SRSess()
+    RS.check_if_processed = lambda *a, **k: True
+    RS.download_raw_tile = lambda *a, **k: None
+    RS.update_ard_tiles = lambda *a, **k: None
+    RS.check_n_tiles = lambda *a, **k: (0, 0)
+    out = {}
+    for tag in tags:
+        seed, T, X, Y, size, size_y, same = {"s": (81, 7, 330, 150, 114, 134, True), "d": (82, 6, 300, 140, 114, 134, False)}[tag]
+        set_geometry(RS, size, size_y)
+        tile, neighb, tif_t, tif_n = synth_border_pair(seed, T, X, Y, same)
+        by_id = {"10": (tile, tif_t), "11": (neighb, tif_n)}
+        RS.load_tif = lambda tid, lp: (by_id[str(tid[0])][1].copy(), 0)
+        RS.load_dates = lambda tx, ty, lp: list(by_id[str(tx)][0]["dates"])
+
+        def _pt(tx, ty, data, lp, bbx, _m=by_id):
+            d = _m[str(tx)][0]
+            return (d["s2"].copy(), np.array(d["dates"]), d["interp"].copy(), d["s1"].copy(), d["dem"].copy(), None, None)
+        RS.process_tile = _pt
+        cap = {}
+        orig = RS.process_subtiles
+
+        def _capture(x, y, s2, dates, interp, s1, dem, sess, gap_sess, tiles_folder, tiles_array, right_all, left_all, hist_align, min_clear):
+            cap.update(strip=np.array(s2, copy=True), dates=np.array(dates), interp=np.array(interp, copy=True), s1=np.array(s1, copy=True),
+                       dem=np.array(dem, copy=True), tf=np.array(tiles_folder), ta=np.array(tiles_array), right_all=np.array(right_all),
+                       left_all=np.array(left_all), hist_align=bool(hist_align), min_clear=np.array(min_clear))
+            return orig(x, y, s2, dates, interp, s1, dem, sess, gap_sess, tiles_folder, tiles_array, right_all, left_all, hist_align, min_clear)
+        RS.process_subtiles = _capture
+        shutil.rmtree(scratch + "10", ignore_errors=True); shutil.rmtree(scratch + "11", ignore_errors=True)
+        random.seed(11)
+        try:
+            res = RS.resegment_border("10", "20", "right", scratch, [0, 0, 1, 1], [1, 0, 2, 1], 2, [0.0, 0.0, 0.0, 0.0])
+        finally:
+            RS.process_subtiles = orig
+        out[f"{tag}_cfg"] = np.array([seed, T, X, Y, size, size_y, int(same)])
+        out[f"{tag}_result"] = np.array([res[0], res[4]])
+        out[f"{tag}_dates"] = cap["dates"]; out[f"{tag}_hist_align"] = np.array(cap["hist_align"])
+        out[f"{tag}_strip_sub"] = cap["strip"][:, ::9, ::5, :].astype(np.float32)
+        out[f"{tag}_strip_sum"] = np.float64(cap["strip"].astype(np.float64).sum())
+        out[f"{tag}_interp_sub"] = cap["interp"][:, ::4, ::4].astype(np.float32)
+        out[f"{tag}_min_clear"] = cap["min_clear"].astype(np.int16)
+        out[f"{tag}_ta"], out[f"{tag}_tf"] = cap["ta"], cap["tf"]
+        for t in range(len(cap["tf"])):
+            p1 = f"{scratch}10/20/processed//right{cap['tf'][t][0]}/{cap['tf'][t][1]}.npy"
+            out[f"{tag}_saved{t}"] = np.array(os.path.exists(p1))
+            if os.path.exists(p1):
+                out[f"{tag}_preds{t}"] = np.asarray(np.load(p1), dtype=np.float32)
+        print("border", tag, res[0], res[4], cap["strip"].shape, cap["dates"], cap["hist_align"], [bool(out[f"{tag}_saved{t}"]) for t in range(len(cap["tf"]))])
+    np.savez_compressed(os.path.join(OUT, "reseg_border.npz"), **out)
+    shutil.rmtree(scratch, ignore_errors=True)
+    print("reseg_border.npz", os.path.getsize(os.path.join(OUT, "reseg_border.npz")) // 1024, "KB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "border":
+        gen_border()
+    else:
+        main()
+        gen_border()
