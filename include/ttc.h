@@ -192,6 +192,8 @@ ttc_status ttc_snow_map(ttc_ctx* ctx, const float* d_s2, int32_t T, int32_t X, i
 ttc_status ttc_merge_cloud_masks(ttc_ctx* ctx, float* d_cloudshad, float* d_clm, const uint8_t* d_fcps, int64_t n, void* stream);
 /* h_counts[t] = #(d_a[t] > 0) (np.mean(interp > 0, axis = (1, 2)) of :868 is count / npix); waits for the stream. */
 ttc_status ttc_count_positive(ttc_ctx* ctx, const float* d_a, int32_t T, int32_t npix, int32_t* h_counts, void* stream);
+/* per date, how many pixels equal `value` (np.mean(interp == 1, axis = (1, 2)) of resegment_tiles_wide.py:651) */
+ttc_status ttc_count_equal(ttc_ctx* ctx, const float* d_a, int32_t T, int32_t npix, float value, int32_t* h_counts, void* stream);
 /* np.clip(x, 0, 1) in place (:994). */
 ttc_status ttc_clip01(ttc_ctx* ctx, float* d_a, int64_t n, void* stream);
 /* x / divisor in place with an IEEE division (dem / 90, :993). */

@@ -23,7 +23,7 @@ EXPORTS = [
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
-    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows",
+    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -430,6 +430,14 @@ class Context:
         self._check(self.lib.ttc_merge_cloud_masks(self._h, C.c_void_p(cloudshad.data_ptr()), C.c_void_p(clm.data_ptr()),
                                                    C.c_void_p(fcps.data_ptr()) if fcps is not None else None, cloudshad.numel(),
                                                    self._stream()), "ttc_merge_cloud_masks")
+
+    def fraction_equal(self, a, value):
+        """a cuda float32 [T, X, Y] -> numpy float64 [T]: np.mean(a == value, axis=(1, 2))"""
+        T, npix = int(a.shape[0]), int(a.shape[1] * a.shape[2])
+        cnt = (C.c_int32 * T)()
+        self._check(self.lib.ttc_count_equal(self._h, C.c_void_p(a.data_ptr()), T, npix, C.c_float(value), cnt, self._stream()),
+                    "ttc_count_equal")
+        return np.array([cnt[i] for i in range(T)], dtype=np.float64) / npix
 
     def fraction_positive(self, a):
         """a cuda float32 [T, X, Y] -> numpy float64 [T]: np.mean(a > 0, axis=(1, 2))"""

@@ -38,7 +38,7 @@ ttc_status prep_sen2cor_clean(ttc_ctx* c, const float* d_clm20, int T, int w20, 
 ttc_status prep_median5(ttc_ctx* c, const float* d_in, int X, int Y, float* d_out, hipStream_t s);
 ttc_status prep_snow(ttc_ctx* c, const float* d_s2, int T, int X, int Y, uint8_t* d_snow, int32_t* h_per_image, hipStream_t s);
 ttc_status prep_merge_clm(ttc_ctx* c, float* d_cloudshad, float* d_clm, const uint8_t* d_fcps, int64_t n, hipStream_t s);
-ttc_status prep_count_positive(ttc_ctx* c, const float* d_a, int T, int npix, int32_t* h_counts, hipStream_t s);
+ttc_status prep_count_positive(ttc_ctx* c, const float* d_a, int T, int npix, float eq, int32_t* h_counts, hipStream_t s);
 ttc_status prep_clip01(ttc_ctx* c, float* d_a, int64_t n, hipStream_t s);
 ttc_status prep_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, hipStream_t s);
 
@@ -260,7 +260,11 @@ ttc_status ttc_merge_cloud_masks(ttc_ctx* c, float* d_cloudshad, float* d_clm, c
     return c ? prep_merge_clm(c, d_cloudshad, d_clm, d_fcps, n, TTC_S(stream)) : TTC_ERR_ARG;
 }
 ttc_status ttc_count_positive(ttc_ctx* c, const float* d_a, int32_t T, int32_t npix, int32_t* h_counts, void* stream) {
-    return c ? prep_count_positive(c, d_a, T, npix, h_counts, TTC_S(stream)) : TTC_ERR_ARG;
+    return c ? prep_count_positive(c, d_a, T, npix, NAN, h_counts, TTC_S(stream)) : TTC_ERR_ARG;
+}
+ttc_status ttc_count_equal(ttc_ctx* c, const float* d_a, int32_t T, int32_t npix, float value, int32_t* h_counts, void* stream) {
+    if (value != value) return c ? c->fail(TTC_ERR_ARG, "count_equal: value is NaN") : TTC_ERR_ARG;
+    return c ? prep_count_positive(c, d_a, T, npix, value, h_counts, TTC_S(stream)) : TTC_ERR_ARG;
 }
 ttc_status ttc_clip01(ttc_ctx* c, float* d_a, int64_t n, void* stream) {
     return c ? prep_clip01(c, d_a, n, TTC_S(stream)) : TTC_ERR_ARG;

@@ -92,10 +92,15 @@ __global__ void k_merge_clm(float* __restrict__ cloudshad, float* __restrict__ c
     if (fcps && fcps[i]) { m = 0.f; clm[i] = 0.f; }
     cloudshad[i] = fmaxf(cloudshad[i], m);
 }
-__global__ void k_count_positive(const float* __restrict__ a, int npix, int* __restrict__ counts) {
+// eq = NaN: count a > 0; otherwise count a == eq
+__global__ void k_count_positive(const float* __restrict__ a, int npix, float eq, int* __restrict__ counts) {
     const int t = blockIdx.y;
+    const bool pos = eq != eq;
     int c = 0;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) c += a[(long)t * npix + p] > 0.f;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        const float v = a[(long)t * npix + p];
+        c += pos ? v > 0.f : v == eq;
+    }
     for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[t], c);
 }
@@ -146,12 +151,12 @@ ttc_status prep_merge_clm(ttc_ctx* c, float* d_cloudshad, float* d_clm, const ui
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }
-ttc_status prep_count_positive(ttc_ctx* c, const float* d_a, int T, int npix, int32_t* h_counts, hipStream_t s) {
+ttc_status prep_count_positive(ttc_ctx* c, const float* d_a, int T, int npix, float eq, int32_t* h_counts, hipStream_t s) {
     if (!d_a || !h_counts || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "count_positive: bad argument (T in [1, 32])");
     int* cnt = static_cast<int*>(c->scratch_buf("prep_cnt", sizeof(int) * kMaxT));
     if (!cnt) return c->fail(TTC_ERR_NOMEM, "count scratch");
     TTC_HIP(c, hipMemsetAsync(cnt, 0, sizeof(int) * kMaxT, s));
-    hipLaunchKernelGGL(k_count_positive, dim3(32, T), dim3(256), 0, s, d_a, npix, cnt);
+    hipLaunchKernelGGL(k_count_positive, dim3(32, T), dim3(256), 0, s, d_a, npix, eq, cnt);
     TTC_HIP(c, hipMemcpyAsync(h_counts, cnt, sizeof(int) * T, hipMemcpyDeviceToHost, s));
     TTC_HIP(c, hipStreamSynchronize(s));
     return TTC_OK;

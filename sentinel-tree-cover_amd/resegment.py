@@ -269,3 +269,124 @@ def recreate_resegmented_tifs(windows, shape, sess, size=SIZE, return_sums=True)
     if return_sums:
         return out[0].cpu().numpy(), out[1].cpu().numpy()
     return out.cpu().numpy()
+
+
+# ---- strip preparation (resegment_border, :847-1161) ---------------------------------------------------------------------
+def _select(t, tensor, keep):
+    return tensor.index_select(0, t.as_tensor(np.asarray(keep, dtype=np.int64), device=tensor.device)).contiguous()
+
+
+def _drop(t, tensor, idx):
+    if tensor is None or len(idx) == 0:
+        return tensor
+    return _select(t, tensor, np.setdiff1d(np.arange(tensor.shape[0]), np.asarray(idx).ravel()))
+
+
+def preprocess_tile(arr, dates, interp, clm, fname, dem, bbx, sess=None, sampler="reference", forest_mask=None, urban_masks=None):
+    """:619-672 on the device -> (arr cuda [T', X, Y, 10], interp cuda [T', X, Y], dates).  `interp` and `fname` are unused
+    (as in the reference); `bbx` only windows the WorldCover rasters there -- pass them cut as forest_mask / urban_masks."""
+    ctx, t = sess.ctx, sess.ctx.torch
+    s2 = ctx._dev(arr, t.float32).clone()
+    dates = np.array(dates, copy=True)
+    demd = ctx._dev(dem, t.float32)
+    clmd = ctx._dev(clm, t.float32).clone() if clm is not None else None
+    X = int(s2.shape[1])
+    missing = np.argwhere(ctx.tile_missing_counts(s2) >= (X ** 2) / 20).flatten()               # id_missing_px(arr, 20)
+    if len(missing) > 0:
+        dates = np.delete(dates, missing)
+        s2 = _drop(t, s2, missing)
+        clmd = _drop(t, clmd, missing)
+    cld, fcps = ctx.identify_clouds_shadows(s2, demd, forest_mask, urban_masks)
+    if clmd is not None and tuple(clmd.shape) == tuple(cld.shape):                               # else: the reference's except branch
+        ctx.merge_cloud_masks(cld, clmd, fcps)
+    itp = ctx.feather(cld, closing=15, clip=True)                                                # id_areas_to_interp
+    heavy = np.argwhere(ctx.fraction_equal(itp, 1.0) > 0.95).flatten()
+    if len(heavy) > 0:
+        dates = np.delete(dates, heavy)
+        s2 = _drop(t, s2, heavy)
+        cld, fcps = ctx.identify_clouds_shadows(s2, demd, forest_mask, urban_masks)
+    fn = job.reference_sampler if sampler == "reference" else None
+    interp2, _, _ = ctx.remove_cloud_and_shadows(s2, cld, fcps, fn)
+    return s2, interp2, dates
+
+
+def _deal_w_missing_px(ctx, s2, dates, interp):
+    """job.py:1031-1054 on the device (date screening on the host from device counts; value repair in a kernel)"""
+    t = ctx.torch
+    X = int(s2.shape[1])
+    missing = np.argwhere(ctx.tile_missing_counts(s2) >= (X ** 2) / 10).flatten()
+    if len(missing) > 0:
+        dates = np.delete(dates, missing)
+        s2, interp = _drop(t, s2, missing), _drop(t, interp, missing)
+    ctx.tile_fix_missing(s2, do_nan=False, do_zero_one=True)
+    return s2, dates, interp
+
+
+def smooth_strip(s2, dates, sess):
+    """regularize_and_smooth (:772-790) + make_and_smooth_indices (job.py:1009-1028) -> cuda [12, X, Y, 14]"""
+    from . import temporal
+    return sess.ctx.smooth_strip(s2, temporal.temporal_operator(np.asarray(dates)))
+
+
+def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, size=SIZE, size_y=SIZE_Y, sampler="reference",
+                     forest_masks=(None, None), urban_masks=(None, None), return_strip=False):
+    """The array flow of resegment_border (:847-1161, edge "right") for a tile and its right-hand neighbour that are both
+    processed and show an artifact (check_if_artifact): `tile` / `neighb` = dicts with process_tile's outputs {s2 [T, X, Y, 10],
+    dates, interp, s1 [12, X, Y, 2], dem [X, Y]} (+ clm: Sen2Cor mask at 10 m or None), numpy or cuda; tile_tif / neighbor_tif
+    the existing rasters (float, NaN = no data).  `sess` = border_session(...) with DSen2 weights loaded.
+    -> ({path: window} as process_subtiles, info)"""
+    ctx, t = sess.ctx, sess.ctx.torch
+    dev = lambda v: ctx._dev(v, t.float32)                                  # noqa: E731
+    a = {k: (dev(v) if k != "dates" and v is not None else v) for k, v in tile.items()}
+    b = {k: (dev(v) if k != "dates" and v is not None else v) for k, v in neighb.items()}
+    dates, dates_n = np.array(a["dates"]), np.array(b["dates"])
+    _, _, min_images = align_dates(dates, dates_n)
+    half = (size + 14) // 2
+    if min_images >= 3:                                                     # shared preprocessing of the strip, :906-1001
+        s2, _, s1, dem, tiles_x = split_to_border(a["s2"], a["interp"], a["s1"], a["dem"], "tile", size=size)
+        s2n, _, s1n, dem_n, _ = split_to_border(b["s2"], b["interp"], b["s1"], b["dem"], "neighbor", size=size)
+        clm = split_fn(a["clm"], "tile", size)[0] if a.get("clm") is not None else None
+        clm_n = split_fn(b["clm"], "neighbor", size)[0] if b.get("clm") is not None else None
+        rm_t, rm_n, _ = align_dates(dates, dates_n)
+        s2, clm, dates = _drop(t, s2, rm_t), _drop(t, clm, rm_t), np.delete(dates, rm_t)
+        s2n, clm_n, dates_n = _drop(t, s2n, rm_n), _drop(t, clm_n, rm_n), np.delete(dates_n, rm_n)
+        both = clm is not None and clm_n is not None and clm.shape[0] == clm_n.shape[0]
+        clm = t.nan_to_num(t.cat([clm_n, clm], dim=2), nan=0.0).contiguous() if both else None     # neighbour first, as coded (:971)
+        s2 = t.cat([s2, s2n], dim=2).contiguous()
+        dem = t.cat([dem, dem_n], dim=1).contiguous()
+        s2, interp, dates = preprocess_tile(s2, dates, None, clm, "tile", dem, None, sess, sampler, forest_masks[0], urban_masks[0])
+        s2, dates, interp = _deal_w_missing_px(ctx, s2, dates, interp)
+        dates_n = dates
+        strip = smooth_strip(s2, dates, sess)
+        min_clear = (interp != 1).sum(dim=0)
+    else:                                                                   # per-tile preprocessing, :1003-1110
+        s2, interp, dates = preprocess_tile(a["s2"], dates, a["interp"], a.get("clm"), "tile", a["dem"], None, sess, sampler,
+                                            forest_masks[0], urban_masks[0])
+        s2, interp, s1, dem, tiles_x = split_to_border(s2, interp, a["s1"], a["dem"], "tile", size=size)
+        s2n, interp_n, dates_n = preprocess_tile(b["s2"], dates_n, b["interp"], b.get("clm"), "neighbor", b["dem"], None, sess, sampler,
+                                                 forest_masks[1], urban_masks[1])
+        s2n, interp_n, s1n, dem_n, _ = split_to_border(s2n, interp_n, b["s1"], b["dem"], "neighbor", size=size)
+        rm_t, rm_n, min_images = align_dates(dates, dates_n)
+        min_clear = t.cat([(interp[..., -half:] != 1).sum(dim=0), (interp_n[..., :half] != 1).sum(dim=0)], dim=1)
+        if min_images >= min_dates:
+            s2, interp, dates = _drop(t, s2, rm_t), _drop(t, interp, rm_t), np.delete(dates, rm_t)
+            s2n, interp_n, dates_n = _drop(t, s2n, rm_n), _drop(t, interp_n, rm_n), np.delete(dates_n, rm_n)
+        s2, dates, interp = _deal_w_missing_px(ctx, s2.contiguous(), dates, interp.contiguous())
+        s2n, dates_n, interp_n = _deal_w_missing_px(ctx, s2n.contiguous(), dates_n, interp_n.contiguous())
+        strip = t.cat([smooth_strip(s2, dates, sess), smooth_strip(s2n, dates_n, sess)], dim=2).contiguous()
+        dem = t.cat([dem, dem_n], dim=1).contiguous()
+        n = min(interp.shape[0], interp_n.shape[0])
+        interp = t.cat([interp[:n], interp_n[:n]], dim=2)
+    s1 = t.cat([s1, s1n], dim=2).contiguous()
+    ctx.superresolve_windows(strip, wsize=125, quirks=1)                     # :1124, on bands 4..9 of the 14-channel strip
+    ta, tf = border_windows(int(s1.shape[1]), tiles_x, size, size_y)
+    hist_align = not np.array_equal(np.array(dates), np.array(dates_n))     # :1140-1145
+    right_all = np.asarray(neighbor_tif)[:, :size // 2]
+    left_all = np.asarray(tile_tif)[:, -(size // 2):]
+    wins = process_subtiles(None, None, strip, dates, interp, s1, dem, sess, None, tf, ta, right_all, left_all, hist_align, min_clear,
+                            size=size, size_y=size_y)
+    info = dict(min_images=int(min_images), hist_align=hist_align, tiles_array=ta, tiles_folder=tf, dates=np.array(dates),
+                dates_neighb=np.array(dates_n), min_clear=min_clear, interp=interp)
+    if return_strip:
+        info.update(strip=strip, s1=s1, dem=dem)
+    return wins, info

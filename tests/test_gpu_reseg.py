@@ -5,7 +5,7 @@ import importlib
 import numpy as np
 import pytest
 
-from tests.helpers import golden, synth_border_strip
+from tests.helpers import golden, synth, synth_border_strip
 from tests.test_oracle_reseg import subtile_inputs, hist_input, artifact_cases
 
 pytestmark = pytest.mark.gpu
@@ -213,3 +213,71 @@ def test_border_mosaic_errors_are_loud():
         RSG.recreate_resegmented_tifs({"0/0.npy": p, "right100/0.npy": np.zeros((46, 91), np.float32)}, (100, 200), sess, size=90)
     out, _ = RSG.recreate_resegmented_tifs({"0/0.npy": p, "60/0.npy": np.full((48, 48), 255.0, np.float32)}, (100, 200), sess, size=90)
     assert (out[:48, :48] == 50).all() and (out[48:] == 255).all()
+
+
+def test_strip_smoothing_and_superresolution_stages():
+    """regularize_and_smooth + make_and_smooth_indices (one 12 x T operator) and the 125-px DSen2 tiling on the
+    14-channel strip, each against the oracle on identical inputs"""
+    import torch
+    from oracle import restate_reseg as O, restate_numpy as R, restate_model as M
+    from ttc import weights as Wt
+    rng = np.random.default_rng(8)
+    T, X, Y = 6, 150, 140
+    s2 = synth.synth_tile(seed=5, T=T, H=X, W=Y)[0]
+    dates = np.array([12, 40, 95, 170, 260, 330])
+    sess = RSG.border_session(Wt.synth_weights(0), size=114, size_y=134)       # DSen2 weights from the package
+    got = RSG.smooth_strip(s2, dates, sess)
+    want = np.concatenate([O.regularize_and_smooth(s2.copy(), dates), O.make_and_smooth_indices(s2.copy(), dates)], axis=-1)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=5e-5)      # the reference's Whittaker LU is float32
+    strip = rng.uniform(0.02, 0.6, (3, 300, 160, 14)).astype(np.float32)
+    net = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    ref = strip.copy()
+    ref[..., :10] = R.superresolve_large_tile(strip[..., :10].copy(), net, wsize=125)
+    dev = sess.ctx._dev(strip.copy(), sess.ctx.torch.float32)
+    sess.ctx.superresolve_windows(dev, wsize=125, quirks=1)
+    out = dev.cpu().numpy()
+    np.testing.assert_array_equal(out[..., 10:], strip[..., 10:])
+    np.testing.assert_array_equal(out[..., :4], strip[..., :4])
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+    assert np.abs(out[..., 4:10] - strip[..., 4:10]).max() > 1e-3
+    # the window column the reference never reaches (y == last, x != last) stays untouched
+    np.testing.assert_array_equal(out[:, :125, 150:, 4:10], strip[:, :125, 150:, 4:10])
+    sess.close()
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_resegment_border_end_to_end(tag):
+    """resegment_border (:847-1161) from two process_tile outputs to the saved windows: shared preprocessing ("s") and
+    per-tile preprocessing + histogram alignment ("d"), against the oracle with the same networks"""
+    import random
+    import torch
+    from oracle import restate_reseg as O, restate_model as M
+    from tests.test_oracle_reseg import border_case
+    from ttc import weights as Wt
+    g = golden("reseg_border.npz")
+    tile, neighb, tt, tn, size, size_y = border_case(g, tag)
+    sess = RSG.border_session(Wt.synth_weights(0), size=size, size_y=size_y)
+    dsen2 = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    random.seed(11)
+    trace = {}
+    ref, rinfo = O.resegment_border_arrays(tile, neighb, tt, tn, oracle_model(), dsen2, min_dates=2, size=size, size_y=size_y, trace=trace)
+    random.seed(11)
+    wins, info = RSG.resegment_border(tile, neighb, tt, tn, sess, min_dates=2, size=size, size_y=size_y, return_strip=True)
+    assert info["min_images"] == rinfo["min_images"] == int(g[f"{tag}_result"][1])
+    assert info["hist_align"] == rinfo["hist_align"] == bool(g[f"{tag}_hist_align"])
+    np.testing.assert_array_equal(info["dates"], g[f"{tag}_dates"])
+    np.testing.assert_array_equal(info["tiles_array"], g[f"{tag}_ta"])
+    np.testing.assert_array_equal(info["tiles_folder"], g[f"{tag}_tf"])
+    np.testing.assert_array_equal(info["min_clear"].cpu().numpy(), g[f"{tag}_min_clear"])
+    np.testing.assert_allclose(info["interp"].cpu().numpy()[:, ::4, ::4], g[f"{tag}_interp_sub"], rtol=0, atol=1e-6)
+    e = np.abs(info["strip"].cpu().numpy() - trace["strip"])
+    print(f"[parity] strip {tag}: max {e.max():.3e} mean {e.mean():.3e}")
+    assert e.max() < 1e-4 and e.mean() < 1e-6           # measured 1.6e-6 / 5e-8; the gap-fill NNLS can move single pixels more
+    for o in ref:
+        name = f"right{o['folder_y']}/{o['folder_x']}.npy"
+        assert (name in wins) == o["saved"]
+        if o["saved"]:
+            d = np.abs(wins[name] - o["preds"])
+            print(f"[parity] window {name}: max {d.max():.3e} mean {d.mean():.3e}")
+            assert d.max() < 3e-4 and d.mean() < 5e-6          # measured 4.3e-5 / 2e-7
+    sess.close()
