@@ -21,7 +21,7 @@ LEN = 4           # :41
 
 # :1664-1685 -- float32 vectors here (the main job keeps Python floats, job.py:1829-1842)
 MIN_ALL32 = np.asarray(R.MIN_ALL, dtype=np.float64).astype(np.float32)
-MAX_ALL32 = np.asarray(R.MAX_ALL, dtype=np.float64)
+MAX_ALL32 = np.array(R.MAX_ALL, dtype=np.float64, copy=True)
 MAX_ALL32[10] = 0.509269855802243     # :1675 (the DEM maximum differs from job.py:1839's 0.4)
 MAX_ALL32 = MAX_ALL32.astype(np.float32)
 
