@@ -13,6 +13,8 @@
 // F7): the conv epilogue emits per-workgroup partial sums, k_gn_finalize reduces them in
 // double, and the NEXT elementwise kernel applies the affine while it gathers
 // (pad / pool / upsample / crop / concat are index math, never separate passes).
+#include <algorithm>
+
 #include "ttc_internal.h"
 
 namespace {
@@ -25,9 +27,10 @@ __device__ __forceinline__ float tanh_fast(float v) { return 1.0f - 2.0f * __bui
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // ---------------------------------------------------------------------------------------
-// [n][L+1][H][W][C] (reference feed layout) -> padded planar frames [n][L+1][C][H+2][W+2];
+// [n][L+1][rows][cols][C] (reference feed layout) -> padded planar frames [n][L+1][C][H+2][W+2];
 // frames < L reflect-padded (ConvGRU, model.py:250), frame L zero-padded (SAME conv).
-__global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict__ frames, int L1, int H, int W, int C) {
+// H, W are the INTERNAL plane dims; tr: the planes hold the window transposed (rows = W, cols = H), see Geo.
+__global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict__ frames, int L1, int H, int W, int C, int tr) {
     const int Wp = W + 2, PP = (H + 2) * Wp;
     const int f = blockIdx.y, n = blockIdx.z;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -37,7 +40,7 @@ __global__ void k_nhwc_to_frames(const float* __restrict__ in, float* __restrict
     int sy = py - 1, sx = px - 1;
     const bool border = sy < 0 || sy >= H || sx < 0 || sx >= W;
     sy = reflect_idx(sy, H); sx = reflect_idx(sx, W);
-    const float* src = in + ((((long)n * L1 + f) * H + sy) * W + sx) * C;
+    const float* src = in + (tr ? (((long)n * L1 + f) * W + sx) * H + sy : (((long)n * L1 + f) * H + sy) * W + sx) * C;
     float* dst = frames + (((long)n * L1 + f) * C) * PP + p;
     for (int c = 0; c < C; ++c) dst[(long)c * PP] = (last && border) ? 0.0f : src[c];
 }
@@ -193,7 +196,7 @@ __global__ void k_block_finalize(FinArgs a) {
 
 // final block tail + 1x1 head (train-model.py:226-231): sigmoid(sum_c hw[c] * z[c] + hb)
 __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
-                       const float* __restrict__ headp, float* __restrict__ out, int C, int P) {
+                       const float* __restrict__ headp, float* __restrict__ out, int C, int P, int ow, int tr) {
     extern __shared__ float sm[];            // scale shift ssew headw
     const int n = blockIdx.y, cpg = C / 8;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -210,12 +213,14 @@ __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__
     gate = sigm(gate);
     float logit = headp[C];
     for (int c = 0; c < C; ++c) logit += sm[3 * C + c] * ((y[(long)c * P] * sm[c] + sm[C + c]) * gate);
-    out[(long)n * P + p] = sigm(logit);
+    const int oh = P / ow;
+    out[(long)n * P + (tr ? (p % ow) * oh + p / ow : p)] = sigm(logit);      // tr: the plane is the transposed window
 }
 
 // ---- feature taps (--gen_feats, job.py:1429-1445, tensors named at :1808-1809) -------------------------
-// early = the bi-ConvGRU output (`gru_drop/.../Merge:0`, inference: identity), [n, H, W, 64] NHWC
-__global__ void k_tap_early(const float* __restrict__ gru_out, int H, int W, int N, float* __restrict__ out) {
+// early = the bi-ConvGRU output (`gru_drop/.../Merge:0`, inference: identity), [n, rows, cols, 64] NHWC
+// (H, W internal plane dims; tr: rows = W, cols = H)
+__global__ void k_tap_early(const float* __restrict__ gru_out, int H, int W, int N, int tr, float* __restrict__ out) {
     const int Wp = W + 2;
     const long PP = (long)(H + 2) * Wp, total = (long)N * H * W * 64;
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,12 +228,14 @@ __global__ void k_tap_early(const float* __restrict__ gru_out, int H, int W, int
     const int ch = (int)(id & 63);
     const long pix = id >> 6;
     const int n = (int)(pix / ((long)H * W)), r = (int)(pix - (long)n * H * W);
-    const int y = r / W, x = r - y * W;
+    const int cols = tr ? H : W;
+    const int uy = r / cols, ux = r - uy * cols;
+    const int y = tr ? ux : uy, x = tr ? uy : ux;
     out[id] = gru_out[((long)n * 64 + ch) * PP + (long)(y + 1) * Wp + (x + 1)];
 }
 // late = output of the last conv_swish_gn block after its sSE gate (`csse_out_mul/mul:0`), [n, o, o, C] NHWC
 __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
-                           float* __restrict__ out, int C, int P) {
+                           float* __restrict__ out, int C, int P, int ow, int tr) {
     extern __shared__ float sm[];            // scale shift ssew
     const int n = blockIdx.y, cpg = C / 8;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -243,7 +250,8 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
     float gate = prm[3 * C];
     for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * P] * sm[c] + sm[C + c]);
     gate = sigm(gate);
-    float* o = out + ((long)n * P + p) * C;
+    const int oh = P / ow;
+    float* o = out + ((long)n * P + (tr ? (p % ow) * oh + p / ow : p)) * C;
     for (int c = 0; c < C; ++c) o[c] = (y[(long)c * P] * sm[c] + sm[C + c]) * gate;
 }
 
@@ -252,10 +260,19 @@ struct Axis {
     int n, np, c1, c2, u2, u3, o;
     explicit Axis(int n_) : n(n_), np(n_ + 2) { c1 = n / 2 - 2; c2 = c1 / 2 - 2; u2 = 2 * c2; u3 = 2 * u2; o = u3 - 2; }
 };
+// The conv engine tiles a FLATTENED padded plane: a 512-position tile stages 512 + 2 * (cols + 2) + 2 positions per input
+// channel, so wide planes waste LDS and loads (686 columns: 1886 staged per 512 computed, one workgroup per CU).  A window
+// with more columns than rows (the 220 x 684 border graph) is therefore held TRANSPOSED: planes are [cols][rows], every
+// 3x3 kernel is uploaded with its taps swapped, and only the kernels at the boundary (frames in, probabilities / taps out,
+// reseg.hip's assembly) know.  Everything else sees `y` = plane rows, `x` = plane columns.
+inline int model_rows(const ttc_config& c) { return c.win_rows > 0 ? c.win_rows : c.win_in; }
+inline bool model_transposed(const ttc_config& c) { return model_rows(c) < c.win_in; }
 struct Geo {
-    Axis y, x;      // rows (win_rows, or win_in when 0) and columns (win_in)
+    bool tr;
+    Axis y, x;      // plane rows / columns
     int L;
-    explicit Geo(const ttc_config& c) : y(c.win_rows > 0 ? c.win_rows : c.win_in), x(c.win_in), L(c.length) {}
+    explicit Geo(const ttc_config& c)
+        : tr(model_transposed(c)), y(tr ? c.win_in : model_rows(c)), x(tr ? model_rows(c) : c.win_in), L(c.length) {}
 };
 
 const char* kBlockNames[8] = {"conv_median", "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out"};
@@ -289,8 +306,8 @@ ttc_status model_alloc(ttc_ctx* c) {
     const size_t N = c->cfg.max_windows, N2 = 2 * N;
     const size_t PP = (size_t)g.y.np * g.x.np, P = (size_t)g.y.n * g.x.n;
     const int F = c->cfg.base_filters, Hd = c->cfg.hidden, C = c->cfg.n_bands;
-    if (g.x.n % 4 != 0 || g.x.n < 28) return c->fail(TTC_ERR_ARG, "win_in must be a multiple of 4 and >= 28");
-    if (g.y.n % 4 != 0 || g.y.n < 28) return c->fail(TTC_ERR_ARG, "win_rows must be a multiple of 4 and >= 28 (or 0)");
+    if (c->cfg.win_in % 4 != 0 || c->cfg.win_in < 28) return c->fail(TTC_ERR_ARG, "win_in must be a multiple of 4 and >= 28");
+    if (model_rows(c->cfg) % 4 != 0 || model_rows(c->cfg) < 28) return c->fail(TTC_ERR_ARG, "win_rows must be a multiple of 4 and >= 28 (or 0)");
     if (F != 64 || Hd != 32 || C != 17) return c->fail(TTC_ERR_ARG, "only base_filters=64, hidden=32, n_bands=17 are built");
     auto area = [&](int Axis::*m, int pad) { return (size_t)(g.y.*m + pad) * (g.x.*m + pad); };
     const size_t Pc1 = area(&Axis::c1, 0), Pc2 = area(&Axis::c2, 0), Pu2 = area(&Axis::u2, 0), Pu2p = area(&Axis::u2, 2);
@@ -325,7 +342,19 @@ static const ttc_tensor* find_t(const ttc_tensor* t, int n, const std::string& n
 }
 
 static ttc_status upload_conv(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout) {
-    return conv_upload(c, pc, hwio, nsets, Cin, Cout, conv_pick_bn(Cout));
+    if (!model_transposed(c->cfg)) return conv_upload(c, pc, hwio, nsets, Cin, Cout, conv_pick_bn(Cout));
+    // transposed planes: tap (kh, kw) of the HWIO kernel acts as (kw, kh)
+    const size_t blk = (size_t)Cin * Cout;
+    std::vector<std::vector<float>> tw(nsets, std::vector<float>(9 * blk));
+    std::vector<const float*> ptr(nsets);
+    for (int sidx = 0; sidx < nsets; ++sidx) {
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw)
+                std::copy(hwio[sidx] + (size_t)(kw * 3 + kh) * blk, hwio[sidx] + (size_t)(kw * 3 + kh + 1) * blk,
+                          tw[sidx].begin() + (size_t)(kh * 3 + kw) * blk);
+        ptr[sidx] = tw[sidx].data();
+    }
+    return conv_upload(c, pc, ptr.data(), nsets, Cin, Cout, conv_pick_bn(Cout));
 }
 
 ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
@@ -396,7 +425,7 @@ ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStrea
     const Geo g(c->cfg);
     KTimer kt(c, "frames_from_nhwc", s);
     dim3 grid((g.y.np * g.x.np + 255) / 256, g.L + 1, n);
-    hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.y.n, g.x.n, c->cfg.n_bands);
+    hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.y.n, g.x.n, c->cfg.n_bands, g.tr ? 1 : 0);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }
@@ -524,7 +553,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         KTimer kt(c, "head", s);
         const int Po = (int)o.area();
         hipLaunchKernelGGL(k_head, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
-                           prm(7), sm + c->small_off["head/"], d_out, F, Po);
+                           prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0);
         TTC_HIP(c, hipGetLastError());
     }
     return TTC_OK;
@@ -539,13 +568,13 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
     if (d_early) {
         const long total = (long)n * g.y.n * g.x.n * 64;
         hipLaunchKernelGGL(k_tap_early, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru_out, g.y.n, g.x.n, n,
-                           d_early);
+                           g.tr ? 1 : 0, d_early);
     }
     if (d_late) {
         const int Po = g.y.o * g.x.o;
         const float* gn7 = c->gn + (size_t)7 * c->cfg.max_windows * 2 * 32;
         hipLaunchKernelGGL(k_tap_late, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
-                           c->d_small + c->small_off["out/"], d_late, F, Po);
+                           c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0);
     }
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;

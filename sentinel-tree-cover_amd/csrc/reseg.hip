@@ -58,13 +58,15 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void k_hist_stats(const float* __restrict__ q, const float* __restrict__ med, BTable bt, int W,
                                                      long npix, int half, double* __restrict__ stats) {
 #pragma clang fp contract(off)
-    __shared__ double red[4];
     const int wf = blockIdx.x, w = wf / 5, f = wf - 5 * w, side = blockIdx.y;
     const BWin bw = bt.w[w];
     const int c0 = side ? half : 0, nc = side ? W - half : half;
+    // gridDim.z row chunks per (window, frame, half): 40 workgroups alone would leave most of the chip idle
+    const int rows_per = (bw.h + gridDim.z - 1) / gridDim.z;
+    const int r0 = blockIdx.z * rows_per, r1 = min(bw.h, r0 + rows_per);
     double acc[14][3];
     for (int b = 0; b < 14; ++b) acc[b][0] = acc[b][1] = acc[b][2] = 0.0;
-    for (int i = threadIdx.x; i < bw.h * nc; i += blockDim.x) {
+    for (int i = r0 * nc + threadIdx.x; i < r1 * nc; i += blockDim.x) {
         const int r = i / nc, cc = i - r * nc;
         const long tp = (long)(bw.start + r) * W + c0 + cc;
         float g, n;
@@ -83,11 +85,12 @@ __global__ __launch_bounds__(256) void k_hist_stats(const float* __restrict__ q,
             if (v == v) { acc[b][0] += 1.0; acc[b][1] += (double)v; acc[b][2] += (double)v * (double)v; }
         }
     }
-    double* out = stats + ((long)wf * 2 + side) * 42;
+    double* out = stats + ((long)wf * 2 + side) * 42;       // zeroed by the caller
     for (int b = 0; b < 14; ++b)
         for (int k = 0; k < 3; ++k) {
-            const double s = block_sum(acc[b][k], red);
-            if (threadIdx.x == 0) out[b * 3 + k] = s;
+            double v = acc[b][k];
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+            if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&out[b * 3 + k], v);
         }
 }
 
@@ -142,20 +145,21 @@ __global__ __launch_bounds__(256) void k_hist_decide(const float* __restrict__ q
     if (threadIdx.x == 0) applied[wf] = take ? 1 : 0;
 }
 
-// frames [n][5][17][H+2][W+2]; frames 0..3 reflect-padded, frame 4 (medians) zero-padded, as model.hip expects
+// frames [n][5][17][plane]; frames 0..3 reflect-padded, frame 4 (medians) zero-padded, as model.hip expects.  H x W is the
+// window; tr: model.hip holds windows with more columns than rows transposed (plane = [W+2][H+2]).
 __global__ __launch_bounds__(256) void k_border_assemble(const float* __restrict__ q, const float* __restrict__ med,
                                                           const float* __restrict__ s1q, const float* __restrict__ s1med,
                                                           const float* __restrict__ dem, const float* __restrict__ aff, BTable bt,
-                                                          Norm17 nm, int H, int W, long npix, int half, float* __restrict__ frames,
-                                                          int* __restrict__ nonzero) {
+                                                          Norm17 nm, int H, int W, int tr, long npix, int half,
+                                                          float* __restrict__ frames, int* __restrict__ nonzero) {
 #pragma clang fp contract(off)
     const int f = blockIdx.y, w = blockIdx.z;
-    const int Wp = W + 2, PP = (H + 2) * Wp;
+    const int Wp = (tr ? H : W) + 2, PP = (H + 2) * (W + 2);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     bool nz = false;
     if (p < PP) {
         const int py = p / Wp, px = p - py * Wp;
-        const int wy = py - 1, wx = px - 1;
+        const int wy = (tr ? px : py) - 1, wx = (tr ? py : px) - 1;
         const bool border = wy < 0 || wy >= H || wx < 0 || wx >= W;
         const BWin bw = bt.w[w];
         const int row = bw.start + reflect_idx(reflect_idx(wy, H) - bw.pad0, bw.h);
@@ -374,7 +378,8 @@ ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s
       TTC_HIP(c, hipGetLastError()); }
     if (hist_align) {
         KTimer kt(c, "border_hist_align", s);
-        hipLaunchKernelGGL(k_hist_stats, dim3(n * 5, 2), dim3(256), 0, s, q, med, bt, W, npix, half, st);
+        TTC_HIP(c, hipMemsetAsync(st, 0, sizeof(double) * kMaxBW * 5 * 2 * 42, s));
+        hipLaunchKernelGGL(k_hist_stats, dim3(n * 5, 2, 16), dim3(256), 0, s, q, med, bt, W, npix, half, st);
         hipLaunchKernelGGL(k_hist_decide, dim3(n * 5), dim3(256), 0, s, q, med, bt, W, npix, half, (W - 14) / 2 + 7, st, aff, applied);
         TTC_HIP(c, hipGetLastError());
     }
@@ -388,7 +393,7 @@ ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s
     { KTimer kt(c, "border_assemble", s);
       const int PP = (H + 2) * (W + 2);
       hipLaunchKernelGGL(k_border_assemble, dim3((PP + 255) / 256, 5, n), dim3(256), 0, s, q, med, s1q, s1med, d_dem,
-                         hist_align ? aff : nullptr, bt, nm, H, W, npix, half, c->frames, flags);
+                         hist_align ? aff : nullptr, bt, nm, H, W, H < W ? 1 : 0, npix, half, c->frames, flags);
       TTC_HIP(c, hipGetLastError()); }
     TTC_CHECK(model_forward_frames(c, n, d_preds, s));
     { KTimer kt(c, "border_seam_adjust", s);

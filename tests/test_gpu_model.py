@@ -142,7 +142,7 @@ def test_rectangular_windows_match_oracle(H, W, L, N):
     assert tuple(gp.shape) == (N, H - 14, W - 14) and tuple(ge.shape) == (N, H, W, 64) and tuple(gl.shape) == (N, H - 14, W - 14, 64)
     fails = []
     for name, got, ref, tol in [("probs", gp.cpu().numpy(), probs[..., 0], PROB_TOL), ("early", ge.cpu().numpy(), early, 2e-5),
-                                ("late", gl.cpu().numpy(), late, 1e-4 if H * W < 100000 else 5e-4)]:    # values up to ~10 there
+                                ("late", gl.cpu().numpy(), late, 3e-4 if H * W < 100000 else 5e-4)]:    # values up to ~10 there
         ok, m = _cmp(name, got, ref, tol); ok or fails.append(m)
     assert not fails, "\n".join(fails)
     np.testing.assert_array_equal(ctx.forward_windows(x).cpu().numpy(), gp.cpu().numpy())

@@ -35,6 +35,10 @@ def oracle_model(seed=0):
 
 
 def device_feeds(sess, n, H, W):
+    """the model's input frames as [n, 5, H, W, 17]; windows with H < W are held transposed on the device (model.hip)"""
+    if H < W:
+        fr = sess.ctx.debug_fetch("frames", (n, 5, 17, W + 2, H + 2))
+        return np.transpose(fr[:, :, :, 1:-1, 1:-1], (0, 1, 4, 3, 2))
     fr = sess.ctx.debug_fetch("frames", (n, 5, 17, H + 2, W + 2))
     return np.transpose(fr[:, :, :, 1:-1, 1:-1], (0, 1, 3, 4, 2))
 

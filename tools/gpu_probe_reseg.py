@@ -1,0 +1,79 @@
+"""Timing probe for the border resegmentation at production size (SIZE = 670, SIZE_Y = 206, 618-row strip):
+python tools/gpu_probe_reseg.py [fp32|bf16x3]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+RSG = importlib.import_module("sentinel-tree-cover_amd.resegment")
+Wt = importlib.import_module("sentinel-tree-cover_amd.weights")
+from tests.helpers import synth_border_strip, synth_reseg_windows  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+sess = RSG.border_session(Wt.synth_weights(0), precision=prec)
+ctx = sess.ctx
+s2, dates, interp, s1, dem, left_all, right_all, min_clear = synth_border_strip(71, 618, 684, offset=0.05)
+ta, tf = RSG.border_windows(618, 618 - 335)
+d = [ctx._dev(v, torch.float32) for v in (s2, s1, dem)]
+rows = np.array([[0, 213, 7, 0], [131, 220, 0, 0], [269, 220, 0, 0], [405, 213, 0, 7]], np.int32)
+mn, mx = RSG.normalisation_vectors()
+for hist in (False, True):
+    for _ in range(2):
+        ctx.border_subtiles(d[0], d[1], d[2], rows, mn, mx, hist, 7)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.border_subtiles(d[0], d[1], d[2], rows, mn, mx, hist, 7)
+    torch.cuda.synchronize()
+    print(f"border_subtiles hist_align={hist} ({prec}): {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms for 4 windows of 220 x 684")
+ctx.timing(True)
+ctx.border_subtiles(d[0], d[1], d[2], rows, mn, mx, True, 7)
+torch.cuda.synchronize()
+names = ["border_medians", "border_hist_align", "border_assemble", "conv_gates", "conv_cand", "gru_apply1", "gru_apply2", "gn_finalize",
+         "block_finalize", "conv_median", "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out_conv", "head", "border_seam_adjust"]
+ms = {k: ctx.kernel_ms(k) for k in names}
+tot = sum(v[0] * v[1] for v in ms.values())
+for k, (avg, n) in sorted(ms.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+    print(f"  {k:22s} {avg * n:8.3f} ms  ({n} launches)")
+print(f"  total of timed kernels {tot:.2f} ms")
+ctx.timing(False)
+
+strip12 = ctx._dev(np.random.default_rng(0).uniform(0.02, 0.6, (12, 618, 684, 14)).astype(np.float32), torch.float32)
+for _ in range(2):
+    ctx.superresolve_windows(strip12, wsize=125)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3):
+    ctx.superresolve_windows(strip12, wsize=125)
+torch.cuda.synchronize()
+print(f"superresolve_windows 12 x 618 x 684 (125 px): {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms")
+raw = ctx._dev(np.random.default_rng(1).uniform(0.02, 0.6, (9, 618, 684, 10)).astype(np.float32), torch.float32)
+from importlib import import_module
+temporal = import_module("sentinel-tree-cover_amd.temporal")
+wm = temporal.temporal_operator(np.array([5, 40, 80, 120, 170, 210, 260, 300, 340]))
+for _ in range(2):
+    ctx.smooth_strip(raw, wm)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5):
+    ctx.smooth_strip(raw, wm)
+torch.cuda.synchronize()
+print(f"smooth_strip T=9 618 x 684: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
+
+wins = synth_reseg_windows(63, (618, 618), 670, 206, False)
+fmt = {"n": "{x}/{y}.npy", "l": "{x}/left{y}.npy", "r": "right{x}/{y}.npy", "u": "{x}/up{y}.npy", "d": "{x}/down{y}.npy"}
+paths = {fmt[k].format(x=x, y=y): p for k, x, y, p in wins}
+for _ in range(2):
+    RSG.recreate_resegmented_tifs(paths, (618, 618), sess)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3):
+    RSG.recreate_resegmented_tifs(paths, (618, 618), sess)
+torch.cuda.synchronize()
+print(f"recreate_resegmented_tifs 618^2, {len(paths)} windows (host tables + upload + kernel + download): {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms")
+ctx.timing(True)
+RSG.recreate_resegmented_tifs(paths, (618, 618), sess)
+torch.cuda.synchronize()
+print("  reseg_mosaic kernels (avg ms, launches):", ctx.kernel_ms("reseg_mosaic"))
