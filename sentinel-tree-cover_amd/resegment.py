@@ -329,14 +329,17 @@ def smooth_strip(s2, dates, sess):
 
 
 def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, size=SIZE, size_y=SIZE_Y, sampler="reference",
-                     forest_masks=(None, None), urban_masks=(None, None), return_strip=False):
+                     forest_masks=(None, None), urban_masks=(None, None), return_strip=False, neighb_is_strip=False):
     """The array flow of resegment_border (:847-1161, edge "right") for a tile and its right-hand neighbour that are both
     processed and show an artifact (check_if_artifact): `tile` / `neighb` = dicts with process_tile's outputs {s2 [T, X, Y, 10],
     dates, interp, s1 [12, X, Y, 2], dem [X, Y]} (+ clm: Sen2Cor mask at 10 m or None), numpy or cuda; tile_tif / neighbor_tif
     the existing rasters (float, NaN = no data).  `sess` = border_session(...) with DSen2 weights loaded.
+    neighb_is_strip: `neighb` already holds only its first size//2 + 7 columns (shard.exchange_border_strips: the tile lives
+    on another GPU); in the per-tile branch it must then also be preprocessed already (its owner ran preprocess_tile).
     -> ({path: window} as process_subtiles, info)"""
     ctx, t = sess.ctx, sess.ctx.torch
     dev = lambda v: ctx._dev(v, t.float32)                                  # noqa: E731
+    cut_n = (lambda *v: v + (None,)) if neighb_is_strip else (lambda *v: split_to_border(*v, "neighbor", size=size))
     a = {k: (dev(v) if k != "dates" and v is not None else v) for k, v in tile.items()}
     b = {k: (dev(v) if k != "dates" and v is not None else v) for k, v in neighb.items()}
     dates, dates_n = np.array(a["dates"]), np.array(b["dates"])
@@ -344,9 +347,9 @@ def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, si
     half = (size + 14) // 2
     if min_images >= 3:                                                     # shared preprocessing of the strip, :906-1001
         s2, _, s1, dem, tiles_x = split_to_border(a["s2"], a["interp"], a["s1"], a["dem"], "tile", size=size)
-        s2n, _, s1n, dem_n, _ = split_to_border(b["s2"], b["interp"], b["s1"], b["dem"], "neighbor", size=size)
+        s2n, _, s1n, dem_n, _ = cut_n(b["s2"], b["interp"], b["s1"], b["dem"])
         clm = split_fn(a["clm"], "tile", size)[0] if a.get("clm") is not None else None
-        clm_n = split_fn(b["clm"], "neighbor", size)[0] if b.get("clm") is not None else None
+        clm_n = (b["clm"] if neighb_is_strip else split_fn(b["clm"], "neighbor", size)[0]) if b.get("clm") is not None else None
         rm_t, rm_n, _ = align_dates(dates, dates_n)
         s2, clm, dates = _drop(t, s2, rm_t), _drop(t, clm, rm_t), np.delete(dates, rm_t)
         s2n, clm_n, dates_n = _drop(t, s2n, rm_n), _drop(t, clm_n, rm_n), np.delete(dates_n, rm_n)
@@ -363,9 +366,12 @@ def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, si
         s2, interp, dates = preprocess_tile(a["s2"], dates, a["interp"], a.get("clm"), "tile", a["dem"], None, sess, sampler,
                                             forest_masks[0], urban_masks[0])
         s2, interp, s1, dem, tiles_x = split_to_border(s2, interp, a["s1"], a["dem"], "tile", size=size)
-        s2n, interp_n, dates_n = preprocess_tile(b["s2"], dates_n, b["interp"], b.get("clm"), "neighbor", b["dem"], None, sess, sampler,
-                                                 forest_masks[1], urban_masks[1])
-        s2n, interp_n, s1n, dem_n, _ = split_to_border(s2n, interp_n, b["s1"], b["dem"], "neighbor", size=size)
+        if neighb_is_strip:
+            s2n, interp_n = b["s2"], b["interp"]
+        else:
+            s2n, interp_n, dates_n = preprocess_tile(b["s2"], dates_n, b["interp"], b.get("clm"), "neighbor", b["dem"], None, sess, sampler,
+                                                     forest_masks[1], urban_masks[1])
+        s2n, interp_n, s1n, dem_n, _ = cut_n(s2n, interp_n, b["s1"], b["dem"])
         rm_t, rm_n, min_images = align_dates(dates, dates_n)
         min_clear = t.cat([(interp[..., -half:] != 1).sum(dim=0), (interp_n[..., :half] != 1).sum(dim=0)], dim=1)
         if min_images >= min_dates:

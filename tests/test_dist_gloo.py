@@ -58,3 +58,44 @@ def test_single_rank_is_passthrough():
     assert shard.gather_rasters(r, 0, 1)[0] is r
     assert shard.tiles_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
     assert shard.max_over_ranks(0.5, "cpu", 1) == 0.5
+
+
+def _tile(tid, T, X=20, Y=40):
+    g = torch.Generator().manual_seed(100 + tid)
+    return {"s2": torch.rand((T, X, Y, 10), generator=g), "interp": torch.rand((T, X, Y), generator=g),
+            "s1": torch.rand((12, X, Y, 2), generator=g), "dem": torch.rand((X, Y), generator=g), "dates": [10 * tid + 3 * i for i in range(T)]}
+
+
+def _border_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_tiles, size = 5, 30                  # strips of size // 2 + 7 = 22 columns; tiles keep 3..7 dates
+        mine = {t: _tile(t, 3 + t) for t in shard.tiles_for_rank(n_tiles, rank, world)}
+        strips = shard.exchange_border_strips(mine, n_tiles, rank, world, size)
+        ok = {}
+        for t, st in strips.items():
+            want = shard.neighbour_strip(_tile(t + 1, 3 + t + 1), size)
+            ok[t] = all(torch.equal(st[k], want[k]) for k in ("s2", "interp", "s1", "dem")) and list(st["dates"]) == list(want["dates"])
+        out.put((rank, sorted(strips), ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_border_strip_exchange_two_ranks():
+    """resegmentation: the neighbour's border columns travel point-to-point to the rank that owns the border"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_border_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, b0, ok0), (r1, b1, ok1) = res
+    assert b0 == [0, 2] and b1 == [1, 3]                # border t belongs to the rank of tile t
+    assert all(ok0.values()) and all(ok1.values())
+    assert shard.borders_for_rank(5, 0, 1) == [0, 1, 2, 3]
+    one = shard.exchange_border_strips({t: _tile(t, 4) for t in range(3)}, 3, 0, 1, 30)
+    assert sorted(one) == [0, 1] and one[0]["s2"].shape == (4, 20, 22, 10)

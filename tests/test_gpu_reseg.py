@@ -285,3 +285,26 @@ def test_resegment_border_end_to_end(tag):
             print(f"[parity] window {name}: max {d.max():.3e} mean {d.mean():.3e}")
             assert d.max() < 3e-4 and d.mean() < 5e-6          # measured 4.3e-5 / 2e-7
     sess.close()
+
+
+def test_resegment_border_from_exchanged_strip():
+    """multi-GPU form: the neighbour arrives as the border strip shard.exchange_border_strips delivers"""
+    import random
+    from tests.test_oracle_reseg import border_case
+    from ttc import shard, weights as Wt
+    g = golden("reseg_border.npz")
+    tile, neighb, tt, tn, size, size_y = border_case(g, "s")
+    sess = RSG.border_session(Wt.synth_weights(0), size=size, size_y=size_y)
+    t = sess.ctx.torch
+    random.seed(11)
+    full, _ = RSG.resegment_border(tile, neighb, tt, tn, sess, size=size, size_y=size_y)
+    tiles = {0: {k: (t.from_numpy(np.ascontiguousarray(v)) if k != "dates" else list(v)) for k, v in tile.items()},
+             1: {k: (t.from_numpy(np.ascontiguousarray(v)) if k != "dates" else list(v)) for k, v in neighb.items()}}
+    strip = shard.exchange_border_strips(tiles, 2, 0, 1, size)[0]
+    assert strip["s2"].shape[2] == size // 2 + 7
+    random.seed(11)
+    part, _ = RSG.resegment_border(tile, strip, tt, tn, sess, size=size, size_y=size_y, neighb_is_strip=True)
+    assert sorted(full) == sorted(part)
+    for k in full:
+        np.testing.assert_array_equal(full[k], part[k])
+    sess.close()
