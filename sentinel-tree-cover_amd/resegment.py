@@ -13,6 +13,8 @@ The keep / skip rule of a re-predicted window (:534-613) is evaluated here from 
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 from . import job
@@ -192,6 +194,11 @@ def parse_window_path(path):
 
 
 def stack_ramps(X, Y, present, size=SIZE):
+    return _stack_ramps(int(X), int(Y), tuple(sorted(present)), int(size))
+
+
+@functools.lru_cache(maxsize=8)
+def _stack_ramps(X, Y, present, size):
     """The `m` maps of mosaic_subtiles (:1176-1236), float64 [5, X, Y]: how much each stack (n, l, r, u, d) counts
     against the others.  `present`: kinds that have windows (the reference's left / right / up / down flags)."""
     half = size // 2
@@ -222,6 +229,7 @@ def stack_ramps(X, Y, present, size=SIZE):
     return ramps
 
 
+@functools.lru_cache(maxsize=32)
 def _window_weights(kind, rows, cols):
     """the per-window blend weights (:1316-1318, :1347-1349 and siblings) for the part of the window that is used"""
     if kind == "n":
