@@ -300,6 +300,14 @@ ttc_status ttc_float_to_int16(ttc_ctx* ctx, const float* d_in, int64_t n, float 
  * median, convert_to_db(., 22) (job.py:74-89).  d_u16 [T, X, Y, 2] -> d_out [T, X, Y, 2] float32. */
 ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t X, int32_t Y, float* d_out, void* stream);
 
+/* ---- output file (host-side) -------------------------------
+ * == write_tif (src/downloading/io.py:229-263) without rasterio: h_raster [rows, cols] uint8 host memory, already in the
+ * file's orientation (write_tif transposes `arr`; load_mosaic_predictions' [Y, X] raster goes in after `.T` like there),
+ * bounds = point[0], point[1], point[2], point[3] (west, south, east, north).  Classic TIFF, LZW strips,
+ * ModelPixelScale / ModelTiepoint as rasterio.transform.from_bounds gives them, EPSG:4326 GeoKeys.  No context needed. */
+ttc_status ttc_write_geotiff_u8(const char* path, const uint8_t* h_raster, int32_t rows, int32_t cols, double west, double south,
+                                double east, double north);
+
 /* ---- introspection for parity tests -------------------------------------------------
  * Copies a named internal activation (device) to host after synchronising the device.
  * Returns TTC_ERR_ARG for unknown names; *n_floats is the element count.  Test aid only. */

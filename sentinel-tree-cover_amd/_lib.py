@@ -23,7 +23,7 @@ EXPORTS = [
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
-    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal",
+    "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -107,6 +107,18 @@ def load():
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def write_geotiff_u8(path, raster, west, south, east, north):
+    """ttc_write_geotiff_u8: raster uint8 [rows, cols] (numpy) -> LZW GeoTIFF at `path` (host-side, no GPU needed)"""
+    a = np.ascontiguousarray(raster, dtype=np.uint8)
+    lib = load()
+    lib.ttc_write_geotiff_u8.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
+    st = lib.ttc_write_geotiff_u8(str(path).encode(), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], float(west), float(south),
+                                  float(east), float(north))
+    if st != 0:
+        raise RuntimeError(f"ttc_write_geotiff_u8: status {st} ({path})")
+    return str(path)
 
 
 def _torch():

@@ -404,3 +404,11 @@ def predict_tile(s2, dates, interp, s1, dem, sess, size=SIZE, to_host=True):
     if to_host:
         return f32.cpu().numpy(), u8.cpu().numpy()
     return f32, u8
+
+
+def write_tif(arr, point, x, y, out_folder, suffix="_FINAL"):
+    """src/downloading/io.py:229-263 without rasterio: arr [X, Y] (any dtype castable to uint8) is transposed like there and
+    written as `{out_folder}{x}X{y}Y{suffix}.tif` -- LZW GeoTIFF, EPSG:4326, bounds point = [west, south, east, north]."""
+    file = f"{out_folder}{str(x)}X{str(y)}Y{suffix}.tif"
+    a = np.ascontiguousarray(np.asarray(arr).T.astype(np.uint8))
+    return _lib.write_geotiff_u8(file, a, west=point[0], south=point[1], east=point[2], north=point[3])

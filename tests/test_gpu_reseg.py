@@ -308,3 +308,27 @@ def test_resegment_border_from_exchanged_strip():
     for k in full:
         np.testing.assert_array_equal(full[k], part[k])
     sess.close()
+
+
+def test_preprocess_tile_with_sen2cor_mask():
+    """preprocess_tile (:619-672) with a Sen2Cor mask: merged into the detector's mask (false-positive pixels cleared
+    first), heavily masked dates dropped and the detection re-run, then the gap-fill"""
+    import random
+    from oracle import restate_reseg as O
+    from ttc import weights as Wt
+    T, X, Y = 7, 120, 112
+    img, dem, _, _, _ = synth.synth_detection_scene(93, T, X, Y)
+    dates = np.array([10, 45, 80, 130, 190, 250, 320])
+    clm = np.zeros((T, X, Y), np.float32)
+    clm[1, 20:60, 30:90] = 1.0
+    clm[3] = 1.0                                   # a fully masked date -> dropped by the 0.95 rule
+    sess = session(90, 134)
+    random.seed(5)
+    want_s2, want_interp, want_dates = O.preprocess_tile(img.copy(), dates.copy(), None, clm.copy(), (dem / 90).astype(np.float32))
+    random.seed(5)
+    s2, interp, got_dates = RSG.preprocess_tile(img.copy(), dates.copy(), None, clm.copy(), "tile", (dem / 90).astype(np.float32), None, sess)
+    np.testing.assert_array_equal(got_dates, want_dates)
+    assert len(got_dates) < T
+    np.testing.assert_allclose(interp.cpu().numpy(), want_interp, rtol=0, atol=1e-6)
+    e = np.abs(s2.cpu().numpy() - want_s2)
+    assert e.max() < 5e-4 and e.mean() < 1e-6
