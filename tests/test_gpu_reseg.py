@@ -332,3 +332,20 @@ def test_preprocess_tile_with_sen2cor_mask():
     np.testing.assert_allclose(interp.cpu().numpy(), want_interp, rtol=0, atol=1e-6)
     e = np.abs(s2.cpu().numpy() - want_s2)
     assert e.max() < 5e-4 and e.mean() < 1e-6
+
+
+def test_border_mosaic_constant_field_property():
+    """size-independent property at production size: every stack holds the same constant -> the blend returns it wherever
+    the reference's no-data rule lets a value through, whatever the Gaussian / ramp weights are"""
+    sess = session(90, 134)
+    wins = {}
+    for x in range(0, 618 - 158 + 1, 92):
+        for y in range(0, 618 - 158 + 1, 92):
+            wins[f"{x}/{y}.npy"] = np.full((158, 158), 0.37, np.float32)
+    for y in (0, 138, 276, 412):
+        wins[f"right283/{y}.npy"] = np.full((206, 670), 0.37, np.float32)
+        wins[f"0/left{y}.npy"] = np.full((206, 670), 0.37, np.float32)
+    out, sums = RSG.recreate_resegmented_tifs(wins, (618, 618), sess)
+    assert (out != 255).mean() > 0.99
+    np.testing.assert_allclose(out[out != 255], 37.0, rtol=0, atol=1e-4)
+    assert (sums[out != 255] > 0).all()
