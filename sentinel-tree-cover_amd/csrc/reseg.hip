@@ -154,11 +154,20 @@ __global__ __launch_bounds__(256) void k_border_assemble(const float* __restrict
                                                           float* __restrict__ frames, int* __restrict__ nonzero) {
 #pragma clang fp contract(off)
     const int f = blockIdx.y, w = blockIdx.z;
-    const int Wp = (tr ? H : W) + 2, PP = (H + 2) * (W + 2);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Wp = (tr ? H : W) + 2, Hp = (tr ? W : H) + 2, PP = (H + 2) * (W + 2);
+    int p, py, px;
+    if (tr) {
+        // one 8 x 8 patch of the plane per wave: the source is read as 8 runs of 8 neighbouring pixels (448 B each), the
+        // planes are written as 8 runs of 32 B -- a plain linear mapping would gather every source pixel from another row
+        const int npx = (Wp + 7) >> 3, gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), l = threadIdx.x & 63;
+        py = (gw / npx) * 8 + (l >> 3); px = (gw % npx) * 8 + (l & 7);
+        p = (py < Hp && px < Wp) ? py * Wp + px : PP;
+    } else {
+        p = blockIdx.x * blockDim.x + threadIdx.x;
+        py = p / Wp; px = p - py * Wp;
+    }
     bool nz = false;
     if (p < PP) {
-        const int py = p / Wp, px = p - py * Wp;
         const int wy = (tr ? px : py) - 1, wx = (tr ? py : px) - 1;
         const bool border = wy < 0 || wy >= H || wx < 0 || wx >= W;
         const BWin bw = bt.w[w];
@@ -391,9 +400,11 @@ ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s
         nm.half[i] = (h_max[i] - h_min[i]) / 2.0f;
     }
     { KTimer kt(c, "border_assemble", s);
-      const int PP = (H + 2) * (W + 2);
-      hipLaunchKernelGGL(k_border_assemble, dim3((PP + 255) / 256, 5, n), dim3(256), 0, s, q, med, s1q, s1med, d_dem,
-                         hist_align ? aff : nullptr, bt, nm, H, W, H < W ? 1 : 0, npix, half, c->frames, flags);
+      const int PP = (H + 2) * (W + 2), tr = H < W ? 1 : 0;
+      const int patches = ((H + 2 + 7) / 8) * ((W + 2 + 7) / 8);              // 8 x 8 patches, one per wave (transposed planes)
+      const int blocks = tr ? (patches + 3) / 4 : (PP + 255) / 256;
+      hipLaunchKernelGGL(k_border_assemble, dim3(blocks, 5, n), dim3(256), 0, s, q, med, s1q, s1med, d_dem,
+                         hist_align ? aff : nullptr, bt, nm, H, W, tr, npix, half, c->frames, flags);
       TTC_HIP(c, hipGetLastError()); }
     TTC_CHECK(model_forward_frames(c, n, d_preds, s));
     { KTimer kt(c, "border_seam_adjust", s);
