@@ -404,3 +404,51 @@ def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, si
     if return_strip:
         info.update(strip=strip, s1=s1, dem=dem)
     return wins, info
+
+
+# ---- one pair of tiles, as the job's main loop handles it (:1724-1826) -----------------------------------------------------
+def seam_difference(predictions_left, predictions_right):
+    """:1742-1748 -- mean |difference| of the 8-row means either side of the seam of the re-mosaicked rasters ([X, Y], 255 = no data)"""
+    import warnings
+    right = np.asarray(predictions_right)[:8, :].astype(np.float32)
+    left = np.asarray(predictions_left)[-8:, :].astype(np.float32)
+    right[right == 255] = np.nan
+    left[left == 255] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return np.nanmean(abs(np.nanmean(right, axis=0) - np.nanmean(left, axis=0)))
+
+
+def diff_for_compare(tile_tif, neighbor_tif):
+    """:872-873 -- the seam step of the EXISTING rasters (NaN = no data; plain means, as coded)"""
+    return np.mean(abs(np.mean(np.asarray(neighbor_tif)[:, :8], axis=1) - np.mean(np.asarray(tile_tif)[:, -8:], axis=1)))
+
+
+def resegment_pair(tile, neighb, tile_tif, neighbor_tif, windows_left, windows_right, sess, process_all=False, **kw):
+    """What the main loop does for one tile and its right-hand neighbour (:1724-1790) once everything is in memory:
+    artifact test on the existing rasters -> resegment_border -> both tiles re-mosaicked with the new border windows ->
+    keep the result unless the seam got more than 20 points worse.  windows_left / windows_right: the {path: window} dicts of
+    the two tiles' processed/ folders (plain windows).  tile_tif / neighbor_tif: uint8 or float rasters, > 100 = no data.
+    -> None when nothing had to be done / the result is rejected, else (predictions_left, predictions_right, info)."""
+    tt, tn = np.asarray(tile_tif, dtype=np.float32).copy(), np.asarray(neighbor_tif, dtype=np.float32).copy()
+    tt[tt > 100] = np.nan
+    tn[tn > 100] = np.nan
+    diff = diff_for_compare(tt, tn)
+    if not (check_if_artifact(tt, tn) == 1 or process_all):
+        return None
+    wins, info = resegment_border(tile, neighb, tt, tn, sess, **kw)
+    shape_l = (int(tile["s2"].shape[1]), int(tile["s2"].shape[2]))            # s2.shape[1:-1], as the reference passes it
+    shape_r = (int(neighb["s2"].shape[1]), int(neighb["s2"].shape[2]))
+    left = dict(windows_left)
+    left.update({k: v for k, v in wins.items() if k.startswith("right")})
+    right = dict(windows_right)
+    right.update({"0/" + k: v for k, v in wins.items() if k.startswith("left")})
+    size = kw.get("size", SIZE)
+    pl = recreate_resegmented_tifs(left, shape_l, sess, size=size, return_sums=False)
+    pr = recreate_resegmented_tifs(right, shape_r, sess, size=size, return_sums=False)
+    smooth = seam_difference(pl, pr)
+    diff = 100 if np.isnan(diff) else diff
+    info.update(diff_for_compare=float(diff), smooth_diff=float(smooth))
+    if smooth < (diff + 20) or np.isnan(smooth):
+        return pl, pr, info
+    return None

@@ -349,3 +349,29 @@ def test_border_mosaic_constant_field_property():
     assert (out != 255).mean() > 0.99
     np.testing.assert_allclose(out[out != 255], 37.0, rtol=0, atol=1e-4)
     assert (sums[out != 255] > 0).all()
+
+
+def test_resegment_pair_flow():
+    """main-loop flow for one pair (:1724-1790): artifact test, border windows, both mosaics, acceptance rule"""
+    import random
+    from tests.test_oracle_reseg import border_case
+    from tests.helpers import synth_border_pair
+    from ttc import weights as Wt
+    g = golden("reseg_border.npz")
+    seed, T, X, Y, size, size_y, same = (int(v) for v in g["s_cfg"])
+    tile, neighb, tif_t, tif_n = synth_border_pair(seed, T, X, Y, bool(same))
+    sess = RSG.border_session(Wt.synth_weights(0), size=size, size_y=size_y)
+    rng = np.random.default_rng(0)
+    # the mosaic is [shape[1], shape[0]] = [Y, X]: the folder name indexes the tile's second axis (job.py:1362 / :1578)
+    plain = {f"{a}/{b}.npy": np.clip(rng.random((48, 48)), 0, 1).astype(np.float32)
+             for a in list(range(0, Y - 48, 34)) + [Y - 48] for b in list(range(0, X - 48, 34)) + [X - 48]}
+    flat = np.full((X, Y), 40, np.uint8)
+    assert RSG.resegment_pair(tile, neighb, flat, flat, plain, plain, sess, size=size, size_y=size_y) is None      # no artifact
+    random.seed(11)
+    got = RSG.resegment_pair(tile, neighb, tif_t, np.clip(tif_n.astype(np.int32) + 30, 0, 100).astype(np.uint8), plain, plain, sess,
+                             size=size, size_y=size_y)
+    assert got is not None
+    pl, pr, info = got
+    assert pl.shape == (Y, X) and pr.shape == (Y, X) and info["smooth_diff"] < info["diff_for_compare"] + 20
+    assert (pl != 255).mean() > 0.9 and pl[pl != 255].max() <= 100.0
+    sess.close()
