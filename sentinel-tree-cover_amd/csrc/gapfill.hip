@@ -891,42 +891,47 @@ __global__ void k_sel_init_dates(SelState* __restrict__ st, const int* __restric
     SelState ss; ss.prefix = 0; ss.mask = 0; ss.k = n > 0 ? (n - 1) / 2 : 0;
     st[q] = ss;
 }
-// LDS histogram update with run-length aggregation: neighbouring pixels mostly share the high key bytes, and 64 lanes
-// adding to ONE LDS word serialise (the top-byte pass cost 250-1000 us per launch that way).  A lane whose bin differs
-// from its predecessor's heads a run and adds the run length once.
-__device__ __forceinline__ void hist_add_runs(unsigned* h, int bin /* < 0 = lane does not contribute */) {
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(bin, 1);
-    const bool head = lane == 0 || prev != bin;
-    const unsigned long long heads = __ballot(head);
-    if (head && bin >= 0) {
-        const unsigned long long rest = lane == 63 ? 0ull : (heads >> (lane + 1));
-        const int len = rest ? __ffsll((long long)rest) : 64 - lane;
-        atomicAdd(&h[bin], (unsigned)len);
-    }
-}
-__global__ void k_hist_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
-                           int npix, const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
+// One radix-select pass for the 20 problems (10 bands x {reference, date}) of date blockIdx.y.  Histograms live in LDS;
+// a lane aggregates its OWN consecutive hits of one bin in registers and touches LDS only when the bin changes: on the high
+// passes reflectances share their top key bytes from pixel to pixel (a handful of bins), on the low passes few keys still match
+// the prefix -- either way almost no atomics, and no wave collectives.
+__global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ ref_all, const float* __restrict__ tiles,
+                                                   const unsigned* __restrict__ vmask, int npix, const SelState* __restrict__ st,
+                                                   int shift, unsigned* __restrict__ hist) {
     __shared__ unsigned h[20 * 256];
     __shared__ unsigned pf[20], mk[20];
     const int i = blockIdx.y;
     for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x) h[k] = 0;
     if (threadIdx.x < 20) { pf[threadIdx.x] = st[i * 20 + threadIdx.x].prefix; mk[threadIdx.x] = st[i * 20 + threadIdx.x].mask; }
     __syncthreads();
-    const int stride = gridDim.x * blockDim.x;
-    for (int p0 = blockIdx.x * blockDim.x; p0 < npix; p0 += stride) {       // block-uniform trip count (wave collectives inside)
-        const int p = p0 + threadIdx.x;
-        const bool valid = p < npix && ((vmask[p] >> i) & 1u);
-        const float* r = ref_all + ((long)i * npix + (valid ? p : 0)) * 10;
-        const float* sv = tiles + ((long)i * npix + (valid ? p : 0)) * 10;
+    int cur[20];
+    unsigned cnt[20];
 #pragma unroll
-        for (int ch = 0; ch < 10; ++ch) {
-            const unsigned k0 = fkey(r[ch]), k1 = fkey(sv[ch]);
-            const bool in0 = valid && (k0 & mk[2 * ch]) == pf[2 * ch], in1 = valid && (k1 & mk[2 * ch + 1]) == pf[2 * ch + 1];
-            hist_add_runs(h + (2 * ch) * 256, in0 ? (int)((k0 >> shift) & 255u) : -1);
-            hist_add_runs(h + (2 * ch + 1) * 256, in1 ? (int)((k1 >> shift) & 255u) : -1);
+    for (int q = 0; q < 20; ++q) { cur[q] = -1; cnt[q] = 0; }
+    const int stride = gridDim.x * blockDim.x;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        if (!((vmask[p] >> i) & 1u)) continue;
+        const float2* r = reinterpret_cast<const float2*>(ref_all + ((long)i * npix + p) * 10);
+        const float2* sv = reinterpret_cast<const float2*>(tiles + ((long)i * npix + p) * 10);
+#pragma unroll
+        for (int c2 = 0; c2 < 5; ++c2) {
+            const float2 a = r[c2], b = sv[c2];
+            const float v[4] = {a.x, b.x, a.y, b.y};         // problems 4*c2 .. 4*c2 + 3 = (ch, ref), (ch, date), (ch+1, ref), (ch+1, date)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 4 * c2 + j;
+                const unsigned k = fkey(v[j]);
+                if ((k & mk[q]) != pf[q]) continue;
+                const int bin = (int)((k >> shift) & 255u);
+                if (bin == cur[q]) { cnt[q]++; continue; }
+                if (cnt[q]) atomicAdd(&h[q * 256 + cur[q]], cnt[q]);
+                cur[q] = bin; cnt[q] = 1;
+            }
         }
     }
+#pragma unroll
+    for (int q = 0; q < 20; ++q)
+        if (cnt[q]) atomicAdd(&h[q * 256 + cur[q]], cnt[q]);
     __syncthreads();
     for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x)
         if (h[k]) atomicAdd(&hist[(long)i * 20 * 256 + k], h[k]);
