@@ -61,7 +61,6 @@ __global__ __launch_bounds__(256) void k_hist_stats(const float* __restrict__ q,
     const int wf = blockIdx.x, w = wf / 5, f = wf - 5 * w, side = blockIdx.y;
     const BWin bw = bt.w[w];
     const int c0 = side ? half : 0, nc = side ? W - half : half;
-    // gridDim.z row chunks per (window, frame, half): 40 workgroups alone would leave most of the chip idle
     const int rows_per = (bw.h + gridDim.z - 1) / gridDim.z;
     const int r0 = blockIdx.z * rows_per, r1 = min(bw.h, r0 + rows_per);
     double acc[14][3];
@@ -85,18 +84,19 @@ __global__ __launch_bounds__(256) void k_hist_stats(const float* __restrict__ q,
             if (v == v) { acc[b][0] += 1.0; acc[b][1] += (double)v; acc[b][2] += (double)v * (double)v; }
         }
     }
-    double* out = stats + ((long)wf * 2 + side) * 42;       // zeroed by the caller
+    // one partial per row chunk, summed in chunk order by k_hist_decide: the result does not depend on scheduling
+    __shared__ double red[4];
+    double* out = stats + (((long)wf * 2 + side) * gridDim.z + blockIdx.z) * 42;
     for (int b = 0; b < 14; ++b)
         for (int k = 0; k < 3; ++k) {
-            double v = acc[b][k];
-            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-            if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&out[b * 3 + k], v);
+            const double v = block_sum(acc[b][k], red);
+            if (threadIdx.x == 0) out[b * 3 + k] = v;
         }
 }
 
 // aff [(w*5 + f)][side][14][2] = (mult, add) applied to columns of that side; (1, 0) when the alignment is rejected
 __global__ __launch_bounds__(256) void k_hist_decide(const float* __restrict__ q, const float* __restrict__ med, BTable bt, int W,
-                                                      long npix, int half, int seam_col, const double* __restrict__ stats,
+                                                      long npix, int half, int seam_col, const double* __restrict__ stats, int nchunk,
                                                       float* __restrict__ aff, int* __restrict__ applied) {
 #pragma clang fp contract(off)
     __shared__ double red[4];
@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256) void k_hist_decide(const float* __restrict__ q
         const int b = threadIdx.x;
         float mean[2], sd[2];
         for (int side = 0; side < 2; ++side) {
-            const double* s = stats + ((long)wf * 2 + side) * 42 + b * 3;
+            double s[3] = {0.0, 0.0, 0.0};
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const double* p = stats + (((long)wf * 2 + side) * nchunk + ch) * 42 + b * 3;
+                s[0] += p[0]; s[1] += p[1]; s[2] += p[2];
+            }
             const double m = s[1] / s[0];
             double var = s[2] / s[0] - m * m;
             if (var < 0) var = 0;
@@ -371,7 +375,8 @@ ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s
     float* med = static_cast<float*>(c->scratch_buf("bs_med", sizeof(float) * 14 * npix));
     float* s1q = static_cast<float*>(c->scratch_buf("bs_s1q", sizeof(float) * 4 * 2 * npix));
     float* s1med = static_cast<float*>(c->scratch_buf("bs_s1med", sizeof(float) * 2 * npix));
-    double* st = static_cast<double*>(c->scratch_buf("bs_stats", sizeof(double) * kMaxBW * 5 * 2 * 42));
+    constexpr int kHistChunks = 16;     // row chunks per (window, frame, half): 40 workgroups alone would leave the chip idle
+    double* st = static_cast<double*>(c->scratch_buf("bs_stats", sizeof(double) * kMaxBW * 5 * 2 * kHistChunks * 42));
     float* aff = static_cast<float*>(c->scratch_buf("bs_aff", sizeof(float) * kMaxBW * 5 * 2 * 14 * 2));
     int* flags = static_cast<int*>(c->scratch_buf("bs_flags", sizeof(int) * (kMaxBW + kMaxBW * 5)));
     float* dstats = static_cast<float*>(c->scratch_buf("bs_dstats", sizeof(float) * kMaxBW * 4));
@@ -387,9 +392,9 @@ ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s
       TTC_HIP(c, hipGetLastError()); }
     if (hist_align) {
         KTimer kt(c, "border_hist_align", s);
-        TTC_HIP(c, hipMemsetAsync(st, 0, sizeof(double) * kMaxBW * 5 * 2 * 42, s));
-        hipLaunchKernelGGL(k_hist_stats, dim3(n * 5, 2, 16), dim3(256), 0, s, q, med, bt, W, npix, half, st);
-        hipLaunchKernelGGL(k_hist_decide, dim3(n * 5), dim3(256), 0, s, q, med, bt, W, npix, half, (W - 14) / 2 + 7, st, aff, applied);
+        hipLaunchKernelGGL(k_hist_stats, dim3(n * 5, 2, kHistChunks), dim3(256), 0, s, q, med, bt, W, npix, half, st);
+        hipLaunchKernelGGL(k_hist_decide, dim3(n * 5), dim3(256), 0, s, q, med, bt, W, npix, half, (W - 14) / 2 + 7, st, kHistChunks,
+                           aff, applied);
         TTC_HIP(c, hipGetLastError());
     }
     Norm17 nm{};
