@@ -747,7 +747,7 @@ __global__ void k_cloud_thresholds(const SelState* __restrict__ st, const int* _
 // a6 ------------------------------------------------------------------------------------------------
 ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y, int closing, int clip, float* d_w,
                            hipStream_t s) {
-    if (!d_mask || !d_w || T < 1) return c->fail(TTC_ERR_ARG, "feather: bad argument");
+    if (!d_mask || !d_w || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "feather: bad argument (T in [1,32])");
     if (closing != 15 && closing != 20) return c->fail(TTC_ERR_ARG, "feather: closing must be 15 or 20");
     const long npix = (long)X * Y;
     unsigned short* g2 = static_cast<unsigned short*>(c->scratch_buf("gf_g2", sizeof(unsigned short) * T * npix));

@@ -37,6 +37,14 @@ def test_feather_weights_match_reference(sess):
         np.testing.assert_array_equal(got, G.feather_stack(m, closing, clip=closing == 15))
 
 
+def test_feather_rejects_more_than_32_dates(sess):
+    """the per-date counters of the feather kernels hold 32 dates: T = 33 must fail cleanly, not write out of bounds"""
+    m = np.zeros((33, 16, 16), np.float32)
+    with pytest.raises(RuntimeError, match="T in"):
+        sess.ctx.feather(m, closing=20)
+    assert sess.ctx.feather(m[:32], closing=20).shape == (32, 16, 16)
+
+
 def test_aligned_mosaic_matches_reference(sess):
     import torch
     from oracle import restate_gapfill as G

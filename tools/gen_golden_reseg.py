@@ -66,6 +66,7 @@ def main():
     J, CR = ref_harness.load()
     import resegment_tiles_wide as RS
     scratch = tempfile.mkdtemp(prefix="ttc_reseg_") + "/"
+    os.chdir(scratch)      # the reference's cloud_removal np.save()s debug arrays into the CWD (cloud_removal.py:927-929, :972)
     RS.args = types.SimpleNamespace(local_path=scratch, year=2020)
     RS.x, RS.y = "10", "20"
     RS.predict_logits, RS.predict_inp, RS.predict_length = "logits", "inp", "len"
@@ -176,6 +177,7 @@ def main():
         print("mosaic", tag, preds.shape, float(np.mean(preds == 255)), float(np.nanmean(np.where(preds == 255, np.nan, preds))))
     np.savez_compressed(os.path.join(OUT, "reseg_mosaic.npz"), **mo)
 
+    os.chdir(ROOT)
     shutil.rmtree(scratch, ignore_errors=True)
     for fn in sorted(os.listdir(OUT)):
         if fn.startswith("reseg"):
@@ -192,6 +194,7 @@ def gen_border(tags=("s", "d")):
     J, CR = ref_harness.load()
     import resegment_tiles_wide as RS
     scratch = tempfile.mkdtemp(prefix="ttc_resegb_") + "/"
+    os.chdir(scratch)      # keep the reference's debug dumps (tiles.npy, mosaic.npy, ...) out of the repository
     RS.args = types.SimpleNamespace(local_path=scratch, year=2020, process_all=True, resmooth=False, s3_bucket="none")
     RS.x, RS.y = "10", "20"
     RS.predict_logits, RS.predict_inp, RS.predict_length = "logits", "inp", "len"
@@ -259,6 +262,7 @@ def gen_border(tags=("s", "d")):
                 out[f"{tag}_preds{t}"] = np.asarray(np.load(p1), dtype=np.float32)
         print("border", tag, res[0], res[4], cap["strip"].shape, cap["dates"], cap["hist_align"], [bool(out[f"{tag}_saved{t}"]) for t in range(len(cap["tf"]))])
     np.savez_compressed(os.path.join(OUT, "reseg_border.npz"), **out)
+    os.chdir(ROOT)
     shutil.rmtree(scratch, ignore_errors=True)
     print("reseg_border.npz", os.path.getsize(os.path.join(OUT, "reseg_border.npz")) // 1024, "KB")
 
