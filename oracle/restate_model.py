@@ -29,7 +29,7 @@ BLOCKS = [  # name, cin, cout  (F = base filters = 64)
 ]
 
 
-def synth_weights(seed=0, n_in=17, hidden=32, dtype=np.float32):
+def synth_weights(seed=0, n_in=17, hidden=32, dtype=np.float32, stored_scale=False):
     """Seeded synthetic weights with the shapes of models-release/master-ckpt-nonfrozen/-0.meta
     (SURVEY.md A.1).  Conv kernels ~ He-normal then weight-standardised like WSConv2D
     (model.py:384-390); gamma/beta perturbed around 1/0 so GN affine is exercised."""
@@ -55,7 +55,7 @@ def synth_weights(seed=0, n_in=17, hidden=32, dtype=np.float32):
     for name, cin, cout in BLOCKS:
         # stored WS kernels are already standardised (std 1 per output channel); scale them
         # down so activations stay O(1) through the stack like a trained net's do after GN
-        w[name + "/kernel"] = ws(he((3, 3, cin, cout))) / np.sqrt(9.0 * cin)
+        w[name + "/kernel"] = ws(he((3, 3, cin, cout))) / (1.0 if stored_scale else np.sqrt(9.0 * cin))
         w[name + "/gamma"] = 1.0 + 0.1 * rng.standard_normal(cout)
         w[name + "/beta"] = 0.1 * rng.standard_normal(cout)
         w[name + "/sse_kernel"] = rng.standard_normal((1, 1, cout, 1)) * (1.0 / np.sqrt(cout))

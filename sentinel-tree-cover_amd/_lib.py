@@ -32,7 +32,14 @@ SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C
 class TTCConfig(C.Structure):
     _fields_ = [("win_in", C.c_int32), ("length", C.c_int32), ("max_windows", C.c_int32),
                 ("n_bands", C.c_int32), ("hidden", C.c_int32), ("base_filters", C.c_int32),
-                ("zoneout", C.c_float), ("precision", C.c_int32), ("win_rows", C.c_int32)]
+                ("zoneout", C.c_float), ("precision", C.c_int32), ("win_rows", C.c_int32),
+                ("one_term_layers", C.c_uint32)]
+
+
+# ttc_config.precision values and the default per-layer map of the 16-bit engine (ttc.h): fp16 runs the ConvGRU gates
+# conv (bit 0) with plain fp16 operands, every other conv with three split products; bf16 needs three everywhere
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16": 3}
+DEFAULT_ONE_TERM = {0: 0, 1: 0, 2: 0x1, 3: 0}
 
 
 class TTCResegWindow(C.Structure):
@@ -147,10 +154,14 @@ def pack_tensors(weights: dict):
 class Context:
     """One libttc context: (device, window geometry, weights, workspace)."""
 
-    def __init__(self, win_in=172, length=4, max_windows=36, device=0, zoneout=0.75, precision=0, win_rows=0):
+    def __init__(self, win_in=172, length=4, max_windows=36, device=0, zoneout=0.75, precision=0, win_rows=0,
+                 one_term_layers=None):
         self.lib = load()
         self.torch = _torch()
-        self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision, win_rows)
+        precision = PRECISIONS.get(precision, precision)
+        if one_term_layers is None:
+            one_term_layers = DEFAULT_ONE_TERM[precision]
+        self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision, win_rows, one_term_layers)
         self.device = device
         self._h = C.c_void_p()
         st = self.lib.ttc_create(C.byref(self._h), device, C.byref(self.cfg))

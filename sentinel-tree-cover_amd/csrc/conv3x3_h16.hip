@@ -1,0 +1,460 @@
+// Implicit-GEMM 3x3 convolution on the gfx950 16-bit matrix cores (v_mfma_f32_32x32x16_f16 / _bf16, fp32 accumulate),
+// fed by CHANNEL-BLOCKED 16-bit activations that their producers already wrote in MFMA operand order.
+// ttc_config.precision = 2 (fp16 elements) or 3 (bf16 elements); replaces the tf.nn.convolution / Conv2D nodes of the two
+// reference graphs (src/train/src/model.py:251, :276, :416-442; superresolve_graph.pb) like the fp32 engine does.
+//
+// Operands.  x = x_hi + x_lo with two 16-bit elements (fp16 pair: 22 mantissa bits, bf16 pair: 16), weights likewise
+// (split on the host).  A layer runs with TERMS = 3 products per K block,
+//     x * w ~= x_lo*w_hi + x_hi*w_lo + x_hi*w_hi          (drops x_lo*w_lo ~ 2^-22 relative for fp16),
+// or TERMS = 1 (x_hi*w_hi: plain 16-bit operands, 2^-11 relative for fp16) where the per-layer precision map allows it
+// (tools/study/precision_study.py: only the ConvGRU gates conv tolerates it inside the 1e-3 probability contract).
+//
+// Layout.  Activations in HBM: [n][C8][Hp*Wp][8 ch] 16-bit, one 16-byte K vector per (channel block, position), hi and lo
+// tensors.  Same "flattened padded plane" formulation as conv3x3_mfma.hip: a workgroup (4 waves) owns 512 consecutive
+// positions q of one window x BN = 32*NCG output channels; a tap is a linear offset.  Per 8-channel chunk the tile
+// [512 + 2*Wp + 2 positions][16 B] is ONE contiguous run of the blocked tensor, so staging is nothing but
+// global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPRs, no VALU, no ds_write): the LDS image is lane-linear
+// and consecutive positions are consecutive 16-byte slots, which ds_read_b128's 16-lane groups read conflict-free.
+// Weights: host-packed LDS image [tap][cout][8 ch] per chunk and plane, copied the same way.
+// One MFMA K block (16) = the 8 channels of TWO taps (half-wave 0: tap 2*kb, half-wave 1: tap 2*kb+1; the tenth tap
+// half has a zero A operand): 5 K blocks per chunk.
+//
+// Schedule (2 workgroups per CU, <= 80 KB LDS each):
+//   TERMS = 1: 3-stage LDS ring, prefetch distance 2, ONE barrier per chunk, counted vmcnt (the DMA of chunk c+1 stays
+//              in flight across the barrier).
+//   TERMS = 3: hi tiles double-buffered, lo tile single (it is read by one of the three products only: that product
+//              runs first, a mid-chunk barrier frees the buffer and the next chunk's lo tile streams in under the other
+//              two products), weights (hi | lo) double-buffered.
+#include "h16_common.h"
+
+using namespace ttcconv;
+
+#ifndef TTC_H16_ABL
+#define TTC_H16_ABL 0     // probe builds only: 1 no output stores, 3 no MFMA
+#endif
+
+namespace {
+
+constexpr int kKB = 5;                      // K blocks per 8-channel chunk (tap pairs)
+
+// raw s_barrier (no vmcnt drain: LDS-DMA stays in flight across it) fenced against compiler reordering of LDS accesses
+__device__ __forceinline__ void cbarrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+#define TTC_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        TTC_W(1) TTC_W(2) TTC_W(3) TTC_W(4) TTC_W(5) TTC_W(6) TTC_W(7) TTC_W(8) TTC_W(9) TTC_W(10) TTC_W(11) TTC_W(12)
+        TTC_W(13) TTC_W(14) TTC_W(15) TTC_W(16)
+#undef TTC_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // 0 and anything unexpected: wait for all
+    }
+}
+
+// fused epilogue of the OUT_B16 kernels: EPI op, then the fp32 accumulators leave as channel-blocked 16-bit hi (+ lo)
+// K vectors in the consumer's padded plane.  A lane holds 4 of a block's 8 channels (rows (r & 3) + 8 * (r >> 2) + 4 * hi):
+// v_permlane32_swap exchanges halves between lane and lane + 32, after which the low half-wave owns channel block 2k
+// and the high half-wave block 2k + 1 of 32 consecutive positions -> 512 contiguous bytes per half-wave and store.
+template <bool BF, int NCG, int EPI>
+__device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)[NCG][kQG], int n, int cb, int bq, int nblk_q,
+                                                 const float* aux, int tid) {
+    using E = Elem<BF>;
+    constexpr int BN = NCG * 32;
+    const ConvArgs& c = a.c;
+    const int Wp = c.Wp, Hp = c.Hp;
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int q0 = bq * kBQ;
+    const int Hout = Hp - 2, Wout = Wp - 2;
+    const int C8out = (c.Cout + 7) >> 3;
+    float ssum[NCG][4], ssq[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ssum[g][k] = 0.f; ssq[g][k] = 0.f; }
+    uint4* ohi = a.o_hi + (long)n * a.o_stride_n;
+    uint4* olo = a.o_lo ? a.o_lo + (long)n * a.o_stride_n : nullptr;
+    const uint2* rhi = (EPI == EPI_BIAS_RES) ? reinterpret_cast<const uint2*>(a.r_hi + (long)n * a.o_stride_n) : nullptr;
+    const uint2* rlo = (EPI == EPI_BIAS_RES) ? reinterpret_cast<const uint2*>(a.r_lo + (long)n * a.o_stride_n) : nullptr;
+
+#pragma unroll
+    for (int j = 0; j < kQG; ++j) {
+        const int q = q0 + (wave * kQG + j) * 32 + lo;
+        const int y = q / Wp, x = q - y * Wp;
+        const bool valid = (x < Wout) && (y < Hout);
+        const long opix = (long)(y + c.oy) * c.out_pitch + (x + c.ox);
+        long dup_y = 0, dup_x = 0;
+        bool any_dup = false;
+        if (EPI >= EPI_BIAS && c.reflect_out) {
+            if (valid) {
+                dup_y = (y == 1) ? -2L * c.out_pitch : ((y == Hout - 2) ? 2L * c.out_pitch : 0L);
+                dup_x = (x == 1) ? -2L : ((x == Wout - 2) ? 2L : 0L);
+            }
+            any_dup = __any((dup_y != 0) || (dup_x != 0));
+        }
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            float v[16];
+            if (EPI == EPI_BIAS_RES) {
+                // residual x = hi + lo of this lane's own 4 channels per block: 8-byte halves of the blocked K vectors
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int blk = cb * (BN / 8) + g * 4 + k;
+                    const bool ok = valid && (blk < C8out);
+                    const long u = ok ? ((long)blk * a.o_plane + opix) * 2 + hi : 0L;
+                    const uint2 h2 = rhi[u], l2 = rlo[u];
+                    float t0, t1;
+                    E::unpack2(h2.x, v[4 * k + 0], v[4 * k + 1]); E::unpack2(l2.x, t0, t1); v[4 * k + 0] += t0; v[4 * k + 1] += t1;
+                    E::unpack2(h2.y, v[4 * k + 2], v[4 * k + 3]); E::unpack2(l2.y, t0, t1); v[4 * k + 2] += t0; v[4 * k + 3] += t1;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float t = acc[g][j][r];
+                if (EPI >= EPI_BIAS) {
+                    if (co < c.Cout) t += aux[co];
+                    if (EPI == EPI_BIAS_RELU) t = fmaxf(t, 0.f);
+                    if (EPI == EPI_BIAS_RES) t = v[r] + 0.1f * t;
+                }
+                if (co >= c.Cout) t = 0.f;                      // pad channels of the last block stay zero
+                v[r] = t;
+                if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += t; ssq[g][r >> 2] += t * t; }
+            }
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {                    // block pairs (2kp, 2kp + 1) of this cout group
+                unsigned xl0, xl1, yl0, yl1;
+                unsigned xh0 = E::pack2(v[8 * kp + 0], v[8 * kp + 1], xl0), xh1 = E::pack2(v[8 * kp + 2], v[8 * kp + 3], xl1);
+                unsigned yh0 = E::pack2(v[8 * kp + 4], v[8 * kp + 5], yl0), yh1 = E::pack2(v[8 * kp + 6], v[8 * kp + 7], yl1);
+                // lanes 32-63 of X <-> lanes 0-31 of Y: afterwards [X | Y] = the 8 channels of block 2kp + hi
+                auto s0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false); xh0 = s0[0]; yh0 = s0[1];
+                auto s1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false); xh1 = s1[0]; yh1 = s1[1];
+                const int blk = cb * (BN / 8) + g * 4 + 2 * kp + hi;
+                const bool ok = valid && (blk < C8out);
+                const long u = (long)blk * a.o_plane + opix;
+                const uint4 vh = make_uint4(xh0, xh1, yh0, yh1);
+                if (ok) {
+                    ohi[u] = vh;
+                    if (any_dup) {
+                        if (dup_y) ohi[u + dup_y] = vh;
+                        if (dup_x) ohi[u + dup_x] = vh;
+                        if (dup_y && dup_x) ohi[u + dup_y + dup_x] = vh;
+                    }
+                }
+                if (olo) {
+                    auto t0 = __builtin_amdgcn_permlane32_swap(xl0, yl0, false, false); xl0 = t0[0]; yl0 = t0[1];
+                    auto t1 = __builtin_amdgcn_permlane32_swap(xl1, yl1, false, false); xl1 = t1[0]; yl1 = t1[1];
+                    const uint4 vl = make_uint4(xl0, xl1, yl0, yl1);
+                    if (ok) {
+                        olo[u] = vl;
+                        if (any_dup) {
+                            if (dup_y) olo[u + dup_y] = vl;
+                            if (dup_x) olo[u + dup_x] = vl;
+                            if (dup_y && dup_x) olo[u + dup_y + dup_x] = vl;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (EPI <= EPI_SWISH && c.stats) {        // same deterministic GroupNorm partials as conv_common.h
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = ssum[g][k], s2 = ssq[g][k];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
+                const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
+                if (lo == 0 && quad * 4 < c.Cout) {
+                    float* dst = c.stats + (((long)n * (c.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
+                    dst[0] = s; dst[1] = s2;
+                }
+            }
+    }
+}
+
+template <bool BF, int TERMS, int NCG, int EPI, int OUT>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb) {
+    using E = Elem<BF>;
+    using v8 = typename E::v8;
+    constexpr int BN = NCG * 32;
+    constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;     // 1-KiB DMA pieces of one weight plane of a chunk
+    constexpr int WUNITS = WPIECES * 64;                     // 16-byte units of that plane (padded)
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const int Wp = a.c.Wp, Hp = a.c.Hp;
+    const long plane = (long)Hp * Wp;
+    const int TL = kBQ + 2 * Wp + 2;
+    const int NIN = (TL + 63) >> 6;                          // 1-KiB pieces of one input plane of a chunk
+    const int INU = NIN * 64;                                // 16-byte units
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bq, cb, n;
+    tile_index(nblk_q, ncb, bq, cb, n);
+    const int set = n / a.c.n_per_set, nn = n - set * a.c.n_per_set;
+    const int q0 = bq * kBQ;
+    const int C8_0 = a.seg[0].C8;
+    const int nchunk = a.nchunk;
+    const float* aux = a.c.aux ? a.c.aux + (long)set * a.c.aux_set_stride : nullptr;
+    const uint4* wsrc = a.w + (long)set * a.w_set_stride + (long)cb * nchunk * (2 * WUNITS);
+
+    // per-lane source position of an input piece p: q0 + 64 * p + lane, clamped into the plane (positions past the end
+    // only feed outputs that the epilogue drops)
+    const long seg_off0 = (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
+    const long seg_off1 = (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set];
+
+    auto dma = [&](const uint4* g, int lds_unit) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(smem + lds_unit), 16, 0, 0);
+    };
+    // copy pieces [wave, wave + 4, ...] of the list {input pieces of `src` (NIN) -> in_unit} ++ {nwp weight pieces of
+    // `ws` -> w_unit}; every wave issues exactly ceil(total / 4) copies (the surplus repeats the last piece), so one
+    // vmcnt value fits all waves
+    auto issue = [&](const uint4* src, int in_unit, const uint4* ws, int w_unit, int nwp) {
+        const int total = NIN + nwp, cnt = (total + 3) >> 2;
+        for (int k = 0; k < cnt; ++k) {
+            int pid = wave + 4 * k;
+            pid = pid < total ? pid : total - 1;
+            if (pid < NIN) {
+                long q = (long)q0 + 64 * pid + lane;
+                q = q < plane ? q : plane - 1;
+                dma(src + q, in_unit + 64 * pid);
+            } else {
+                const int wp = pid - NIN;
+                dma(ws + 64 * wp + lane, w_unit + 64 * wp);
+            }
+        }
+    };
+    auto in_plane = [&](int c, bool lo_plane) -> const uint4* {
+        const bool first = c < C8_0;
+        const H16Seg& sg = a.seg[first ? 0 : 1];
+        const uint4* base = lo_plane ? sg.lo : sg.hi;
+        return base + (first ? seg_off0 : seg_off1) + (long)(first ? c : c - C8_0) * plane;
+    };
+
+    f32x16 acc[NCG][kQG];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int j = 0; j < kQG; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
+
+    // operand slots (16-byte units), independent of the chunk
+    int bslot[kKB], aslot[kKB];
+#pragma unroll
+    for (int kb = 0; kb < kKB; ++kb) {
+        const int tap = (2 * kb + hi) > 8 ? 8 : (2 * kb + hi);
+        bslot[kb] = wave * (kQG * 32) + lo + (tap / 3) * Wp + (tap % 3);
+        aslot[kb] = tap * BN + lo;
+    }
+    const bool zero_half = hi != 0;            // K block 4: the second half-wave has no tap
+
+    // products of one chunk: which = 0 -> x(in_unit) * w(w_unit) for all K blocks
+    auto mfma_chunk = [&](int in_unit, int w_unit) {
+#pragma unroll
+        for (int kb = 0; kb < kKB; ++kb) {
+            v8 av[NCG], bv[kQG];
+#pragma unroll
+            for (int g = 0; g < NCG; ++g) {
+                av[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
+                if (kb == kKB - 1 && zero_half) av[g] = v8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+#pragma unroll
+            for (int g = 0; g < NCG; ++g)
+#pragma unroll
+                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(av[g], bv[j], acc[g][j]);
+        }
+    };
+    // the two products that read the hi tile: x_hi * w_lo + x_hi * w_hi (B operands fetched once)
+    auto mfma_chunk_hi2 = [&](int in_unit, int w_unit) {
+#pragma unroll
+        for (int kb = 0; kb < kKB; ++kb) {
+            v8 ah[NCG], al[NCG], bv[kQG];
+#pragma unroll
+            for (int g = 0; g < NCG; ++g) {
+                ah[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
+                al[g] = *reinterpret_cast<const v8*>(smem + w_unit + WUNITS + aslot[kb] + g * 32);
+                if (kb == kKB - 1 && zero_half) { ah[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; al[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; }
+            }
+#pragma unroll
+            for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+#pragma unroll
+            for (int g = 0; g < NCG; ++g)
+#pragma unroll
+                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[g], bv[j], acc[g][j]);
+#pragma unroll
+            for (int g = 0; g < NCG; ++g)
+#pragma unroll
+                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[g], bv[j], acc[g][j]);
+        }
+    };
+
+    if (TERMS == 1) {
+        // LDS: 3 stages of [input tile | weight plane hi]
+        const int STU = INU + WUNITS;
+        const int cnt = (NIN + WPIECES + 3) >> 2;
+        issue(in_plane(0, false), 0, wsrc, INU, WPIECES);
+        if (nchunk > 1) issue(in_plane(1, false), STU, wsrc + 2 * WUNITS, STU + INU, WPIECES);
+        int st = 0;                                     // stage of chunk c
+        for (int c = 0; c < nchunk; ++c) {
+            wait_vm(c + 1 < nchunk ? cnt : 0);          // chunk c has landed (chunk c + 1 may still be in flight)
+            cbarrier();               // ... for every wave; and every wave is done reading chunk c - 1
+            if (c + 2 < nchunk) {
+                const int s2 = st == 0 ? 2 : st - 1;    // (c + 2) % 3 == (c - 1) % 3
+                issue(in_plane(c + 2, false), s2 * STU, wsrc + (long)(c + 2) * (2 * WUNITS), s2 * STU + INU, WPIECES);
+            }
+            if (TTC_H16_ABL != 3) mfma_chunk(st * STU, st * STU + INU);
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else {
+        // LDS: HI[0] HI[1] LO W[0] W[1], W = [hi plane | lo plane]
+        const int LOU = 2 * INU, WU0 = 3 * INU;
+        issue(in_plane(0, false), 0, wsrc, WU0, 2 * WPIECES);
+        issue(in_plane(0, true), LOU, nullptr, 0, 0);
+        for (int c = 0; c < nchunk; ++c) {
+            const int b = c & 1;
+            wait_vm(0);                                 // hi, lo and weights of chunk c have landed
+            cbarrier();               // ... for every wave; every wave is done with chunk c - 1
+            if (c + 1 < nchunk) issue(in_plane(c + 1, false), (b ^ 1) * INU, wsrc + (long)(c + 1) * (2 * WUNITS), WU0 + (b ^ 1) * 2 * WUNITS, 2 * WPIECES);
+            if (TTC_H16_ABL != 3) mfma_chunk(LOU, WU0 + b * 2 * WUNITS);          // x_lo * w_hi
+            cbarrier();               // the lo tile is free
+            if (c + 1 < nchunk) issue(in_plane(c + 1, true), LOU, nullptr, 0, 0);
+            if (TTC_H16_ABL != 3) mfma_chunk_hi2(b * INU, WU0 + b * 2 * WUNITS);   // x_hi * w_lo + x_hi * w_hi
+        }
+    }
+    if (TTC_H16_ABL == 3) acc[0][0][0] = __builtin_bit_cast(float, smem[tid].x);
+
+    if (TTC_H16_ABL == 1) {
+        float t = 0.f;
+        for (int g = 0; g < NCG; ++g) for (int j = 0; j < kQG; ++j) for (int r = 0; r < 16; ++r) t += acc[g][j][r];
+        if (t == 1234.5f) a.c.out[tid] = t;
+    } else if (OUT == OUT_B16) {
+        h16_epilogue_b16<BF, NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
+    } else {
+        conv_epilogue<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid);
+    }
+}
+
+template <bool BF, int TERMS, int NCG, int EPI, int OUT>
+hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t s) {
+    constexpr int BN = NCG * 32;
+    constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;
+    const int TL = kBQ + 2 * a.c.Wp + 2;
+    const int NIN = (TL + 63) >> 6;
+    const size_t lds = TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)(3 * NIN + 4 * WPIECES) * 1024;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static LdsConfig lds_cfg;
+    if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds); e != hipSuccess) return e;
+    const int nblk_q = conv_q_blocks(a.c.Hp, a.c.Wp);
+    dim3 grid(nblk_q * pw.ncb * n);
+    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds, s, a, nblk_q, pw.ncb);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// ---- host: 16-bit conversions (round to nearest even), weight packing, dispatch -----------------------------------
+uint16_t h16_from_float(float f, bool bf) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if (bf) {
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t ax = u & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                        // NaN
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | (ax >= 0x7f800000u ? 0x7c00u : 0x7bffu));   // inf stays inf; finite overflow saturates
+    if (ax < 0x33000001u) return (uint16_t)sign;                                    // < 2^-25: rounds to zero
+    const int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    int shift;                                                                      // bits to drop from the 24-bit mantissa
+    uint32_t base;
+    if (e >= -14) { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }  // normal: drop the hidden bit into the exponent
+    else { shift = 13 + (-14 - e); base = 0; }                                      // subnormal
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    return (uint16_t)(sign | (base + r));                                           // a mantissa carry bumps the exponent correctly
+}
+
+float h16_to_float(uint16_t h, bool bf) {
+    uint32_t u;
+    if (bf) u = (uint32_t)h << 16;
+    else {
+        const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+        if (e == 0) {
+            if (m == 0) u = sign;
+            else {                                                                  // subnormal: value = m * 2^-24
+                float f = (float)m * 5.9604644775390625e-08f;
+                std::memcpy(&u, &f, 4);
+                u |= sign;
+            }
+        } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+        else u = sign | ((e + 112) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// LDS images per (set, cout block, chunk): [hi | lo] planes of [tap 0..8][cout 0..BN)[8 ch] 16-bit, each plane padded to
+// whole 1-KiB DMA pieces.  Chunks follow the blocked input layout: the first segment's C0 channels are padded to a multiple
+// of 8 on their own, the second segment starts on a block boundary.  Returns 16-byte units per set.
+long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, bool bf, std::vector<uint16_t>& out,
+                   int* nchunk_out) {
+    const int c8_0 = (C0 + 7) / 8, c8_1 = (Cin - C0 + 7) / 8, nchunk = c8_0 + c8_1, ncb = (Cout + BN - 1) / BN;
+    const int wpieces = (9 * BN * 16 + 1023) / 1024;
+    const long plane_el = (long)wpieces * 512;                              // u16 elements per padded plane
+    const long per_set = (long)ncb * nchunk * 2 * plane_el;
+    out.assign((size_t)per_set * nsets, 0);
+    for (int s = 0; s < nsets; ++s)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int c = 0; c < nchunk; ++c)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int co = 0; co < BN; ++co)
+                        for (int k = 0; k < 8; ++k) {
+                            const int ci = c < c8_0 ? c * 8 + k : C0 + (c - c8_0) * 8 + k;
+                            const bool real = c < c8_0 ? (c * 8 + k < C0) : (ci < Cin);
+                            const int o = cb * BN + co;
+                            if (!real || o >= Cout) continue;
+                            const float w = hwio[s][((long)tap * Cin + ci) * Cout + o];       // HWIO, tap = 3*dy + dx
+                            const uint16_t h = h16_from_float(w, bf), l = h16_from_float(w - h16_to_float(h, bf), bf);
+                            const long base = (long)s * per_set + (((long)cb * nchunk + c) * 2) * plane_el;
+                            const long e = ((long)tap * BN + co) * 8 + k;
+                            out[base + e] = h;
+                            out[base + plane_el + e] = l;
+                        }
+    if (nchunk_out) *nchunk_out = nchunk;
+    return per_set / 8;
+}
+
+hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, bool bf, int epi, int out_kind, int n, hipStream_t s) {
+    const int terms = pw.terms == 1 ? 1 : 3;
+#define TTC_H16_CASE(BFV, T, ncg, e, o) \
+    if (bf == BFV && terms == T && pw.BN == ncg * 32 && epi == e && out_kind == o) return launch_h16<BFV, T, ncg, e, o>(a, pw, n, s);
+#define TTC_H16_LAYERS(BFV, T)                                                                         \
+    TTC_H16_CASE(BFV, T, 2, EPI_RAW, OUT_F32)             /* ConvGRU gates                          */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_SSE, OUT_F32)             /* ConvGRU candidate                      */ \
+    TTC_H16_CASE(BFV, T, 2, EPI_SWISH, OUT_F32)           /* conv_swish_gn blocks                   */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_RELU, OUT_B16)       /* DSen2 in / x1 convs -> blocked 16-bit   */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_RES, OUT_B16)        /* DSen2 residual convs -> blocked 16-bit  */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_TANH_ADD, OUT_F32)   /* DSen2 head                             */
+    TTC_H16_LAYERS(false, 3)
+    TTC_H16_LAYERS(false, 1)
+    TTC_H16_LAYERS(true, 3)
+#undef TTC_H16_LAYERS
+#undef TTC_H16_CASE
+    return hipErrorInvalidValue;
+}

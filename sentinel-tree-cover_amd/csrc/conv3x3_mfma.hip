@@ -220,7 +220,7 @@ long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, i
     return per_set;
 }
 
-ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN) {
+ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN, int C0) {
     pc.Cin = Cin; pc.Cout = Cout; pc.nsets = nsets;
     pc.CK = conv_pick_ck(Cin); pc.BN = BN;
     pc.nchunk = (Cin + pc.CK - 1) / pc.CK; pc.ncb = (Cout + pc.BN - 1) / pc.BN;
@@ -236,6 +236,14 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
         if (!pc.d_w3 && !(pc.d_w3 = reinterpret_cast<uint16_t*>(c->alloc_f((p3.size() + 1) / 2))))
             return c->fail(TTC_ERR_NOMEM, "hipMalloc bf16 weights");
         TTC_HIP(c, hipMemcpy(pc.d_w3, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
+    if (pc.mode >= 2) {                        // 16-bit engine: fp16 (2) / bf16 (3) hi | lo LDS images
+        std::vector<uint16_t> ph;
+        pc.set_stride_h = conv_pack_h16(hwio, nsets, Cin, C0 < 0 ? Cin : C0, Cout, pc.BN, pc.mode == 3, ph, &pc.nchunk_h);
+        // + one DMA piece of slack: the last 1-KiB piece of a 32-cout plane is only half used
+        if (!pc.d_wh && !(pc.d_wh = reinterpret_cast<uint4*>(c->alloc_f((ph.size() + 1) / 2 + 256))))
+            return c->fail(TTC_ERR_NOMEM, "hipMalloc 16-bit weights");
+        TTC_HIP(c, hipMemcpy(pc.d_wh, ph.data(), ph.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     return TTC_OK;
 }

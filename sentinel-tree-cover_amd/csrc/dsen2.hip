@@ -6,9 +6,11 @@
 // (conv3x3_mfma.hip): activations live planar and reflect-padded ([n][32][H+2][W+2]); each conv
 // writes the interior of the next padded buffer and k_reflect_border fills the 1-px rim
 // (MirrorPad REFLECT before every Conv2D VALID in the graph).
-#include "ttc_internal.h"
+#include "h16_common.h"
 
 namespace {
+
+using B16 = ttc_ctx::B16;
 
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
@@ -60,6 +62,54 @@ __global__ void k_sr_gather(const float* __restrict__ tile, int X, int Y, SRWin 
     const float* src = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * cs;      // cs: floats per pixel (>= 10)
     float* dst = out + ((long)(t * sw.n + w) * 10) * Ep * Ep + p;
     for (int c = 0; c < 10; ++c) dst[(long)c * Ep * Ep] = src[c];
+}
+
+// 16-bit engine: the same gather, written channel-blocked (10 bands -> 2 blocks, 6 zero pad channels) as hi / lo pairs
+template <bool BF>
+__global__ void k_sr_gather_b16(const float* __restrict__ tile, int X, int Y, SRWin sw, int ws, int cs, uint4* __restrict__ ohi,
+                                uint4* __restrict__ olo) {
+    const int E = ws + 8, Ep = E + 2;
+    const int w = blockIdx.y, t = blockIdx.z;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Ep * Ep) return;
+    const int qy = reflect_idx(p / Ep - 1, E), qx = reflect_idx(p % Ep - 1, E);
+    const int lx = reflect_idx(qy - 4, ws), ly = reflect_idx(qx - 4, ws);
+    const float* src = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * cs;
+    const long u = ((long)(t * sw.n + w) * 2) * Ep * Ep + p;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = src[c];
+    b16_store8<BF>(ohi, olo, u, v);
+    v[0] = src[8]; v[1] = src[9];
+#pragma unroll
+    for (int c = 2; c < 8; ++c) v[c] = 0.0f;
+    b16_store8<BF>(ohi, olo, u + (long)Ep * Ep, v);
+}
+// ... and the exact fp32 bilinear operand straight from the tile (bands 4..9 of the 4-padded window, job.py:114)
+__global__ void k_sr_bil_tile(const float* __restrict__ tile, int X, int Y, SRWin sw, int ws, int cs, float* __restrict__ bil) {
+    const int E = ws + 8;
+    const int w = blockIdx.y, t = blockIdx.z;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= E * E) return;
+    const int lx = reflect_idx(p / E - 4, ws), ly = reflect_idx(p % E - 4, ws);
+    const float* src = tile + (((long)t * X + sw.x0[w] + lx) * Y + sw.y0[w] + ly) * cs + 4;
+    float* dst = bil + ((long)(t * sw.n + w) * 6) * E * E + p;
+    for (int c = 0; c < 6; ++c) dst[(long)c * E * E] = src[c];
+}
+// fill the 1-px reflect rim of blocked planes [img][Hp*Wp] (degenerate window sizes only)
+__global__ void k_reflect_border_b16(uint4* __restrict__ hi, uint4* __restrict__ lo, int Hp, int Wp) {
+    const long base = (long)blockIdx.y * Hp * Wp;
+    const int per = 2 * Wp + 2 * Hp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per) return;
+    int y, x;
+    if (i < Wp) { y = 0; x = i; }
+    else if (i < 2 * Wp) { y = Hp - 1; x = i - Wp; }
+    else if (i < 2 * Wp + Hp) { y = i - 2 * Wp; x = 0; }
+    else { y = i - 2 * Wp - Hp; x = Wp - 1; }
+    const int sy = 1 + reflect_idx(y - 1, Hp - 2), sx = 1 + reflect_idx(x - 1, Wp - 2);
+    hi[base + y * Wp + x] = hi[base + sy * Wp + sx];
+    lo[base + y * Wp + x] = lo[base + sy * Wp + sx];
 }
 
 // bilinear operand of the graph = channels 4..9 of the 4-padded window (job.py:114): the interior of
@@ -170,6 +220,7 @@ ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n) {
         PackedConv& pc = c->w_ds[l];
         const float* kk[1] = {k->data};
         TTC_CHECK(conv_upload(c, pc, kk, 1, kDsCin[l], kDsCout[l], 32));
+        pc.terms = (c->cfg.one_term_layers >> (10 + l)) & 1u ? 1 : 3;
         std::vector<float> bb(32, 0.0f);
         for (int i = 0; i < pc.Cout; ++i) bb[i] = b->data[i];
         bias.insert(bias.end(), bb.begin(), bb.end());
@@ -217,6 +268,53 @@ static ttc_status dsen2_core(ttc_ctx* c, const float* xin, const float* bil, int
     return TTC_OK;
 }
 
+// the six convs on the 16-bit engine: xin blocked [n][2][PP] hi / lo (reflect-padded), intermediates blocked [n][4][PP];
+// conv epilogues write the next conv's padded input directly (bias / ReLU / 0.1 x residual fused, reflect rim included)
+template <bool BF>
+static ttc_status dsen2_core_h16(ttc_ctx* c, const B16& xin, const float* bil, int n, int H, int W, float* out, hipStream_t s) {
+    const int Hp = H + 2, Wp = W + 2;
+    const long PP = (long)Hp * Wp, P = (long)H * W;
+    const size_t bytes = (size_t)n * 4 * PP * 16;
+    B16 A{static_cast<uint4*>(c->scratch_buf("ds16_Ah", bytes)), static_cast<uint4*>(c->scratch_buf("ds16_Al", bytes))};
+    B16 B{static_cast<uint4*>(c->scratch_buf("ds16_Bh", bytes)), static_cast<uint4*>(c->scratch_buf("ds16_Bl", bytes))};
+    B16 Cb{static_cast<uint4*>(c->scratch_buf("ds16_Ch", bytes)), static_cast<uint4*>(c->scratch_buf("ds16_Cl", bytes))};
+    if (!A.hi || !A.lo || !B.hi || !B.lo || !Cb.hi || !Cb.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
+    const bool rim = (H >= 4 && W >= 4);
+    auto conv = [&](int l, const B16& in, int C8, int epi, const B16* dst, const B16* res) -> ttc_status {
+        const PackedConv& pw = c->w_ds[l];
+        H16Args a{};
+        a.seg[0] = {in.hi, in.lo, (long)C8 * PP, {0, 0}, C8};
+        a.seg[1] = {nullptr, nullptr, 0, {0, 0}, 0};
+        a.nchunk = C8;
+        if (a.nchunk != pw.nchunk_h) return c->fail(TTC_ERR_STATE, "DSen2 16-bit conv: channel blocks do not match the packed weights");
+        a.w = pw.d_wh; a.w_set_stride = 0;
+        a.c.Hp = Hp; a.c.Wp = Wp; a.c.Cout = kDsCout[l]; a.c.n_per_set = n;
+        a.c.aux = c->d_ds_bias + 32 * l;
+        int kind = OUT_F32;
+        if (dst) {
+            kind = OUT_B16;
+            a.o_hi = dst->hi; a.o_lo = dst->lo; a.o_stride_n = 4 * PP; a.o_plane = PP;
+            a.c.out_pitch = Wp; a.c.oy = a.c.ox = 1; a.c.reflect_out = rim ? 1 : 0;
+            if (res) { a.r_hi = res->hi; a.r_lo = res->lo; }
+        } else {
+            a.c.out = out; a.c.res = bil; a.c.out_stride_n = 6 * P; a.c.out_plane = P; a.c.out_pitch = W;
+        }
+        { KTimer kt(c, "dsen2_conv", s); TTC_HIP(c, conv_launch_h16(a, pw, BF, epi, kind, n, s)); }
+        if (dst && !rim) {
+            hipLaunchKernelGGL(k_reflect_border_b16, dim3((2 * Wp + 2 * Hp + 255) / 256, n * 4), dim3(256), 0, s, dst->hi, dst->lo, Hp, Wp);
+            TTC_HIP(c, hipGetLastError());
+        }
+        return TTC_OK;
+    };
+    TTC_CHECK(conv(0, xin, 2, EPI_BIAS_RELU, &A, nullptr));              // x0 = relu(in_conv)
+    TTC_CHECK(conv(1, A, 4, EPI_BIAS_RELU, &B, nullptr));
+    TTC_CHECK(conv(2, B, 4, EPI_BIAS_RES, &Cb, &A));                     // x1 = x0 + 0.1 * conv
+    TTC_CHECK(conv(3, Cb, 4, EPI_BIAS_RELU, &B, nullptr));
+    TTC_CHECK(conv(4, B, 4, EPI_BIAS_RES, &A, &Cb));                     // x2 = x1 + 0.1 * conv
+    TTC_CHECK(conv(5, A, 4, EPI_BIAS_TANH_ADD, nullptr, nullptr));       // bilinear + tanh(out_conv), fp32
+    return TTC_OK;
+}
+
 ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int n, int H, int W, float* d_out,
                          hipStream_t s) {
     if (!c->have_dsen2) return c->fail(TTC_ERR_STATE, "ttc_load_dsen2_weights has not been called");
@@ -229,7 +327,18 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
     hipLaunchKernelGGL(k_nhwc_to_planar, dim3((Hp * Wp + 255) / 256, n), dim3(256), 0, s, d_in, 10, 0, 10, H, W, 1, xin);
     hipLaunchKernelGGL(k_nhwc_to_planar, dim3((H * W + 255) / 256, n), dim3(256), 0, s, d_bil, 6, 0, 6, H, W, 0, bil);
     TTC_HIP(c, hipGetLastError());
-    TTC_CHECK(dsen2_core(c, xin, bil, n, H, W, res, s));
+    if (c->half()) {
+        const size_t ub = (size_t)n * 2 * Hp * Wp * 16;
+        B16 x16{static_cast<uint4*>(c->scratch_buf("ds16_inh", ub)), static_cast<uint4*>(c->scratch_buf("ds16_inl", ub))};
+        if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
+        const dim3 g16((Hp * Wp + 255) / 256, n);
+        if (c->bf()) hipLaunchKernelGGL((k_planar_to_b16<true>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
+        else hipLaunchKernelGGL((k_planar_to_b16<false>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
+        TTC_HIP(c, hipGetLastError());
+        TTC_CHECK(c->bf() ? dsen2_core_h16<true>(c, x16, bil, n, H, W, res, s) : dsen2_core_h16<false>(c, x16, bil, n, H, W, res, s));
+    } else {
+        TTC_CHECK(dsen2_core(c, xin, bil, n, H, W, res, s));
+    }
     hipLaunchKernelGGL(k_planar_to_nhwc, dim3((H * W + 255) / 256, n), dim3(256), 0, s, res, 6, H, W, d_out);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
@@ -273,16 +382,30 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
         const SRWin& sw = pass == 0 ? p1 : p2;
         if (sw.n == 0) continue;
         const int n = T * sw.n;
-        float* xin = static_cast<float*>(c->scratch_buf("ds_in", sizeof(float) * (size_t)n * 10 * Ep * Ep));
         float* bil = static_cast<float*>(c->scratch_buf("ds_bil", sizeof(float) * (size_t)n * 6 * E * E));
         float* res = static_cast<float*>(c->scratch_buf("ds_out", sizeof(float) * (size_t)n * 6 * E * E));
-        if (!xin || !bil || !res) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
-        { KTimer kt(c, "dsen2_gather", s);
-          hipLaunchKernelGGL(k_sr_gather, dim3((Ep * Ep + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, xin);
-          TTC_HIP(c, hipGetLastError()); }
-        hipLaunchKernelGGL(k_sr_bil, dim3((E * E + 255) / 256, n), dim3(256), 0, s, xin, E, bil);
-        TTC_HIP(c, hipGetLastError());
-        TTC_CHECK(dsen2_core(c, xin, bil, n, E, E, res, s));
+        if (!bil || !res) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
+        if (c->half()) {
+            const size_t ub = (size_t)n * 2 * Ep * Ep * 16;
+            B16 x16{static_cast<uint4*>(c->scratch_buf("ds16_inh", ub)), static_cast<uint4*>(c->scratch_buf("ds16_inl", ub))};
+            if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
+            { KTimer kt(c, "dsen2_gather", s);
+              const dim3 gg((Ep * Ep + 255) / 256, sw.n, T);
+              if (c->bf()) hipLaunchKernelGGL((k_sr_gather_b16<true>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
+              else hipLaunchKernelGGL((k_sr_gather_b16<false>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
+              hipLaunchKernelGGL(k_sr_bil_tile, dim3((E * E + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, bil);
+              TTC_HIP(c, hipGetLastError()); }
+            TTC_CHECK(c->bf() ? dsen2_core_h16<true>(c, x16, bil, n, E, E, res, s) : dsen2_core_h16<false>(c, x16, bil, n, E, E, res, s));
+        } else {
+            float* xin = static_cast<float*>(c->scratch_buf("ds_in", sizeof(float) * (size_t)n * 10 * Ep * Ep));
+            if (!xin) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
+            { KTimer kt(c, "dsen2_gather", s);
+              hipLaunchKernelGGL(k_sr_gather, dim3((Ep * Ep + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, xin);
+              TTC_HIP(c, hipGetLastError()); }
+            hipLaunchKernelGGL(k_sr_bil, dim3((E * E + 255) / 256, n), dim3(256), 0, s, xin, E, bil);
+            TTC_HIP(c, hipGetLastError());
+            TTC_CHECK(dsen2_core(c, xin, bil, n, E, E, res, s));
+        }
         { KTimer kt(c, "dsen2_scatter", s);
           if (pass == 0) {
               for (int g = 0; g < 4; ++g)

@@ -1,0 +1,79 @@
+// Device helpers shared by the 16-bit conv engine (conv3x3_h16.hip) and the kernels that produce / consume its
+// channel-blocked activations: element traits (fp16 / bf16), hi + lo splitting, 16-byte K-vector loads and stores.
+#pragma once
+#include "conv_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF> struct Elem;
+template <> struct Elem<false> {
+    using v8 = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b, unsigned& lo2) {
+        a = fminf(fmaxf(a, -65504.f), 65504.f); b = fminf(fmaxf(b, -65504.f), 65504.f);
+        f16x2 h; h[0] = (_Float16)a; h[1] = (_Float16)b;
+        f16x2 l; l[0] = (_Float16)(a - (float)h[0]); l[1] = (_Float16)(b - (float)h[1]);
+        lo2 = __builtin_bit_cast(unsigned, l);
+        return __builtin_bit_cast(unsigned, h);
+    }
+    static __device__ __forceinline__ void unpack2(unsigned u, float& a, float& b) {
+        const f16x2 h = __builtin_bit_cast(f16x2, u); a = (float)h[0]; b = (float)h[1];
+    }
+};
+template <> struct Elem<true> {
+    using v8 = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b, unsigned& lo2) {
+        bf16x2 h; h[0] = (__bf16)a; h[1] = (__bf16)b;
+        bf16x2 l; l[0] = (__bf16)(a - (float)h[0]); l[1] = (__bf16)(b - (float)h[1]);
+        lo2 = __builtin_bit_cast(unsigned, l);
+        return __builtin_bit_cast(unsigned, h);
+    }
+    static __device__ __forceinline__ void unpack2(unsigned u, float& a, float& b) {
+        const bf16x2 h = __builtin_bit_cast(bf16x2, u); a = (float)h[0]; b = (float)h[1];
+    }
+};
+
+
+// one channel block (8 channels) of one position: x = hi + lo
+template <bool BF>
+__device__ __forceinline__ void b16_store8(uint4* hi, uint4* lo, long u, const float (&v)[8]) {
+    using E = Elem<BF>;
+    uint4 h, l;
+    h.x = E::pack2(v[0], v[1], l.x); h.y = E::pack2(v[2], v[3], l.y);
+    h.z = E::pack2(v[4], v[5], l.z); h.w = E::pack2(v[6], v[7], l.w);
+    hi[u] = h;
+    if (lo) lo[u] = l;
+}
+template <bool BF>
+__device__ __forceinline__ void b16_load8(const uint4* hi, const uint4* lo, long u, float (&v)[8]) {
+    using E = Elem<BF>;
+    const uint4 h = hi[u];
+    E::unpack2(h.x, v[0], v[1]); E::unpack2(h.y, v[2], v[3]); E::unpack2(h.z, v[4], v[5]); E::unpack2(h.w, v[6], v[7]);
+    if (lo) {
+        const uint4 l = lo[u];
+        float t[8];
+        E::unpack2(l.x, t[0], t[1]); E::unpack2(l.y, t[2], t[3]); E::unpack2(l.z, t[4], t[5]); E::unpack2(l.w, t[6], t[7]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+}
+
+// fp32 planar images [img][C][PP] -> channel-blocked hi / lo [img][C8][PP][8] (pad channels = 0)
+template <bool BF>
+__global__ void k_planar_to_b16(const float* __restrict__ src, int C, long PP, int C8, uint4* __restrict__ hi, uint4* __restrict__ lo) {
+    const long img = blockIdx.y;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= PP) return;
+    const float* sp = src + img * C * PP + p;
+    for (int k = 0; k < C8; ++k) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (8 * k + j < C) ? sp[(long)(8 * k + j) * PP] : 0.0f;
+        b16_store8<BF>(hi, lo, (img * C8 + k) * PP + p, v);
+    }
+}
+

@@ -15,9 +15,11 @@
 // (pad / pool / upsample / crop / concat are index math, never separate passes).
 #include <algorithm>
 
-#include "ttc_internal.h"
+#include "h16_common.h"
 
 namespace {
+
+using B16 = ttc_ctx::B16;
 
 // Activations on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error <= 2e-7, two
 // orders below the fp32 summation-order differences the parity tests already allow; libm's expf / tanhf / IEEE division made
@@ -143,6 +145,8 @@ struct FinArgs {
     int pad, crop, mode;
     long dst_stride_n;    // floats per n in dst (lets two producers share a concat buffer)
     int dst_coff;         // channel offset inside dst
+    // 16-bit engine: channel-blocked destination instead of dst; dst_stride_n then counts 16-byte units and dst_coff blocks
+    uint4* dhi = nullptr; uint4* dlo = nullptr;
 };
 
 template <int MODE>
@@ -255,6 +259,154 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
     for (int c = 0; c < C; ++c) o[c] = (y[(long)c * P] * sm[c] + sm[C + c]) * gate;
 }
 
+// ======================================================================================================================
+// 16-bit engine (cfg.precision >= 2, conv3x3_h16.hip): the same elementwise stages, reading the fp32 raw conv outputs and
+// writing the NEXT conv's input channel-blocked as hi + lo 16-bit K vectors ([n][C8][plane][8]).  The ConvGRU state lives
+// only as such a pair (fp16: 22 mantissa bits).
+template <bool BF>
+__global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm, B16 hcur, B16 rh,
+                                 int H, int W, int N) {
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
+    const int n = blockIdx.y, dir = n / N;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= PP) return;
+    const int py = p / Wp, px = p - py * Wp;
+    const int s = reflect_idx(py - 1, H) * W + reflect_idx(px - 1, W);
+    const float* pr = prm.base + dir * prm.dir_stride;
+    const float* y = yg + (long)n * 64 * P + s;
+    const float* g = gn + (long)n * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long u = ((long)n * 4 + k) * PP + p;
+        float hv[8], o[8];
+        b16_load8<BF>(hcur.hi, hcur.lo, u, hv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * k + j, gi = c >> 2;
+            const float r = sigm((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[c] + pr[32 + c]);
+            o[j] = r * hv[j];
+        }
+        b16_store8<BF>(rh.hi, rh.lo, u, o);
+    }
+}
+
+template <bool BF>
+__global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
+                                 const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
+                                 B16 hcur, B16 hnext, B16 gru_out, int H, int W, int N, float z) {
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
+    const int n = blockIdx.y, dir = n / N;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= PP) return;
+    const int py = p / Wp, px = p - py * Wp;
+    const int sy0 = py - 1, sx0 = px - 1;
+    const bool interior = sy0 >= 0 && sy0 < H && sx0 >= 0 && sx0 < W;
+    const int s = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);
+    const float* pr = prm.base + dir * prm.dir_stride;
+    const float* y = yc + (long)n * 32 * P + s;
+    const float* g = gn + (long)n * 16;
+    const float* yu = yg + ((long)n * 64 + 32) * P + s;
+    const float* gu = gn_gates + (long)n * 32 + 16;
+    float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * P + s : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long u = ((long)n * 4 + k) * PP + p;
+        float hv[8], o[8];
+        b16_load8<BF>(hcur.hi, hcur.lo, u, hv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * k + j, gi = c >> 2;
+            const float cand = tanh_fast((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
+            const float uv = sigm((yu[(long)c * P] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
+            if (uk) uk[(long)c * P] = uv;
+            const float hnew = uv * hv[j] + (1.0f - uv) * cand;
+            o[j] = hv[j] * z + hnew * (1.0f - z);
+        }
+        b16_store8<BF>(hnext.hi, hnext.lo, u, o);
+        if (gru_out.hi) {
+            if (!interior) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+            }
+            b16_store8<BF>(gru_out.hi, gru_out.lo, ((long)(n - dir * N) * 8 + dir * 4 + k) * PP + p, o);
+        }
+    }
+}
+
+template <bool BF, int MODE>
+__global__ void k_block_finalize_b16(FinArgs a) {
+    extern __shared__ float sm[];            // scale[C] shift[C] ssew[C]
+    const int C = a.C, n = blockIdx.y;
+    const int cpg = C / 8;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mean = a.gn[((long)n * 8 + c / cpg) * 2], rstd = a.gn[((long)n * 8 + c / cpg) * 2 + 1];
+        const float sc = rstd * a.prm[c];
+        sm[c] = sc; sm[C + c] = a.prm[C + c] - mean * sc; sm[2 * C + c] = a.prm[2 * C + c];
+    }
+    __syncthreads();
+    const float sseb = a.prm[3 * C];
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.Hd * a.Wd) return;
+    const int dy = d / a.Wd, dx = d - dy * a.Wd;
+    const long PS = (long)a.Hs * a.Ws, PD = (long)a.Hd * a.Wd;
+    const long u0 = (long)n * a.dst_stride_n + (long)a.dst_coff * PD + d;
+    const int iy = dy - a.pad, ix = dx - a.pad;
+    if (iy < 0 || ix < 0 || iy >= a.Hd - 2 * a.pad || ix >= a.Wd - 2 * a.pad) {
+        const uint4 zv = make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < C / 8; ++k) { a.dhi[u0 + k * PD] = zv; a.dlo[u0 + k * PD] = zv; }
+        return;
+    }
+    constexpr int NS = (MODE == G_POOL) ? 4 : 1;
+    int src[NS];
+    if (MODE == G_COPY) src[0] = (iy + a.crop) * a.Ws + ix + a.crop;
+    if (MODE == G_UP) src[0] = (iy >> 1) * a.Ws + (ix >> 1);
+    if (MODE == G_POOL) {
+        src[0] = (2 * iy) * a.Ws + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + a.Ws; src[3] = src[2] + 1;
+    }
+    const float* y = a.y + (long)n * C * PS;
+    float gate[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) gate[k] = sseb;
+    for (int c = 0; c < C; ++c) {
+        const float sc = sm[c], sh = sm[C + c], w = sm[2 * C + c];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) gate[k] += w * (y[(long)c * PS + src[k]] * sc + sh);
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) gate[k] = sigm(gate[k]);
+    for (int cb = 0; cb < C / 8; ++cb) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * cb + j;
+            const float sc = sm[c], sh = sm[C + c];
+            float v = (y[(long)c * PS + src[0]] * sc + sh) * gate[0];
+#pragma unroll
+            for (int k = 1; k < NS; ++k) v = fmaxf(v, (y[(long)c * PS + src[k]] * sc + sh) * gate[k]);
+            o[j] = v;
+        }
+        b16_store8<BF>(a.dhi, a.dlo, u0 + cb * PD, o);
+    }
+}
+
+template <bool BF>
+__global__ void k_tap_early_b16(B16 gru_out, int H, int W, int N, int tr, float* __restrict__ out) {
+    const int Wp = W + 2;
+    const long PP = (long)(H + 2) * Wp, total = (long)N * H * W * 8;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one channel block of one pixel
+    if (id >= total) return;
+    const int blk = (int)(id & 7);
+    const long pix = id >> 3;
+    const int n = (int)(pix / ((long)H * W)), r = (int)(pix - (long)n * H * W);
+    const int cols = tr ? H : W;
+    const int uy = r / cols, ux = r - uy * cols;
+    const int y = tr ? ux : uy, x = tr ? uy : ux;
+    float v[8];
+    b16_load8<BF>(gru_out.hi, gru_out.lo, ((long)n * 8 + blk) * PP + (long)(y + 1) * Wp + (x + 1), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[pix * 64 + blk * 8 + j] = v[j];
+}
+
 // U-Net geometry of one axis (train-model.py:140-231): pool, VALID conv, pool, VALID conv, x2, x2, VALID conv
 struct Axis {
     int n, np, c1, c2, u2, u3, o;
@@ -290,6 +442,12 @@ float* ttc_ctx::alloc_f(size_t n, const char* name) {
     return static_cast<float*>(p);
 }
 
+bool ttc_ctx::alloc_b16(B16& b, size_t units) {
+    b.hi = reinterpret_cast<uint4*>(alloc_f(units * 4));
+    b.lo = reinterpret_cast<uint4*>(alloc_f(units * 4));
+    return b.hi && b.lo;
+}
+
 void* ttc_ctx::scratch_buf(const std::string& key, size_t bytes) {
     auto it = scratch.find(key);
     if (it != scratch.end() && it->second.second >= bytes) return it->second.first;
@@ -315,22 +473,38 @@ ttc_status model_alloc(ttc_ctx* c) {
     const size_t Ph2 = (size_t)(g.y.c1 / 2) * (g.x.c1 / 2);
 #define A(field, count, name)                                                        \
     if (!(c->field = c->alloc_f((count), name))) return c->fail(TTC_ERR_NOMEM, "hipMalloc " name)
+#define B(field, units, name)                                                        \
+    if (!c->alloc_b16(c->field, (units))) return c->fail(TTC_ERR_NOMEM, "hipMalloc " name)
+    const bool half = c->half();
     A(frames, N * (g.L + 1) * C * PP, "frames");
-    A(h[0], N2 * Hd * PP, "h0"); A(h[1], N2 * Hd * PP, "h1"); A(rh, N2 * Hd * PP, "rh");
     A(yg, N2 * 2 * Hd * P, "yg"); A(ug, N2 * Hd * P, "u"); A(yc, N2 * Hd * P, "yc");
-    A(gru_out, N * F * PP, "gru_out");
-    A(y_med, N * F * P, "y_med"); A(z_med, N * F * PP, "z_med"); A(y_cat, N * F * P, "y_cat");
-    A(p1, N * F * (P / 4), "p1"); A(y_c1, N * 2 * F * Pc1, "y_c1");
-    A(p2, N * 2 * F * Ph2, "p2"); A(y_c2, N * 4 * F * Pc2, "y_c2");
-    A(u2in, N * 4 * F * Pu2p, "u2in"); A(y_u2, N * 2 * F * Pu2, "y_u2");
-    A(u2a, N * 4 * F * Pu2p, "u2cat");                         // [up2 | crop(conv1)] concat buffer
-    A(y_u2o, N * 2 * F * Pu2, "y_u2o");
-    A(u3in, N * 2 * F * Pu3p, "u3in"); A(y_u3, N * F * Pu3, "y_u3");
-    A(oa, N * 2 * F * Pu3, "ocat");                            // [up3 | crop(concat)] concat buffer
-    A(y_out, N * F * Po, "y_out");
+    A(y_med, N * F * P, "y_med"); A(y_cat, N * F * P, "y_cat");
+    A(y_c1, N * 2 * F * Pc1, "y_c1"); A(y_c2, N * 4 * F * Pc2, "y_c2");
+    A(y_u2, N * 2 * F * Pu2, "y_u2"); A(y_u2o, N * 2 * F * Pu2, "y_u2o");
+    A(y_u3, N * F * Pu3, "y_u3"); A(y_out, N * F * Po, "y_out");
+    if (!half) {
+        A(h[0], N2 * Hd * PP, "h0"); A(h[1], N2 * Hd * PP, "h1"); A(rh, N2 * Hd * PP, "rh");
+        A(gru_out, N * F * PP, "gru_out");
+        A(z_med, N * F * PP, "z_med");
+        A(p1, N * F * (P / 4), "p1");
+        A(p2, N * 2 * F * Ph2, "p2");
+        A(u2in, N * 4 * F * Pu2p, "u2in");
+        A(u2a, N * 4 * F * Pu2p, "u2cat");                         // [up2 | crop(conv1)] concat buffer
+        A(u3in, N * 2 * F * Pu3p, "u3in");
+        A(oa, N * 2 * F * Pu3, "ocat");                            // [up3 | crop(concat)] concat buffer
+    } else {
+        // channel-blocked hi / lo pairs, 16-byte units = channel blocks x positions
+        B(frames16, N * (g.L + 1) * ((C + 7) / 8) * PP, "frames16");
+        B(h16[0], N2 * (Hd / 8) * PP, "h16_0"); B(h16[1], N2 * (Hd / 8) * PP, "h16_1"); B(rh16, N2 * (Hd / 8) * PP, "rh16");
+        B(gru16, N * (F / 8) * PP, "gru16"); B(z_med16, N * (F / 8) * PP, "z_med16");
+        B(p1_16, N * (F / 8) * (P / 4), "p1_16"); B(p2_16, N * (2 * F / 8) * Ph2, "p2_16");
+        B(u2in16, N * (4 * F / 8) * Pu2p, "u2in16"); B(u2a16, N * (4 * F / 8) * Pu2p, "u2cat16");
+        B(u3in16, N * (2 * F / 8) * Pu3p, "u3in16"); B(oa16, N * (2 * F / 8) * Pu3, "ocat16");
+    }
     c->stats_floats = N2 * 16 * (size_t)conv_stat_slots(g.y.np, g.x.np) * 2 + 1024;
     A(stats, c->stats_floats, "stats");
     A(gn, 10 * N2 * 32, "gn");
+#undef B
 #undef A
     return TTC_OK;
 }
@@ -341,8 +515,8 @@ static const ttc_tensor* find_t(const ttc_tensor* t, int n, const std::string& n
     return nullptr;
 }
 
-static ttc_status upload_conv(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout) {
-    if (!model_transposed(c->cfg)) return conv_upload(c, pc, hwio, nsets, Cin, Cout, conv_pick_bn(Cout));
+static ttc_status upload_conv(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int C0 = -1) {
+    if (!model_transposed(c->cfg)) return conv_upload(c, pc, hwio, nsets, Cin, Cout, conv_pick_bn(Cout), C0);
     // transposed planes: tap (kh, kw) of the HWIO kernel acts as (kw, kh)
     const size_t blk = (size_t)Cin * Cout;
     std::vector<std::vector<float>> tw(nsets, std::vector<float>(9 * blk));
@@ -354,7 +528,7 @@ static ttc_status upload_conv(ttc_ctx* c, PackedConv& pc, const float* const* hw
                           tw[sidx].begin() + (size_t)(kh * 3 + kw) * blk);
         ptr[sidx] = tw[sidx].data();
     }
-    return conv_upload(c, pc, ptr.data(), nsets, Cin, Cout, conv_pick_bn(Cout));
+    return conv_upload(c, pc, ptr.data(), nsets, Cin, Cout, conv_pick_bn(Cout), C0);
 }
 
 ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
@@ -386,8 +560,11 @@ ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
             small.insert(small.end(), q->data, q->data + Hd);
         }
     }
-    TTC_CHECK(upload_conv(c, c->w_gates, gk, 2, Cx + Hd, 2 * Hd));
-    TTC_CHECK(upload_conv(c, c->w_cand, ck, 2, Cx + Hd, Hd));
+    const uint32_t one = c->cfg.one_term_layers;         // 16-bit engine: layers that multiply hi x hi only
+    TTC_CHECK(upload_conv(c, c->w_gates, gk, 2, Cx + Hd, 2 * Hd, Cx));
+    TTC_CHECK(upload_conv(c, c->w_cand, ck, 2, Cx + Hd, Hd, Cx));
+    c->w_gates.terms = (one & 1u) ? 1 : 3;
+    c->w_cand.terms = (one & 2u) ? 1 : 3;
     for (int b = 0; b < 8; ++b) {
         const std::string p = std::string(kBlockNames[b]) + "/";
         const int Ci = kBlockCin[b], Co = kBlockCout[b];
@@ -399,6 +576,7 @@ ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
         if (!k || !ga || !be || !sw || !sb) return TTC_ERR_ARG;
         const float* kk[1] = {k->data};
         TTC_CHECK(upload_conv(c, c->w_block[b], kk, 1, Ci, Co));
+        c->w_block[b].terms = (one >> (2 + b)) & 1u ? 1 : 3;
         c->small_off[p] = (long)small.size();
         small.insert(small.end(), ga->data, ga->data + Co);
         small.insert(small.end(), be->data, be->data + Co);
@@ -450,9 +628,142 @@ static ttc_status finalize(ttc_ctx* c, int mode, const FinArgs& a, int n, hipStr
     return TTC_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// forward on the 16-bit engine: same graph, same launch order; every conv input is a channel-blocked hi / lo pair
+template <bool BF>
+static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
+    const Geo g(c->cfg);
+    const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
+    const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
+    const long PP = (long)Hp * Wp, P = (long)H * W;
+    const int Cx8 = (Cx + 7) / 8, Hd8 = Hd / 8;
+    const float* sm = c->d_small;
+    float* gn_slot[10];
+    for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
+    const int nblk_full = conv_stat_slots(Hp, Wp);
+
+    // frames (written fp32 planar by the window assembly) -> channel-blocked hi / lo
+    {
+        KTimer kt(c, "frames_to_b16", s);
+        hipLaunchKernelGGL((k_planar_to_b16<BF>), dim3((unsigned)((PP + 255) / 256), N * (g.L + 1)), dim3(256), 0, s, c->frames,
+                           Cx, PP, Cx8, c->frames16.hi, c->frames16.lo);
+        TTC_HIP(c, hipGetLastError());
+    }
+    auto launch = [&](H16Args& a, const PackedConv& pw, int epi, int nseq) -> ttc_status {
+        a.nchunk = a.seg[0].C8 + a.seg[1].C8;
+        if (a.nchunk != pw.nchunk_h) return c->fail(TTC_ERR_STATE, "16-bit conv: channel blocks do not match the packed weights");
+        a.w = pw.d_wh; a.w_set_stride = pw.nsets > 1 ? pw.set_stride_h : 0;
+        TTC_HIP(c, conv_launch_h16(a, pw, BF, epi, OUT_F32, nseq, s));
+        return TTC_OK;
+    };
+
+    // ---------------- bi-directional ConvGRU ----------------
+    TTC_HIP(c, hipMemsetAsync(c->h16[0].hi, 0, (size_t)N2 * Hd8 * PP * 16, s));
+    TTC_HIP(c, hipMemsetAsync(c->h16[0].lo, 0, (size_t)N2 * Hd8 * PP * 16, s));
+    const GruParams gp{sm + c->small_off["gru/fw/"], c->small_off["gru/bw/"] - c->small_off["gru/fw/"]};
+    int cur = 0;
+    for (int st = 0; st < g.L; ++st) {
+        H16Args a{};
+        a.seg[0] = {c->frames16.hi, c->frames16.lo, (long)(g.L + 1) * Cx8 * PP, {(long)st * Cx8 * PP, (long)(g.L - 1 - st) * Cx8 * PP}, Cx8};
+        a.seg[1] = {c->h16[cur].hi, c->h16[cur].lo, (long)Hd8 * PP, {0, (long)N * Hd8 * PP}, Hd8};
+        a.c.Hp = Hp; a.c.Wp = Wp; a.c.Cout = 2 * Hd; a.c.n_per_set = N;
+        a.c.out = c->yg; a.c.out_stride_n = 2L * Hd * P; a.c.out_plane = P; a.c.out_pitch = W;
+        a.c.stats = c->stats;
+        { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2)); }
+        TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
+        {
+            KTimer kt(c, "gru_apply1", s);
+            hipLaunchKernelGGL((k_gru_apply1_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
+                               c->h16[cur], c->rh16, H, W, N);
+            TTC_HIP(c, hipGetLastError());
+        }
+        a.seg[1].hi = c->rh16.hi; a.seg[1].lo = c->rh16.lo;
+        a.c.Cout = Hd; a.c.out = c->yc; a.c.out_stride_n = (long)Hd * P;
+        a.c.aux = gp.base + 4 * 32; a.c.aux_set_stride = gp.dir_stride;
+        { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2)); }
+        TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
+        {
+            KTimer kt(c, "gru_apply2", s);
+            hipLaunchKernelGGL((k_gru_apply2_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
+                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h16[cur], c->h16[cur ^ 1],
+                               st == g.L - 1 ? c->gru16 : B16{}, H, W, N, c->cfg.zoneout);
+            TTC_HIP(c, hipGetLastError());
+        }
+        cur ^= 1;
+    }
+
+    // ---------------- U-Net ----------------
+    struct Dim { int h, w; long area() const { return (long)h * w; } };
+    auto dim = [&](int Axis::*m, int pad) { return Dim{g.y.*m + pad, g.x.*m + pad}; };
+    auto block_conv = [&](int b, H16Seg s0, H16Seg s1, Dim in, int same, float* out, const char* tname) -> ttc_status {
+        H16Args a{};
+        a.seg[0] = s0; a.seg[1] = s1;
+        a.c.Hp = in.h; a.c.Wp = in.w; a.c.Cout = kBlockCout[b]; a.c.n_per_set = N;
+        const long Po = (long)(in.h - 2) * (in.w - 2);
+        a.c.out = out; a.c.out_stride_n = (long)a.c.Cout * Po; a.c.out_plane = Po; a.c.out_pitch = in.w - 2;
+        a.c.stats = c->stats; a.c.same_pad = same;
+        { KTimer kt(c, tname, s); TTC_CHECK(launch(a, c->w_block[b], EPI_SWISH, N)); }
+        return gn_fin(c, gn_slot[b], N, a.c.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.c.Cout / 8) * Po, s);
+    };
+    auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
+    // src: raw conv output dims; dst: blocked destination, dims INCLUDING pad; cblk: its channel blocks per n; boff: block offset
+    auto fin = [&](int b, int mode, const float* y, Dim src, const B16& dst, Dim d, int pad, int crop, int cblk, int boff) -> ttc_status {
+        FinArgs f{y, gn_slot[b], prm(b), nullptr, kBlockCout[b], src.h, src.w, d.h, d.w, pad, crop, mode, (long)cblk * d.area(), boff,
+                  dst.hi, dst.lo};
+        KTimer kt(c, "block_finalize", s);
+        dim3 grid((f.Hd * f.Wd + 255) / 256, N);
+        const size_t lds = 3 * f.C * sizeof(float);
+        if (mode == G_COPY) hipLaunchKernelGGL((k_block_finalize_b16<BF, G_COPY>), grid, dim3(256), lds, s, f);
+        else if (mode == G_POOL) hipLaunchKernelGGL((k_block_finalize_b16<BF, G_POOL>), grid, dim3(256), lds, s, f);
+        else hipLaunchKernelGGL((k_block_finalize_b16<BF, G_UP>), grid, dim3(256), lds, s, f);
+        TTC_HIP(c, hipGetLastError());
+        return TTC_OK;
+    };
+    auto seg = [](const B16& t, long stride_n, long off, int C8) { return H16Seg{t.hi, t.lo, stride_n, {off, off}, C8}; };
+    const H16Seg none{nullptr, nullptr, 0, {0, 0}, 0};
+    const int F8 = F / 8;
+    const Dim full{H, W}, fullp{Hp, Wp}, half{H / 2, W / 2};
+    const Dim c1 = dim(&Axis::c1, 0), c2 = dim(&Axis::c2, 0), u2 = dim(&Axis::u2, 0), u2p = dim(&Axis::u2, 2);
+    const Dim u3 = dim(&Axis::u3, 0), u3p = dim(&Axis::u3, 2), o = dim(&Axis::o, 0);
+    const Dim h2{c1.h / 2, c1.w / 2};
+    // conv_median on the median frame (zero-padded SAME)
+    TTC_CHECK(block_conv(0, seg(c->frames16, (long)(g.L + 1) * Cx8 * PP, (long)g.L * Cx8 * PP, Cx8), none, fullp, 1, c->y_med, "conv_median"));
+    TTC_CHECK(fin(0, G_COPY, c->y_med, full, c->z_med16, fullp, 1, 0, F8, 0));
+    // conv_concat([gru, median_conv])
+    TTC_CHECK(block_conv(1, seg(c->gru16, (long)F8 * PP, 0, F8), seg(c->z_med16, (long)F8 * PP, 0, F8), fullp, 1, c->y_cat, "conv_concat"));
+    TTC_CHECK(fin(1, G_POOL, c->y_cat, full, c->p1_16, half, 0, 0, F8, 0));
+    // conv1 (VALID) on pool1
+    TTC_CHECK(block_conv(2, seg(c->p1_16, (long)F8 * half.area(), 0, F8), none, half, 0, c->y_c1, "conv1"));
+    TTC_CHECK(fin(2, G_POOL, c->y_c1, c1, c->p2_16, h2, 0, 0, 2 * F8, 0));
+    // conv2 (VALID) on pool2
+    TTC_CHECK(block_conv(3, seg(c->p2_16, 2L * F8 * h2.area(), 0, 2 * F8), none, h2, 0, c->y_c2, "conv2"));
+    TTC_CHECK(fin(3, G_UP, c->y_c2, c2, c->u2in16, u2p, 1, 0, 4 * F8, 0));
+    // up2 (SAME) on nearest x2
+    TTC_CHECK(block_conv(4, seg(c->u2in16, 4L * F8 * u2p.area(), 0, 4 * F8), none, u2p, 1, c->y_u2, "up2"));
+    TTC_CHECK(fin(4, G_COPY, c->y_u2, u2, c->u2a16, u2p, 1, 0, 4 * F8, 0));
+    TTC_CHECK(fin(2, G_COPY, c->y_c1, c1, c->u2a16, u2p, 1, 2, 4 * F8, 2 * F8));            // crop(conv1, 2)
+    TTC_CHECK(block_conv(5, seg(c->u2a16, 4L * F8 * u2p.area(), 0, 4 * F8), none, u2p, 1, c->y_u2o, "up2_out"));
+    TTC_CHECK(fin(5, G_UP, c->y_u2o, u2, c->u3in16, u3p, 1, 0, 2 * F8, 0));
+    // up3 (SAME)
+    TTC_CHECK(block_conv(6, seg(c->u3in16, 2L * F8 * u3p.area(), 0, 2 * F8), none, u3p, 1, c->y_u3, "up3"));
+    TTC_CHECK(fin(6, G_COPY, c->y_u3, u3, c->oa16, u3, 0, 0, 2 * F8, 0));
+    TTC_CHECK(fin(1, G_COPY, c->y_cat, full, c->oa16, u3, 0, 6, 2 * F8, F8));               // crop(concat, 6)
+    // out (VALID)
+    TTC_CHECK(block_conv(7, seg(c->oa16, 2L * F8 * u3.area(), 0, 2 * F8), none, u3, 0, c->y_out, "out_conv"));
+    {
+        KTimer kt(c, "head", s);
+        const int Po = (int)o.area();
+        hipLaunchKernelGGL(k_head, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
+                           prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0);
+        TTC_HIP(c, hipGetLastError());
+    }
+    return TTC_OK;
+}
+
 ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     if (!c->have_model) return c->fail(TTC_ERR_STATE, "ttc_load_weights has not been called");
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
+    if (c->half()) return c->bf() ? forward_h16<true>(c, n, d_out, s) : forward_h16<false>(c, n, d_out, s);
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
     const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
@@ -565,7 +876,11 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
     const Geo g(c->cfg);
     const int F = c->cfg.base_filters;
     KTimer kt(c, "taps", s);
-    if (d_early) {
+    if (d_early && c->half()) {
+        const long total = (long)n * g.y.n * g.x.n * 8;
+        if (c->bf()) hipLaunchKernelGGL((k_tap_early_b16<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
+        else hipLaunchKernelGGL((k_tap_early_b16<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
+    } else if (d_early) {
         const long total = (long)n * g.y.n * g.x.n * 64;
         hipLaunchKernelGGL(k_tap_early, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru_out, g.y.n, g.x.n, n,
                            g.tr ? 1 : 0, d_early);

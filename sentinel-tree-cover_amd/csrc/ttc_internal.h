@@ -78,6 +78,11 @@ struct PackedConv {      // device copy of one layer's packed weights
     uint16_t* d_w3 = nullptr;
     int nchunk3 = 0;
     long set_stride3 = 0;         // 16-byte units between weight sets
+    // 16-bit engine (precision 2 = fp16, 3 = bf16): LDS-image weights hi | lo per chunk, see conv3x3_h16.hip
+    uint4* d_wh = nullptr;
+    int nchunk_h = 0;             // 8-channel blocks (padded per input segment)
+    long set_stride_h = 0;        // 16-byte units between weight sets
+    int terms = 3;                // MFMA products per K block: 1 (hi*hi) or 3 (lo*hi + hi*lo + hi*hi)
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the size configured on each device
@@ -99,6 +104,30 @@ struct LdsConfig {
     }
 };
 
+// ----------------------------------------------------------------------------- 16-bit conv engine (conv3x3_h16.hip)
+// Activations that feed a convolution live CHANNEL-BLOCKED in HBM: [n][C8][Hp*Wp][8] 16-bit elements (fp16 or bf16),
+// i.e. one 16-byte K vector per (channel block, position), as a `hi` tensor and an optional `lo` tensor with
+// x = hi + lo (fp16 pair: 22 mantissa bits; bf16 pair: 16).  A conv stage then is a pure global -> LDS DMA.
+// Pad channels (C not a multiple of 8) hold zeros.  All strides / offsets below are in 16-byte units.
+struct H16Seg {
+    const uint4* hi;     // [n][C8][PP]
+    const uint4* lo;     // same layout, or nullptr (1-term layers read hi only)
+    long stride_n;       // units between consecutive n (within a weight set)
+    long set_off[2];     // extra offset for weight-set 0 / 1
+    int C8;              // channel blocks in this segment
+};
+struct H16Args {
+    H16Seg seg[2];
+    int nchunk;          // seg[0].C8 + seg[1].C8
+    const uint4* w;      // packed LDS images: [set][cout_block][chunk][hi|lo][plane_units]
+    long w_set_stride;
+    // channel-blocked 16-bit output (OUT_B16 kernels): [n][Cout8][o_plane] hi (+ lo), pixel (y + c.oy) * c.out_pitch + x + c.ox
+    uint4* o_hi; uint4* o_lo; long o_stride_n; long o_plane;
+    const uint4* r_hi; const uint4* r_lo;   // EPI_BIAS_RES residual in the same blocked layout / indexing as the output
+    ConvArgs c;          // geometry (Hp, Wp, Cout, n_per_set) and the fp32 epilogue operands (out, stats, aux, res, ...)
+};
+enum H16Out : int { OUT_F32 = 0, OUT_B16 = 1 };
+
 int conv_pick_ck(int Cin);
 int conv_pick_bn(int Cout);
 // packs HWIO host kernels (one per weight set) into the layout above; returns floats per set
@@ -108,9 +137,16 @@ int conv_stat_slots(int Hp, int Wp); // GroupNorm partial sums per (window, chan
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
 long conv_pack_b3(const float* const* hwio, int nsets, int Cin, int Cout, int BN, std::vector<uint16_t>& out);
 hipError_t conv_launch_b3(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+// C0: real channels of the first input segment (its blocks are padded to a multiple of 8 on their own); bf: bf16 elements
+long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, bool bf, std::vector<uint16_t>& out,
+                   int* nchunk);
+hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, bool bf, int epi, int out_kind, int n, hipStream_t s);
+uint16_t h16_from_float(float f, bool bf);
+float h16_to_float(uint16_t h, bool bf);
 struct ttc_ctx;
 // packs + uploads the weights of one layer for the engine selected by ctx->cfg.precision (both images when 1)
-ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN);
+// C0: real channels of the first of two concatenated input segments (-1: one segment); only the 16-bit engine needs it
+ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN, int C0 = -1);
 
 // ----------------------------------------------------------------------------- context
 struct Timing {
@@ -143,6 +179,9 @@ struct ttc_ctx {
     float *y_med = nullptr, *z_med = nullptr, *y_cat = nullptr, *p1 = nullptr, *y_c1 = nullptr, *p2 = nullptr,
           *y_c2 = nullptr, *u2in = nullptr, *y_u2 = nullptr, *u2a = nullptr, *y_u2o = nullptr,
           *u3in = nullptr, *y_u3 = nullptr, *oa = nullptr, *y_out = nullptr;
+    // 16-bit engine (cfg.precision >= 2): channel-blocked hi / lo activations [n][C8][plane] (16-byte units), see conv3x3_h16.hip
+    struct B16 { uint4* hi = nullptr; uint4* lo = nullptr; };
+    B16 frames16, h16[2], rh16, gru16, z_med16, p1_16, p2_16, u2in16, u2a16, u3in16, oa16;
     float *stats = nullptr, *gn = nullptr;      // GN partial sums / (mean, rstd)
     size_t stats_floats = 0;
     int clouds_debug_stage = 0;   // ttc_debug_clouds_stage: return the flags after that stage of the cloud detector (test aid)
@@ -154,6 +193,9 @@ struct ttc_ctx {
 
     ttc_status fail(ttc_status s, const std::string& m) { err = m; return s; }
     float* alloc_f(size_t n, const char* name = nullptr);
+    bool alloc_b16(B16& b, size_t units);       // hi + lo tensors of `units` 16-byte K vectors each
+    bool half() const { return cfg.precision >= 2; }      // 16-bit conv engine selected
+    bool bf() const { return cfg.precision == 3; }
     void* scratch_buf(const std::string& key, size_t bytes);
 };
 

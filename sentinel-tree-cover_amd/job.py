@@ -57,13 +57,15 @@ class TTCSession:
     """
 
     def __init__(self, weights=None, win_in=SIZE + 14, length=LEN, max_windows=36, device=0, zoneout=0.75,
-                 dsen2_weights="package", precision="fp32", win_rows=0):
-        """precision: "fp32" = exact fp32 MFMA chains (default); "bf16x3" = split-bf16 MFMA (3 products per
-        term, fp32 accumulate; ~2^-17 operand error, max |dprob| ~5e-5 vs fp32, 3-5x faster convolutions)."""
-        prec = {"fp32": 0, "bf16x3": 1, 0: 0, 1: 1}[precision]
+                 dsen2_weights="package", precision="fp32", win_rows=0, one_term_layers=None):
+        """precision: "fp32" = exact fp32 MFMA chains (default); "fp16" / "bf16" = the 16-bit engine (conv inputs stored
+        as hi + lo 16-bit pairs, fp32 accumulate; per layer three split products or one, `one_term_layers` bit mask as in
+        ttc.h -- default: fp16 runs only the ConvGRU gates conv with plain fp16 operands, bf16 none);
+        "bf16x3" = the round-1 split-bf16 engine on fp32 activations."""
+        prec = _lib.PRECISIONS.get(precision, precision)
         # win_rows: rows of a non-square window (the 220 x 684 border graph of resegment_tiles_wide.py); 0 = square
         self.ctx = _lib.Context(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout,
-                                precision=prec, win_rows=win_rows)
+                                precision=prec, win_rows=win_rows, one_term_layers=one_term_layers)
         self.win_in, self.length = win_in, length
         if weights is not None:
             self.ctx.load_weights(_weights.validate(dict(weights)))

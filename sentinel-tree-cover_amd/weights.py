@@ -113,7 +113,7 @@ def from_tf_checkpoint_npz(path_or_dict, fuzzy=True):
     return validate({k: np.asarray(v, dtype=np.float32) for k, v in out.items()})
 
 
-def synth_weights(seed=0, n_in=17, hidden=32, dtype=np.float32):
+def synth_weights(seed=0, n_in=17, hidden=32, dtype=np.float32, stored_scale=False):
     """Seeded stand-in weights: He-normal conv kernels, block kernels
     weight-standardised like WSConv2D (model.py:384-390) and rescaled to keep activations
     O(1); gamma/beta perturbed around 1/0."""
@@ -136,7 +136,9 @@ def synth_weights(seed=0, n_in=17, hidden=32, dtype=np.float32):
             w[p + g + "/gamma"] = 1.0 + 0.1 * rng.standard_normal(hidden)
             w[p + g + "/beta"] = 0.1 * rng.standard_normal(hidden)
     for name, cin, cout in BLOCKS:
-        w[name + "/kernel"] = ws(he((3, 3, cin, cout))) / np.sqrt(9.0 * cin)
+        # stored_scale: the kernels as a checkpoint stores them (weight-standardised, std 1 per output channel, SURVEY A.1:
+        # inference uses them as stored); default: divided by sqrt(fan-in) so that raw conv outputs stay O(1)
+        w[name + "/kernel"] = ws(he((3, 3, cin, cout))) / (1.0 if stored_scale else np.sqrt(9.0 * cin))
         w[name + "/gamma"] = 1.0 + 0.1 * rng.standard_normal(cout)
         w[name + "/beta"] = 0.1 * rng.standard_normal(cout)
         w[name + "/sse_kernel"] = rng.standard_normal((1, 1, cout, 1)) * (1.0 / np.sqrt(cout))
