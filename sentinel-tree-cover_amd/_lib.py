@@ -36,10 +36,15 @@ class TTCConfig(C.Structure):
                 ("one_term_layers", C.c_uint32)]
 
 
-# ttc_config.precision values and the default per-layer map of the 16-bit engine (ttc.h): fp16 runs the ConvGRU gates
-# conv (bit 0) with plain fp16 operands, every other conv with three split products; bf16 needs three everywhere
+# ttc_config.precision values and the default per-layer map of the 16-bit engine (ttc.h): with L <= 4 ConvGRU steps fp16
+# runs the gates conv (bit 0) with plain fp16 operands (max |dprob| 2e-4 on the oracle; the error grows with the number
+# of recurrent steps: 6.5e-4 at L = 12, too close to the 1e-3 contract), every other conv with three split products;
+# bf16 needs three everywhere
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16": 3}
-DEFAULT_ONE_TERM = {0: 0, 1: 0, 2: 0x1, 3: 0}
+
+
+def default_one_term(precision, length):
+    return 0x1 if (precision == 2 and length <= 4) else 0
 
 
 class TTCResegWindow(C.Structure):
@@ -160,7 +165,7 @@ class Context:
         self.torch = _torch()
         precision = PRECISIONS.get(precision, precision)
         if one_term_layers is None:
-            one_term_layers = DEFAULT_ONE_TERM[precision]
+            one_term_layers = default_one_term(precision, length)
         self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision, win_rows, one_term_layers)
         self.device = device
         self._h = C.c_void_p()

@@ -16,6 +16,8 @@
 //     half-wave addresses LDS independently, so pairing taps costs nothing); tap "9" has zero weights.  5 K blocks per
 //     chunk, 10 % K padding; Cin is padded to a multiple of 8 (49 -> 56).
 //   * Weights are packed on the host into the exact LDS image [kb][hi|lo][k-half][cout][8 bf16].
+#include <algorithm>
+
 #include "conv_common.h"
 
 using namespace ttcconv;
@@ -190,6 +192,9 @@ __global__ __launch_bounds__(kThreads, NCG == 1 ? 3 : 2) void conv3x3_b3(ConvArg
         for (int g = 0; g < NCG; ++g) for (int j = 0; j < kQG; ++j) for (int r = 0; r < 16; ++r) t += acc[g][j][r];
         if (t == 1234.5f) a.out[tid] = t;
     } else {
+        if constexpr (EPI <= EPI_SWISH) {
+            conv_epilogue_flat<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid, smem); return;
+        }
         conv_epilogue<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
     }
 }
@@ -200,7 +205,7 @@ hipError_t launch_b3(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t
     const int TL = kBQ + 2 * a.Wp + 2;
     const int TL4 = (TL + 3) >> 2;
     const int TLq = ((TL4 + 11) & ~15) + 4;
-    const size_t lds = (size_t)(2 * 4 * TLq + 2 * kKB * 2 * 2 * BN) * 16;
+    const size_t lds = std::max((size_t)(2 * 4 * TLq + 2 * kKB * 2 * 2 * BN) * 16, kFlatLdsBytes);
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_b3<NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);

@@ -25,13 +25,14 @@
 //   TERMS = 3: hi tiles double-buffered, lo tile single (it is read by one of the three products only: that product
 //              runs first, a mid-chunk barrier frees the buffer and the next chunk's lo tile streams in under the other
 //              two products), weights (hi | lo) double-buffered.
+#include <algorithm>
+
 #include "h16_common.h"
 
 using namespace ttcconv;
 
-#ifndef TTC_H16_ABL
-#define TTC_H16_ABL 0     // probe builds only: 1 no output stores, 3 no MFMA
-#endif
+// probe aid: H16Args.abl (env TTC_H16_ABL) switches parts of the kernel off at run time -- bit 0: no epilogue / output
+// stores, bit 1: no MFMAs, bit 2: no LDS-DMA.  0 in production; results are garbage otherwise.
 
 namespace {
 
@@ -189,13 +190,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     const int Wp = a.c.Wp, Hp = a.c.Hp;
     const long plane = (long)Hp * Wp;
     const int TL = kBQ + 2 * Wp + 2;
-    const int NIN = (TL + 63) >> 6;                          // 1-KiB pieces of one input plane of a chunk
+    const int NIN = (TL + 63) >> 6;                          // 1-KiB pieces of one input plane of a chunk (<= 16, checked at launch)
     const int INU = NIN * 64;                                // 16-byte units
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (a.trace) tr0 = __builtin_amdgcn_s_memtime();
     int bq, cb, n;
     tile_index(nblk_q, ncb, bq, cb, n);
     const int set = n / a.c.n_per_set, nn = n - set * a.c.n_per_set;
@@ -210,27 +213,54 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     const long seg_off0 = (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
     const long seg_off1 = (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set];
 
+    const int abl = a.abl;
     auto dma = [&](const uint4* g, int lds_unit) {
+        if (abl & 4) return;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(smem + lds_unit), 16, 0, 0);
     };
-    // copy pieces [wave, wave + 4, ...] of the list {input pieces of `src` (NIN) -> in_unit} ++ {nwp weight pieces of
-    // `ws` -> w_unit}; every wave issues exactly ceil(total / 4) copies (the surplus repeats the last piece), so one
-    // vmcnt value fits all waves
-    auto issue = [&](const uint4* src, int in_unit, const uint4* ws, int w_unit, int nwp) {
-        const int total = NIN + nwp, cnt = (total + 3) >> 2;
-        for (int k = 0; k < cnt; ++k) {
-            int pid = wave + 4 * k;
-            pid = pid < total ? pid : total - 1;
-            if (pid < NIN) {
-                long q = (long)q0 + 64 * pid + lane;
-                q = q < plane ? q : plane - 1;
-                dma(src + q, in_unit + 64 * pid);
-            } else {
-                const int wp = pid - NIN;
-                dma(ws + 64 * wp + lane, w_unit + 64 * wp);
-            }
+    // A stage copy = this wave's share of {NIN input pieces of `src` -> in_unit} and {nwp weight pieces of `ws` -> w_unit}:
+    // input pieces wave, wave + 4, ...; weight pieces likewise; every wave issues exactly ceil(NIN / 4) + ceil(nwp / 4) copies
+    // (a surplus repeats the last piece), so one vmcnt value fits all waves.  The per-lane byte offsets are chunk-invariant
+    // and computed once: a copy then costs its wave an M0 write and one global_load_lds with an SGPR base.
+    // The copies of a stage are issued a few at a time BETWEEN the MFMAs of the running chunk (issue_some): an LDS-DMA costs
+    // its wave 60-180 issue cycles, which the matrix pipe hides while MFMAs are queued on it.
+    constexpr int kMaxIn = 4;                                // input pieces per wave: NIN <= 16 (Wp <= 254)
+    constexpr int kMaxW = (2 * WPIECES + 3) / 4;             // weight pieces per wave (TERMS == 3: hi | lo planes)
+    const int cnt_in = (NIN + 3) >> 2;
+    unsigned off_in[kMaxIn];                                 // byte offset of this lane's 16 bytes inside an input plane
+    int unit_in[kMaxIn];
+#pragma unroll
+    for (int k = 0; k < kMaxIn; ++k) {
+        int pid = wave + 4 * k;
+        pid = pid < NIN ? pid : NIN - 1;
+        long q = (long)q0 + 64 * pid + lane;
+        q = q < plane ? q : plane - 1;
+        off_in[k] = (unsigned)(q * 16);
+        unit_in[k] = 64 * pid;
+    }
+    struct Stage { const char* src; const char* ws; int in_unit, w_unit, nwp, cnt, k; };
+    auto stage_of = [&](const uint4* src, int in_unit, const uint4* ws, int w_unit, int nwp) {
+        Stage st{reinterpret_cast<const char*>(src), reinterpret_cast<const char*>(ws), in_unit, w_unit, nwp, cnt_in + ((nwp + 3) >> 2), 0};
+        return st;
+    };
+    auto issue_one = [&](const Stage& st, int k) {           // k < st.cnt, wave-uniform
+        if (k < cnt_in) {
+#pragma unroll
+            for (int i = 0; i < kMaxIn; ++i)
+                if (k == i) dma(reinterpret_cast<const uint4*>(st.src + off_in[i]), st.in_unit + unit_in[i]);
+        } else {
+            int wp = wave + 4 * (k - cnt_in);
+            wp = wp < st.nwp ? wp : st.nwp - 1;
+            dma(reinterpret_cast<const uint4*>(st.ws + (unsigned)((64 * wp + lane) * 16)), st.w_unit + 64 * wp);
         }
+    };
+    auto issue_some = [&](Stage& st, int npieces) {
+        for (int i = 0; i < npieces && st.k < st.cnt; ++i, ++st.k) issue_one(st, st.k);
+    };
+    auto issue = [&](const uint4* src, int in_unit, const uint4* ws, int w_unit, int nwp) {
+        Stage st = stage_of(src, in_unit, ws, w_unit, nwp);
+        issue_some(st, st.cnt);
     };
     auto in_plane = [&](int c, bool lo_plane) -> const uint4* {
         const bool first = c < C8_0;
@@ -257,91 +287,143 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     }
     const bool zero_half = hi != 0;            // K block 4: the second half-wave has no tap
 
-    // products of one chunk: which = 0 -> x(in_unit) * w(w_unit) for all K blocks
-    auto mfma_chunk = [&](int in_unit, int w_unit) {
+    // The LDS-DMA path of a CU accepts about one 1-KiB copy per 50 cycles, and a wave stays blocked in its copy until the
+    // copies of the other waves ahead of it are accepted (measured: ~350 cycles per copy when all 8 waves of a CU issue at
+    // once).  Probe switch `stagger`: wave w issues its whole share of the pending stage after the MFMAs of K block w.
+    const bool stagger = (a.desync & 8192) != 0;    // measured: no gain over the even spread (0.477 vs 0.462 ms), off
+    // One product of a chunk: x(in_unit) * w(w_unit) over its 5 K blocks.  Operands of K block kb + 1 are fetched before
+    // the MFMAs of kb issue, so a wave that has its SIMD to itself does not wait for LDS between K blocks.
+    auto load_ab = [&](int kb, int in_unit, int w_unit, v8 (&av)[NCG], v8 (&bv)[kQG]) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            av[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
+            if (kb == kKB - 1 && zero_half) av[g] = v8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+    };
+    auto mfma_chunk = [&](int in_unit, int w_unit, Stage& pend, int per_kb) {
+        v8 av[2][NCG], bv[2][kQG];
+        load_ab(0, in_unit, w_unit, av[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < kKB; ++kb) {
-            v8 av[NCG], bv[kQG];
-#pragma unroll
-            for (int g = 0; g < NCG; ++g) {
-                av[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
-                if (kb == kKB - 1 && zero_half) av[g] = v8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+            if (kb + 1 < kKB) load_ab(kb + 1, in_unit, w_unit, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
 #pragma unroll
             for (int g = 0; g < NCG; ++g)
 #pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(av[g], bv[j], acc[g][j]);
+                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(av[kb & 1][g], bv[kb & 1][j], acc[g][j]);
+            if (stagger) { if (kb == wave) issue_some(pend, pend.cnt); } else issue_some(pend, per_kb);
         }
     };
     // the two products that read the hi tile: x_hi * w_lo + x_hi * w_hi (B operands fetched once)
-    auto mfma_chunk_hi2 = [&](int in_unit, int w_unit) {
+    auto load_a2b = [&](int kb, int in_unit, int w_unit, v8 (&ah)[NCG], v8 (&al)[NCG], v8 (&bv)[kQG]) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            ah[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
+            al[g] = *reinterpret_cast<const v8*>(smem + w_unit + WUNITS + aslot[kb] + g * 32);
+            if (kb == kKB - 1 && zero_half) { ah[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; al[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; }
+        }
+#pragma unroll
+        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+    };
+    auto mfma_chunk_hi2 = [&](int in_unit, int w_unit, Stage& pend, int per_kb) {
+        v8 ah[2][NCG], al[2][NCG], bv[2][kQG];
+        load_a2b(0, in_unit, w_unit, ah[0], al[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < kKB; ++kb) {
-            v8 ah[NCG], al[NCG], bv[kQG];
-#pragma unroll
-            for (int g = 0; g < NCG; ++g) {
-                ah[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
-                al[g] = *reinterpret_cast<const v8*>(smem + w_unit + WUNITS + aslot[kb] + g * 32);
-                if (kb == kKB - 1 && zero_half) { ah[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; al[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; }
-            }
-#pragma unroll
-            for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+            if (kb + 1 < kKB) load_a2b(kb + 1, in_unit, w_unit, ah[(kb + 1) & 1], al[(kb + 1) & 1], bv[(kb + 1) & 1]);
 #pragma unroll
             for (int g = 0; g < NCG; ++g)
 #pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[g], bv[j], acc[g][j]);
+                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[kb & 1][g], bv[kb & 1][j], acc[g][j]);
 #pragma unroll
             for (int g = 0; g < NCG; ++g)
 #pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[g], bv[j], acc[g][j]);
+                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[kb & 1][g], bv[kb & 1][j], acc[g][j]);
+            if (stagger) { if (kb == wave) issue_some(pend, pend.cnt); } else issue_some(pend, per_kb);
         }
     };
 
+    const bool up_front = (a.desync & 4096) != 0;           // probe aid: issue a stage's copies in one go, before the MFMAs
     if (TERMS == 1) {
         // LDS: 3 stages of [input tile | weight plane hi]
         const int STU = INU + WUNITS;
-        const int cnt = (NIN + WPIECES + 3) >> 2;
+        const int cnt = cnt_in + ((WPIECES + 3) >> 2), per_kb = (cnt + kKB - 1) / kKB;
         issue(in_plane(0, false), 0, wsrc, INU, WPIECES);
         if (nchunk > 1) issue(in_plane(1, false), STU, wsrc + 2 * WUNITS, STU + INU, WPIECES);
         int st = 0;                                     // stage of chunk c
         for (int c = 0; c < nchunk; ++c) {
             wait_vm(c + 1 < nchunk ? cnt : 0);          // chunk c has landed (chunk c + 1 may still be in flight)
             cbarrier();               // ... for every wave; and every wave is done reading chunk c - 1
-            if (c + 2 < nchunk) {
-                const int s2 = st == 0 ? 2 : st - 1;    // (c + 2) % 3 == (c - 1) % 3
-                issue(in_plane(c + 2, false), s2 * STU, wsrc + (long)(c + 2) * (2 * WUNITS), s2 * STU + INU, WPIECES);
-            }
-            if (TTC_H16_ABL != 3) mfma_chunk(st * STU, st * STU + INU);
+            if (a.trace && c == 0) tr1 = __builtin_amdgcn_s_memtime();
+            const int s2 = st == 0 ? 2 : st - 1;        // (c + 2) % 3 == (c - 1) % 3
+            const int cn = c + 2 < nchunk ? c + 2 : c;  // nothing left to prefetch: an empty stage
+            Stage pend = stage_of(in_plane(cn, false), s2 * STU, wsrc + (long)cn * (2 * WUNITS), s2 * STU + INU, WPIECES);
+            if (c + 2 >= nchunk) pend.cnt = 0;
+            if (up_front) issue_some(pend, pend.cnt);
+            if (!(abl & 2)) mfma_chunk(st * STU, st * STU + INU, pend, per_kb);
+            issue_some(pend, pend.cnt);
             st = st == 2 ? 0 : st + 1;
         }
     } else {
         // LDS: HI[0] HI[1] LO W[0] W[1], W = [hi plane | lo plane]
         const int LOU = 2 * INU, WU0 = 3 * INU;
+        const int cntA = cnt_in + ((2 * WPIECES + 3) >> 2), cntB = cnt_in;
+        const int perA = (cntA + kKB - 1) / kKB, perB = (cntB + kKB - 1) / kKB;
         issue(in_plane(0, false), 0, wsrc, WU0, 2 * WPIECES);
-        issue(in_plane(0, true), LOU, nullptr, 0, 0);
+        issue(in_plane(0, true), LOU, wsrc, 0, 0);
         for (int c = 0; c < nchunk; ++c) {
             const int b = c & 1;
+            const bool more = c + 1 < nchunk;
+            const int cn = more ? c + 1 : c;
+            unsigned long long* tq = (a.trace && tid == 0 && c < 7) ? a.trace + (long)blockIdx.x * 64 + 8 + c * 6 : nullptr;
+            if (tq) tq[0] = __builtin_amdgcn_s_memtime();
             wait_vm(0);                                 // hi, lo and weights of chunk c have landed
+            if (tq) tq[1] = __builtin_amdgcn_s_memtime();
             cbarrier();               // ... for every wave; every wave is done with chunk c - 1
-            if (c + 1 < nchunk) issue(in_plane(c + 1, false), (b ^ 1) * INU, wsrc + (long)(c + 1) * (2 * WUNITS), WU0 + (b ^ 1) * 2 * WUNITS, 2 * WPIECES);
-            if (TTC_H16_ABL != 3) mfma_chunk(LOU, WU0 + b * 2 * WUNITS);          // x_lo * w_hi
+            if (tq) tq[2] = __builtin_amdgcn_s_memtime();
+            if (a.trace && c == 0) tr1 = __builtin_amdgcn_s_memtime();
+            Stage pa = stage_of(in_plane(cn, false), (b ^ 1) * INU, wsrc + (long)cn * (2 * WUNITS), WU0 + (b ^ 1) * 2 * WUNITS, 2 * WPIECES);
+            if (!more) pa.cnt = 0;
+            if (up_front) issue_some(pa, pa.cnt);
+            if (!(abl & 2)) mfma_chunk(LOU, WU0 + b * 2 * WUNITS, pa, perA);          // x_lo * w_hi
+            issue_some(pa, pa.cnt);
+            if (tq) tq[3] = __builtin_amdgcn_s_memtime();
             cbarrier();               // the lo tile is free
-            if (c + 1 < nchunk) issue(in_plane(c + 1, true), LOU, nullptr, 0, 0);
-            if (TTC_H16_ABL != 3) mfma_chunk_hi2(b * INU, WU0 + b * 2 * WUNITS);   // x_hi * w_lo + x_hi * w_hi
+            if (tq) tq[4] = __builtin_amdgcn_s_memtime();
+            Stage pb = stage_of(in_plane(cn, true), LOU, wsrc, 0, 0);
+            if (!more) pb.cnt = 0;
+            if (up_front) issue_some(pb, pb.cnt);
+            if (!(abl & 2)) mfma_chunk_hi2(b * INU, WU0 + b * 2 * WUNITS, pb, perB);   // x_hi * w_lo + x_hi * w_hi
+            issue_some(pb, pb.cnt);
+            if (tq) tq[5] = __builtin_amdgcn_s_memtime();
         }
     }
-    if (TTC_H16_ABL == 3) acc[0][0][0] = __builtin_bit_cast(float, smem[tid].x);
-
-    if (TTC_H16_ABL == 1) {
+    if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
+    if (abl & 1) {
         float t = 0.f;
         for (int g = 0; g < NCG; ++g) for (int j = 0; j < kQG; ++j) for (int r = 0; r < 16; ++r) t += acc[g][j][r];
-        if (t == 1234.5f) a.c.out[tid] = t;
+        if (t == 1234.5f) a.c.stats[tid] = t + __builtin_bit_cast(float, smem[tid].x);
     } else if (OUT == OUT_B16) {
         h16_epilogue_b16<BF, NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
     } else {
+        if constexpr (EPI <= EPI_SWISH) {
+            conv_epilogue_flat<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid, reinterpret_cast<float*>(smem),
+                                         (a.trace && tid == 0) ? a.trace + (long)blockIdx.x * 64 + 52 : nullptr);
+            goto done;
+        }
         conv_epilogue<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid);
+    }
+done:
+    if (a.trace && tid == 0) {
+        const unsigned long long tr3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tr4 = __builtin_amdgcn_s_memtime();
+        unsigned long long* t = a.trace + (long)blockIdx.x * 64;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = tr4;
+        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
+        t[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);          // HW_REG_XCC_ID
+        t[7] = ((unsigned long long)bq << 32) | (unsigned)n;
     }
 }
 
@@ -351,13 +433,49 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
     constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;
     const int TL = kBQ + 2 * a.c.Wp + 2;
     const int NIN = (TL + 63) >> 6;
-    const size_t lds = TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)(3 * NIN + 4 * WPIECES) * 1024;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const size_t lds = std::max(TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)(3 * NIN + 4 * WPIECES) * 1024,
+                                kFlatLdsBytes);
+    if (lds > 160 * 1024 || NIN > 16) return hipErrorInvalidValue;
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.c.Hp, a.c.Wp);
     dim3 grid(nblk_q * pw.ncb * n);
-    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds, s, a, nblk_q, pw.ncb);
+    static const int dbg = [] { const char* e = getenv("TTC_H16_DEBUG"); return e ? atoi(e) : 0; }();
+    size_t lds_req = lds;
+    if (dbg >= 2) lds_req = 100 * 1024;          // probe: force one workgroup per CU
+    if (dbg) {
+        static int shown = 0;
+        if (shown++ < 12) {
+            int nb = -1;
+            (void)lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds_req);
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, kThreads, lds_req);
+            fprintf(stderr, "[h16] terms %d ncg %d epi %d out %d: grid %u lds %zu B -> occupancy API %d blocks/CU (%s)\n", TERMS, NCG, EPI, OUT,
+                    grid.x, lds_req, nb, hipGetErrorString(e));
+        }
+    }
+    if (lds_req != lds) { if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds_req); e != hipSuccess) return e; }
+    static const char* trace_path = getenv("TTC_H16_TRACE");
+    static int trace_left = trace_path ? 1 : 0;
+    if (trace_left > 0 && grid.x > 4000 && NCG == 2 && EPI == EPI_RAW) {               // probe aid: per-workgroup timestamps of one big launch
+        trace_left--;
+        unsigned long long* d = nullptr;
+        const size_t bytes = (size_t)grid.x * 64 * sizeof(unsigned long long);
+        (void)hipStreamSynchronize(s);
+        if (hipMalloc(&d, bytes) == hipSuccess) {
+            (void)hipMemset(d, 0, bytes);
+            H16Args b = a; b.trace = d;
+            for (int rep = 0; rep < 2; ++rep) {          // second pass = warm
+                hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds_req, s, b, nblk_q, pw.ncb);
+                (void)hipStreamSynchronize(s);
+            }
+            std::vector<unsigned long long> h((size_t)grid.x * 64);
+            (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+            fprintf(stderr, "[h16] trace of terms %d ncg %d epi %d grid %u -> %s\n", TERMS, NCG, EPI, grid.x, trace_path);
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds_req, s, a, nblk_q, pw.ncb);
     return hipGetLastError();
 }
 
@@ -440,8 +558,13 @@ long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cou
     return per_set / 8;
 }
 
-hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, bool bf, int epi, int out_kind, int n, hipStream_t s) {
+hipError_t conv_launch_h16(const H16Args& a_in, const PackedConv& pw, bool bf, int epi, int out_kind, int n, hipStream_t s) {
     const int terms = pw.terms == 1 ? 1 : 3;
+    static const int desync_env = [] { const char* e = getenv("TTC_H16_DESYNC"); return e ? atoi(e) : -1; }();   // probe switches
+    H16Args a = a_in;
+    if (desync_env >= 0) a.desync = desync_env;
+    static const int abl_env = [] { const char* e = getenv("TTC_H16_ABL"); return e ? atoi(e) : 0; }();
+    a.abl = abl_env;
 #define TTC_H16_CASE(BFV, T, ncg, e, o) \
     if (bf == BFV && terms == T && pw.BN == ncg * 32 && epi == e && out_kind == o) return launch_h16<BFV, T, ncg, e, o>(a, pw, n, s);
 #define TTC_H16_LAYERS(BFV, T)                                                                         \

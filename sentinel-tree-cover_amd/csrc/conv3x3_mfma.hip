@@ -30,6 +30,8 @@
 //   Ablations of the 8-wave variant: no staging 1.02 ms; no staging + no output stores 0.99 ms; the bare
 //   MFMA + ds_read loop therefore runs at ~84 % of the 157 TFLOP/s peak (2.34 GHz measured clock,
 //   SQ_VALU_MFMA_BUSY 66-70 % overall), i.e. ~0.84 ms is the floor of this formulation.
+#include <algorithm>
+
 #include "conv_common.h"
 
 using namespace ttcconv;
@@ -169,6 +171,9 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
         }
     }
 
+    if constexpr (EPI <= EPI_SWISH) {
+        conv_epilogue_flat<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid, smem); return;
+    }
     conv_epilogue<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
 }
 
@@ -177,7 +182,7 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     constexpr int BN = NCG * 32;
     const int TL = kBQ + 2 * a.Wp + 2;
     const int TLp = (TL + 3) & ~3;
-    const size_t lds = (size_t)(CK * TLp + 9 * CK * BN) * sizeof(float);
+    const size_t lds = std::max((size_t)(CK * TLp + 9 * CK * BN) * sizeof(float), kFlatLdsBytes);
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_f32<CK, NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);

@@ -13,7 +13,9 @@ constexpr int kWaves = 4;
 constexpr int kQG = 4;                       // pixel groups (of 32) per wave
 constexpr int kBQ = kWaves * kQG * 32;       // 512 flattened positions per workgroup
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each, absolute error of the sigmoid <= 2e-7): libm's expf and the IEEE
+// division cost ~40 VALU instructions and enough temporaries to spill the 128 accumulators of the swish epilogue
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // XCD-aware tile order: the dispatcher deals workgroup ids round-robin over the 8 XCDs, so id -> (id % 8) owns
 // the contiguous slice [start(xcd), ...) of the logical tile list.  Neighbouring q tiles (which share a
@@ -89,27 +91,49 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     rv[r] = resn[ok ? (long)co * a.out_plane + opix : 0];
                 }
             }
+            float vv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float v = acc[g][j][r];
                 if (EPI == EPI_SSE) v *= gate;
                 if (EPI == EPI_SWISH) { v *= ratio; v = v * sigmoidf_(v); }
-                const bool ok = valid && (co < a.Cout);
                 if (EPI >= EPI_BIAS) {
                     if (co < a.Cout) v += aux[co];
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                     if (EPI == EPI_BIAS_RES) v = rv[r] + 0.1f * v;
                     if (EPI == EPI_BIAS_TANH_ADD) v = rv[r] + tanhf(v);
                 }
-                if (ok) outn[(long)co * a.out_plane + opix] = v;
-                if (EPI >= EPI_BIAS && any_dup && ok) {
-                    float* o = outn + (long)co * a.out_plane + opix;
-                    if (dup_y) o[dup_y] = v;
-                    if (dup_x) o[dup_x] = v;
-                    if (dup_y && dup_x) o[dup_y + dup_x] = v;
-                }
+                vv[r] = v;
                 if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
+            }
+            // stores: ONE exec-masked region per accumulator tile when the whole cout group is real (every layer but
+            // DSen2's 6-channel head), instead of a branch around each of the 16 stores
+            const bool group_full = (cb * BN + g * 32 + 32 <= a.Cout);
+            if (group_full) {
+                if (valid) {
+                    float* o = outn + (long)(cb * BN + g * 32 + 4 * hi) * a.out_plane + opix;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(long)((r & 3) + 8 * (r >> 2)) * a.out_plane] = vv[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (valid && co < a.Cout) outn[(long)co * a.out_plane + opix] = vv[r];
+                }
+            }
+            if (EPI >= EPI_BIAS && any_dup) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (valid && co < a.Cout) {
+                        float* o = outn + (long)co * a.out_plane + opix;
+                        if (dup_y) o[dup_y] = vv[r];
+                        if (dup_x) o[dup_x] = vv[r];
+                        if (dup_y && dup_x) o[dup_y + dup_x] = vv[r];
+                    }
+                }
             }
         }
     }
@@ -131,6 +155,111 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                     dst[0] = s; dst[1] = s2;
                 }
             }
+    }
+}
+
+// LDS bytes conv_epilogue_flat needs (one 32-cout group of a tile, rows padded by 4 floats)
+constexpr int kFlatRow = kBQ + 4;
+constexpr size_t kFlatLdsBytes = (size_t)32 * kFlatRow * sizeof(float);
+
+// Epilogue of the GroupNorm layers when the output keeps the input pitch (ConvArgs.flat_out): the tile's 512 positions are 512
+// CONSECUTIVE floats of every output plane.  The accumulator layout (lane = one position, 16 couts) would leave as 4-byte
+// stores -- 128 store instructions per wave whose issue, not HBM, bounds the tile's tail (measured: 4.8 us of a 23 us tile).
+// Instead each 32-cout group goes through LDS ([cout][position], free after the main loop) and leaves as rows:
+// wave w stores couts 8w .. 8w+7, a lane 4 consecutive positions -> 16 global_store_dwordx4 of 1 KiB per wave and group.
+// EPI op and the deterministic GroupNorm partial sums are the same as in conv_epilogue.
+template <int NCG, int EPI>
+__device__ __forceinline__ void conv_epilogue_flat(const ConvArgs& a, f32x16 (&acc)[NCG][kQG], int n, int cb, int bq, int nblk_q,
+                                                   const float* aux, int tid, float* lds, unsigned long long* tq = nullptr) {
+    static_assert(EPI <= EPI_SWISH, "flat output is for the GroupNorm layers");
+    if (tq) tq[0] = __builtin_amdgcn_s_memtime();
+    constexpr int BN = NCG * 32;
+    const int Wp = a.Wp, Hp = a.Hp;
+    const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
+    const int q0 = bq * kBQ;
+    const int Hout = Hp - 2, Wout = Wp - 2;
+    float ssum[NCG][4], ssq[NCG][4];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ssum[g][k] = 0.f; ssq[g][k] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < kQG; ++j) {
+        const int q = q0 + (wave * kQG + j) * 32 + lo;
+        const int y = q / Wp, x = q - y * Wp;
+        const bool valid = (x < Wout) && (y < Hout);
+        float gate = 1.0f;
+        if (EPI == EPI_SSE) {
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot += aux[(r & 3) + 8 * (r >> 2) + 4 * hi] * acc[0][j][r];
+            dot += __shfl_xor(dot, 32);
+            gate = sigmoidf_(dot);
+        }
+        float ratio = 1.0f;
+        if (EPI == EPI_SWISH && a.same_pad) {
+            const bool ey = (y == 0) || (y == Hout - 1), ex = (x == 0) || (x == Wout - 1);
+            ratio = (ey && ex) ? 2.25f : ((ey || ex) ? 1.5f : 1.0f);
+        }
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[g][j][r];
+                if (EPI == EPI_SSE) v *= gate;
+                if (EPI == EPI_SWISH) { v *= ratio; v = v * sigmoidf_(v); }
+                acc[g][j][r] = v;
+                if (valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
+            }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = ssum[g][k], s2 = ssq[g][k];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
+                const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
+                if (lo == 0 && quad * 4 < a.Cout) {
+                    float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
+                    dst[0] = s; dst[1] = s2;
+                }
+            }
+    }
+    if (tq) tq[1] = __builtin_amdgcn_s_memtime();
+    float* outn = a.out + (long)n * a.out_stride_n;
+    const long qend = (long)Hout * Wp;                 // positions of the rows that exist
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) {
+        __syncthreads();                               // LDS is free: every wave is past its last MFMA read / previous group
+        if (tq && g == 0) tq[2] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int j = 0; j < kQG; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds[((r & 3) + 8 * (r >> 2) + 4 * hi) * kFlatRow + (wave * kQG + j) * 32 + lo] = acc[g][j][r];
+        if (tq && g == 0) tq[3] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (tq && g == 0) tq[4] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wave * 8 + i, co = cb * BN + g * 32 + row;
+            if (co >= a.Cout) continue;
+            float* orow = outn + (long)co * a.out_plane;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p4 = (h * 64 + lane) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(lds + row * kFlatRow + p4);
+                if (q0 + p4 + 3 < qend) *reinterpret_cast<float4*>(orow + q0 + p4) = v;
+                else {                                         // ragged end of a plane whose size is not a multiple of 4
+                    if (q0 + p4 < qend) orow[q0 + p4] = v.x;
+                    if (q0 + p4 + 1 < qend) orow[q0 + p4 + 1] = v.y;
+                    if (q0 + p4 + 2 < qend) orow[q0 + p4 + 2] = v.z;
+                }
+            }
+        }
+        if (tq && g == 0) tq[5] = __builtin_amdgcn_s_memtime();
     }
 }
 

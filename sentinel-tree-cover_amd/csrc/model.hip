@@ -74,12 +74,12 @@ struct GruParams { const float* base; long dir_stride; };   // per-direction par
 
 __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm,
                              const float* __restrict__ hcur, float* __restrict__ rh, int H, int W, int N) {
-    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
-    const int s = reflect_idx(py - 1, H) * W + reflect_idx(px - 1, W);
+    const int s = reflect_idx(py - 1, H) * Wp + reflect_idx(px - 1, W);
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yg + (long)n * 64 * P + s;
     const float* g = gn + (long)n * 32;      // 16 groups x (mean, rstd): 0-7 r, 8-15 u
@@ -101,14 +101,15 @@ __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restri
                              const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
                              const float* __restrict__ hcur, float* __restrict__ hnext,
                              float* __restrict__ gru_out, int H, int W, int N, float z) {
-    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
     const int sy0 = py - 1, sx0 = px - 1;
     const bool interior = sy0 >= 0 && sy0 < H && sx0 >= 0 && sx0 < W;
-    const int s = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);
+    const int s = reflect_idx(sy0, H) * Wp + reflect_idx(sx0, W);
+    const int su = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);      // the debug copy of u stays [c][H][W]
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yc + (long)n * 32 * P + s;
     const float* g = gn + (long)n * 16;      // 8 groups x (mean, rstd)
@@ -117,13 +118,13 @@ __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restri
     const float* h = hcur + (long)n * 32 * PP + p;
     float* hn = hnext + (long)n * 32 * PP + p;
     float* go = gru_out ? gru_out + ((long)(n - dir * N) * 64 + dir * 32) * PP + p : nullptr;
-    float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * P + s : nullptr;
+    float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * (H * W) + su : nullptr;
 #pragma unroll 4
     for (int c = 0; c < 32; ++c) {
         const int gi = c >> 2;
         const float cand = tanh_fast((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
         const float uv = sigm((yu[(long)c * P] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
-        if (uk) uk[(long)c * P] = uv;
+        if (uk) uk[(long)c * (H * W)] = uv;
         const float hv = h[(long)c * PP];
         const float hnew = uv * hv + (1.0f - uv) * cand;
         const float hz = hv * z + hnew * (1.0f - z);
@@ -140,7 +141,7 @@ enum GatherMode : int { G_COPY = 0, G_POOL = 1, G_UP = 2 };
 struct FinArgs {
     const float* y; const float* gn; const float* prm;
     float* dst;
-    int C, Hs, Ws;        // source (raw conv output) dims
+    int C, Hs, Ws;        // source (raw conv output) dims; its rows have pitch Ws + 2 (the conv's input pitch)
     int Hd, Wd;           // destination dims INCLUDING pad
     int pad, crop, mode;
     long dst_stride_n;    // floats per n in dst (lets two producers share a concat buffer)
@@ -164,7 +165,8 @@ __global__ void k_block_finalize(FinArgs a) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= a.Hd * a.Wd) return;
     const int dy = d / a.Wd, dx = d - dy * a.Wd;
-    const long PS = (long)a.Hs * a.Ws, PD = (long)a.Hd * a.Wd;
+    const int SP = a.Ws + 2;
+    const long PS = (long)a.Hs * SP, PD = (long)a.Hd * a.Wd;
     float* dst = a.dst + (long)n * a.dst_stride_n + (long)a.dst_coff * PD + d;
     const int iy = dy - a.pad, ix = dx - a.pad;
     if (iy < 0 || ix < 0 || iy >= a.Hd - 2 * a.pad || ix >= a.Wd - 2 * a.pad) {
@@ -173,10 +175,10 @@ __global__ void k_block_finalize(FinArgs a) {
     }
     constexpr int NS = (MODE == G_POOL) ? 4 : 1;
     int src[NS];
-    if (MODE == G_COPY) src[0] = (iy + a.crop) * a.Ws + ix + a.crop;
-    if (MODE == G_UP) src[0] = (iy >> 1) * a.Ws + (ix >> 1);
+    if (MODE == G_COPY) src[0] = (iy + a.crop) * SP + ix + a.crop;
+    if (MODE == G_UP) src[0] = (iy >> 1) * SP + (ix >> 1);
     if (MODE == G_POOL) {
-        src[0] = (2 * iy) * a.Ws + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + a.Ws; src[3] = src[2] + 1;
+        src[0] = (2 * iy) * SP + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + SP; src[3] = src[2] + 1;
     }
     const float* y = a.y + (long)n * C * PS;
     float gate[NS];
@@ -211,13 +213,14 @@ __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const float* y = yraw + (long)n * C * P + p;
+    const int oh = P / ow;
+    const long PS = (long)oh * (ow + 2);                                   // raw plane with the conv's input pitch
+    const float* y = yraw + (long)n * C * PS + (p / ow) * (ow + 2) + p % ow;
     float gate = prm[3 * C];
-    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * P] * sm[c] + sm[C + c]);
+    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * PS] * sm[c] + sm[C + c]);
     gate = sigm(gate);
     float logit = headp[C];
-    for (int c = 0; c < C; ++c) logit += sm[3 * C + c] * ((y[(long)c * P] * sm[c] + sm[C + c]) * gate);
-    const int oh = P / ow;
+    for (int c = 0; c < C; ++c) logit += sm[3 * C + c] * ((y[(long)c * PS] * sm[c] + sm[C + c]) * gate);
     out[(long)n * P + (tr ? (p % ow) * oh + p / ow : p)] = sigm(logit);      // tr: the plane is the transposed window
 }
 
@@ -250,13 +253,14 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const float* y = yraw + (long)n * C * P + p;
-    float gate = prm[3 * C];
-    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * P] * sm[c] + sm[C + c]);
-    gate = sigm(gate);
     const int oh = P / ow;
+    const long PS = (long)oh * (ow + 2);                                   // raw plane with the conv's input pitch
+    const float* y = yraw + (long)n * C * PS + (p / ow) * (ow + 2) + p % ow;
+    float gate = prm[3 * C];
+    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * PS] * sm[c] + sm[C + c]);
+    gate = sigm(gate);
     float* o = out + ((long)n * P + (tr ? (p % ow) * oh + p / ow : p)) * C;
-    for (int c = 0; c < C; ++c) o[c] = (y[(long)c * P] * sm[c] + sm[C + c]) * gate;
+    for (int c = 0; c < C; ++c) o[c] = (y[(long)c * PS] * sm[c] + sm[C + c]) * gate;
 }
 
 // ======================================================================================================================
@@ -266,12 +270,12 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
 template <bool BF>
 __global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm, B16 hcur, B16 rh,
                                  int H, int W, int N) {
-    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
-    const int s = reflect_idx(py - 1, H) * W + reflect_idx(px - 1, W);
+    const int s = reflect_idx(py - 1, H) * Wp + reflect_idx(px - 1, W);
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yg + (long)n * 64 * P + s;
     const float* g = gn + (long)n * 32;
@@ -294,20 +298,21 @@ template <bool BF>
 __global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
                                  const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
                                  B16 hcur, B16 hnext, B16 gru_out, int H, int W, int N, float z) {
-    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * W;
+    const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= PP) return;
     const int py = p / Wp, px = p - py * Wp;
     const int sy0 = py - 1, sx0 = px - 1;
     const bool interior = sy0 >= 0 && sy0 < H && sx0 >= 0 && sx0 < W;
-    const int s = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);
+    const int s = reflect_idx(sy0, H) * Wp + reflect_idx(sx0, W);
+    const int su = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);      // the debug copy of u stays [c][H][W]
     const float* pr = prm.base + dir * prm.dir_stride;
     const float* y = yc + (long)n * 32 * P + s;
     const float* g = gn + (long)n * 16;
     const float* yu = yg + ((long)n * 64 + 32) * P + s;
     const float* gu = gn_gates + (long)n * 32 + 16;
-    float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * P + s : nullptr;
+    float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * (H * W) + su : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long u = ((long)n * 4 + k) * PP + p;
@@ -318,7 +323,7 @@ __global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __re
             const int c = 8 * k + j, gi = c >> 2;
             const float cand = tanh_fast((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
             const float uv = sigm((yu[(long)c * P] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
-            if (uk) uk[(long)c * P] = uv;
+            if (uk) uk[(long)c * (H * W)] = uv;
             const float hnew = uv * hv[j] + (1.0f - uv) * cand;
             o[j] = hv[j] * z + hnew * (1.0f - z);
         }
@@ -348,7 +353,8 @@ __global__ void k_block_finalize_b16(FinArgs a) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= a.Hd * a.Wd) return;
     const int dy = d / a.Wd, dx = d - dy * a.Wd;
-    const long PS = (long)a.Hs * a.Ws, PD = (long)a.Hd * a.Wd;
+    const int SP = a.Ws + 2;
+    const long PS = (long)a.Hs * SP, PD = (long)a.Hd * a.Wd;
     const long u0 = (long)n * a.dst_stride_n + (long)a.dst_coff * PD + d;
     const int iy = dy - a.pad, ix = dx - a.pad;
     if (iy < 0 || ix < 0 || iy >= a.Hd - 2 * a.pad || ix >= a.Wd - 2 * a.pad) {
@@ -358,10 +364,10 @@ __global__ void k_block_finalize_b16(FinArgs a) {
     }
     constexpr int NS = (MODE == G_POOL) ? 4 : 1;
     int src[NS];
-    if (MODE == G_COPY) src[0] = (iy + a.crop) * a.Ws + ix + a.crop;
-    if (MODE == G_UP) src[0] = (iy >> 1) * a.Ws + (ix >> 1);
+    if (MODE == G_COPY) src[0] = (iy + a.crop) * SP + ix + a.crop;
+    if (MODE == G_UP) src[0] = (iy >> 1) * SP + (ix >> 1);
     if (MODE == G_POOL) {
-        src[0] = (2 * iy) * a.Ws + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + a.Ws; src[3] = src[2] + 1;
+        src[0] = (2 * iy) * SP + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + SP; src[3] = src[2] + 1;
     }
     const float* y = a.y + (long)n * C * PS;
     float gate[NS];
@@ -468,6 +474,7 @@ ttc_status model_alloc(ttc_ctx* c) {
     if (model_rows(c->cfg) % 4 != 0 || model_rows(c->cfg) < 28) return c->fail(TTC_ERR_ARG, "win_rows must be a multiple of 4 and >= 28 (or 0)");
     if (F != 64 || Hd != 32 || C != 17) return c->fail(TTC_ERR_ARG, "only base_filters=64, hidden=32, n_bands=17 are built");
     auto area = [&](int Axis::*m, int pad) { return (size_t)(g.y.*m + pad) * (g.x.*m + pad); };
+    auto rawa = [&](int Axis::*m) { return (size_t)(g.y.*m) * (g.x.*m + 2); };     // raw conv output: rows keep the input pitch
     const size_t Pc1 = area(&Axis::c1, 0), Pc2 = area(&Axis::c2, 0), Pu2 = area(&Axis::u2, 0), Pu2p = area(&Axis::u2, 2);
     const size_t Pu3 = area(&Axis::u3, 0), Pu3p = area(&Axis::u3, 2), Po = area(&Axis::o, 0);
     const size_t Ph2 = (size_t)(g.y.c1 / 2) * (g.x.c1 / 2);
@@ -477,11 +484,12 @@ ttc_status model_alloc(ttc_ctx* c) {
     if (!c->alloc_b16(c->field, (units))) return c->fail(TTC_ERR_NOMEM, "hipMalloc " name)
     const bool half = c->half();
     A(frames, N * (g.L + 1) * C * PP, "frames");
-    A(yg, N2 * 2 * Hd * P, "yg"); A(ug, N2 * Hd * P, "u"); A(yc, N2 * Hd * P, "yc");
-    A(y_med, N * F * P, "y_med"); A(y_cat, N * F * P, "y_cat");
-    A(y_c1, N * 2 * F * Pc1, "y_c1"); A(y_c2, N * 4 * F * Pc2, "y_c2");
-    A(y_u2, N * 2 * F * Pu2, "y_u2"); A(y_u2o, N * 2 * F * Pu2, "y_u2o");
-    A(y_u3, N * F * Pu3, "y_u3"); A(y_out, N * F * Po, "y_out");
+    const size_t Pr = (size_t)g.y.n * g.x.np;
+    A(yg, N2 * 2 * Hd * Pr, "yg"); A(ug, N2 * Hd * P, "u"); A(yc, N2 * Hd * Pr, "yc");
+    A(y_med, N * F * Pr, "y_med"); A(y_cat, N * F * Pr, "y_cat");
+    A(y_c1, N * 2 * F * rawa(&Axis::c1), "y_c1"); A(y_c2, N * 4 * F * rawa(&Axis::c2), "y_c2");
+    A(y_u2, N * 2 * F * rawa(&Axis::u2), "y_u2"); A(y_u2o, N * 2 * F * rawa(&Axis::u2), "y_u2o");
+    A(y_u3, N * F * rawa(&Axis::u3), "y_u3"); A(y_out, N * F * rawa(&Axis::o), "y_out");
     if (!half) {
         A(h[0], N2 * Hd * PP, "h0"); A(h[1], N2 * Hd * PP, "h1"); A(rh, N2 * Hd * PP, "rh");
         A(gru_out, N * F * PP, "gru_out");
@@ -635,7 +643,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
     const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
-    const long PP = (long)Hp * Wp, P = (long)H * W;
+    const long PP = (long)Hp * Wp, P = (long)H * W, Pr = (long)H * Wp;
     const int Cx8 = (Cx + 7) / 8, Hd8 = Hd / 8;
     const float* sm = c->d_small;
     float* gn_slot[10];
@@ -667,7 +675,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
         a.seg[0] = {c->frames16.hi, c->frames16.lo, (long)(g.L + 1) * Cx8 * PP, {(long)st * Cx8 * PP, (long)(g.L - 1 - st) * Cx8 * PP}, Cx8};
         a.seg[1] = {c->h16[cur].hi, c->h16[cur].lo, (long)Hd8 * PP, {0, (long)N * Hd8 * PP}, Hd8};
         a.c.Hp = Hp; a.c.Wp = Wp; a.c.Cout = 2 * Hd; a.c.n_per_set = N;
-        a.c.out = c->yg; a.c.out_stride_n = 2L * Hd * P; a.c.out_plane = P; a.c.out_pitch = W;
+        a.c.out = c->yg; a.c.out_stride_n = 2L * Hd * Pr; a.c.out_plane = Pr; a.c.out_pitch = Wp;
         a.c.stats = c->stats;
         { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
@@ -678,7 +686,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
             TTC_HIP(c, hipGetLastError());
         }
         a.seg[1].hi = c->rh16.hi; a.seg[1].lo = c->rh16.lo;
-        a.c.Cout = Hd; a.c.out = c->yc; a.c.out_stride_n = (long)Hd * P;
+        a.c.Cout = Hd; a.c.out = c->yc; a.c.out_stride_n = (long)Hd * Pr;
         a.c.aux = gp.base + 4 * 32; a.c.aux_set_stride = gp.dir_stride;
         { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2)); }
         TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
@@ -699,8 +707,8 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
         H16Args a{};
         a.seg[0] = s0; a.seg[1] = s1;
         a.c.Hp = in.h; a.c.Wp = in.w; a.c.Cout = kBlockCout[b]; a.c.n_per_set = N;
-        const long Po = (long)(in.h - 2) * (in.w - 2);
-        a.c.out = out; a.c.out_stride_n = (long)a.c.Cout * Po; a.c.out_plane = Po; a.c.out_pitch = in.w - 2;
+        const long Po = (long)(in.h - 2) * (in.w - 2), Pro = (long)(in.h - 2) * in.w;
+        a.c.out = out; a.c.out_stride_n = (long)a.c.Cout * Pro; a.c.out_plane = Pro; a.c.out_pitch = in.w;
         a.c.stats = c->stats; a.c.same_pad = same;
         { KTimer kt(c, tname, s); TTC_CHECK(launch(a, c->w_block[b], EPI_SWISH, N)); }
         return gn_fin(c, gn_slot[b], N, a.c.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.c.Cout / 8) * Po, s);
@@ -767,7 +775,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
     const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
-    const long PP = (long)Hp * Wp, P = (long)H * W;
+    const long PP = (long)Hp * Wp, P = (long)H * W, Pr = (long)H * Wp;
     const float* sm = c->d_small;
     float* gn_slot[10];
     for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
@@ -783,7 +791,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         a.seg[1] = {c->h[cur], (long)Hd * PP, {0, (long)N * Hd * PP}, Hd};
         a.Cin = Cx + Hd; a.Hp = Hp; a.Wp = Wp; a.Cout = 2 * Hd;
         a.w = c->w_gates.d_w; a.w_set_stride = c->w_gates.set_stride; a.n_per_set = N;
-        a.out = c->yg; a.out_stride_n = 2L * Hd * P; a.out_plane = P; a.out_pitch = W; a.oy = a.ox = 0;
+        a.out = c->yg; a.out_stride_n = 2L * Hd * Pr; a.out_plane = Pr; a.out_pitch = Wp; a.oy = a.ox = 0;
         a.stats = c->stats;
         { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
@@ -795,7 +803,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         }
         a.seg[1].base = c->rh;
         a.Cout = Hd; a.w = c->w_cand.d_w; a.w_set_stride = c->w_cand.set_stride;
-        a.out = c->yc; a.out_stride_n = (long)Hd * P;
+        a.out = c->yc; a.out_stride_n = (long)Hd * Pr;
         a.aux = gp.base + 4 * 32; a.aux_set_stride = gp.dir_stride;
         { KTimer kt(c, "conv_cand", s); TTC_HIP(c, conv_launch(a, c->w_cand, EPI_SSE, N2, s)); }
         TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
@@ -816,8 +824,8 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         ConvArgs a{};
         a.seg[0] = s0; a.seg[1] = s1; a.Cin = s0.C + s1.C; a.Hp = in.h; a.Wp = in.w; a.Cout = kBlockCout[b];
         a.w = c->w_block[b].d_w; a.w_set_stride = 0; a.n_per_set = N;
-        const long Po = (long)(in.h - 2) * (in.w - 2);
-        a.out = out; a.out_stride_n = (long)a.Cout * Po; a.out_plane = Po; a.out_pitch = in.w - 2; a.oy = a.ox = 0;
+        const long Po = (long)(in.h - 2) * (in.w - 2), Pro = (long)(in.h - 2) * in.w;
+        a.out = out; a.out_stride_n = (long)a.Cout * Pro; a.out_plane = Pro; a.out_pitch = in.w; a.oy = a.ox = 0;
         a.stats = c->stats; a.same_pad = same;
         { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
         return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.Cout / 8) * Po, s);

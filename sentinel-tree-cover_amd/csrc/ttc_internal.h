@@ -66,6 +66,9 @@ struct ConvArgs {
     const float* res;    // EPI_BIAS_RES / _TANH_ADD: residual, same indexing as out
     int same_pad;        // EPI_SWISH: 1 -> multiply by the partial-conv ratio (zero-padded SAME conv)
     int reflect_out;     // EPI_BIAS*: 1 -> also write the 1-px reflect rim of the (padded) output plane
+    // EPI <= EPI_SWISH (the GroupNorm layers): the output ALWAYS keeps the input pitch -- out_pitch == Wp, oy == ox == 0,
+    // out_plane == (Hp-2)*Wp: out[co][q] for the tile's own flat positions q, junk columns included -- so that a tile leaves
+    // through an LDS transpose as fully coalesced 16-byte stores (conv_epilogue_flat); out_pitch / oy / ox are ignored there
 };
 
 struct PackedConv {      // device copy of one layer's packed weights
@@ -123,6 +126,9 @@ struct H16Args {
     long w_set_stride;
     // channel-blocked 16-bit output (OUT_B16 kernels): [n][Cout8][o_plane] hi (+ lo), pixel (y + c.oy) * c.out_pitch + x + c.ox
     uint4* o_hi; uint4* o_lo; long o_stride_n; long o_plane;
+    int abl;             // probe aid, see conv3x3_h16.hip (0 in production)
+    unsigned long long* trace;   // probe aid: per-workgroup timestamps (8 x u64 each) or nullptr
+    int desync;          // probe switches (env TTC_H16_DESYNC): 4096 = issue a stage's copies up front, 8192 = staggered issue; 0 in production
     const uint4* r_hi; const uint4* r_lo;   // EPI_BIAS_RES residual in the same blocked layout / indexing as the output
     ConvArgs c;          // geometry (Hp, Wp, Cout, n_per_set) and the fp32 epilogue operands (out, stats, aux, res, ...)
 };

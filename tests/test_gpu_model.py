@@ -46,11 +46,11 @@ def test_single_step_intermediates():
     out = ctx.forward_windows(x).cpu().numpy()
     P = W * W
     fails = []
-    yg = ctx.debug_fetch("yg", (2 * N, 64, W, W))
+    yg = ctx.debug_fetch("yg", (2 * N, 64, W, W + 2))[..., :W]      # raw conv outputs keep the input pitch (W + 2)
     for d, name in enumerate(("fw", "bw")):
         ok, m = _cmp("yg_" + name, yg[d * N:(d + 1) * N], tr["yg_" + name], 2e-5); ok or fails.append(m)
     u = ctx.debug_fetch("u", (2 * N, 32, W, W))
-    yc = ctx.debug_fetch("yc", (2 * N, 32, W, W))
+    yc = ctx.debug_fetch("yc", (2 * N, 32, W, W + 2))[..., :W]
     for d, name in enumerate(("fw", "bw")):
         ok, m = _cmp("u_" + name, u[d * N:(d + 1) * N], tr["u_" + name], 2e-5); ok or fails.append(m)
         ok, m = _cmp("yc_" + name, yc[d * N:(d + 1) * N], tr["yc_" + name], 2e-5); ok or fails.append(m)
@@ -61,7 +61,7 @@ def test_single_step_intermediates():
     for buf, name, C, H in [("y_med", "conv_median", 64, W), ("y_cat", "conv_concat", 64, W), ("y_c1", "conv1", 128, c1),
                             ("y_c2", "conv2", 256, c2), ("y_u2", "up2", 128, u2), ("y_u2o", "up2_out", 128, u2),
                             ("y_u3", "up3", 64, u3), ("y_out", "out", 64, o)]:
-        ok, m = _cmp(buf, ctx.debug_fetch(buf, (N, C, H, H)), tr["raw_" + name], 5e-5); ok or fails.append(m)
+        ok, m = _cmp(buf, ctx.debug_fetch(buf, (N, C, H, H + 2))[..., :H], tr["raw_" + name], 5e-5); ok or fails.append(m)
     ok, m = _cmp("prob", out, ref[..., 0], PROB_TOL); ok or fails.append(m)
     assert not fails, "\n".join(fails)
 
@@ -87,7 +87,7 @@ def test_forward_bf16x3_matches_oracle(W, L, N):
     np.testing.assert_array_equal(out, ctx.forward_windows(x).cpu().numpy())
     # the raw gate pre-activations (one conv deep) stay within 16-bit-operand rounding of the fp32 values
     if L == 2:
-        yg = ctx.debug_fetch("yg", (2 * N, 64, W, W))
+        yg = ctx.debug_fetch("yg", (2 * N, 64, W, W + 2))[..., :W]      # raw conv outputs keep the input pitch (W + 2)
         assert np.isfinite(yg).all()
 
 
@@ -105,7 +105,7 @@ def test_feature_taps_match_oracle():
     gp, ge, gl = sess.ctx.forward_taps(x)
     fails = []
     for name, got, ref, tol in [("probs", gp.cpu().numpy(), probs[..., 0], PROB_TOL), ("early", ge.cpu().numpy(), early, 2e-5),
-                                ("late", gl.cpu().numpy(), late, 1e-4)]:
+                                ("late", gl.cpu().numpy(), late, 2e-4)]:      # values up to ~10; the conv epilogue evaluates swish with v_exp / v_rcp
         ok, m = _cmp(name, got, ref, tol); ok or fails.append(m)
     assert not fails, "\n".join(fails)
     via = sess.run([job.PREDICT_EARLYFEATS, job.PREDICT_LATEFEATS], feed_dict={job.PREDICT_INP: x})

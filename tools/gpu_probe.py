@@ -9,8 +9,9 @@ from ttc import _lib, synth, weights
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 172
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 36
-PREC = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=PREC)
+PREC = sys.argv[4] if len(sys.argv) > 4 else "fp32"        # fp32 | bf16x3 | fp16 | bf16
+MASK = int(sys.argv[5], 0) if len(sys.argv) > 5 else None     # one_term_layers of the 16-bit engine
+ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=PREC, one_term_layers=MASK)
 ctx.load_weights(weights.synth_weights(0))
 x = torch.from_numpy(synth.synth_windows(seed=1, N=N, L=L, W=W)).cuda()
 print("device bytes", ctx.device_bytes / 1e9, "GB")
@@ -30,7 +31,7 @@ ctx.timing(True)
 for _ in range(3):
     ctx.forward_windows(x)
 tot = 0
-for k in ["frames_from_nhwc", "conv_gates", "conv_cand", "gn_finalize", "gru_apply1", "gru_apply2", "conv_median",
+for k in ["frames_from_nhwc", "frames_to_b16", "conv_gates", "conv_cand", "gn_finalize", "gru_apply1", "gru_apply2", "conv_median",
           "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out_conv", "block_finalize", "head"]:
     ms, n = ctx.kernel_ms(k)
     per_fwd = ms * n / 3

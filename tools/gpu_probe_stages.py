@@ -47,7 +47,7 @@ names = sys.argv[1:] or []
 import ctypes as C
 for k in ["upsample_20m", "feather", "aligned_mosaic", "gapfill_dates", "clouds_in_mosaic", "dsen2_gather", "dsen2_border", "dsen2_conv",
           "dsen2_scatter", "missing_counts", "fix_missing", "tile_temporal", "tile_s1", "assemble", "bright", "post",
-          "frames_from_nhwc", "conv_gates", "conv_cand", "gn_finalize", "gru_apply1", "gru_apply2", "conv_median", "conv_concat",
+          "frames_from_nhwc", "frames_to_b16", "conv_gates", "conv_cand", "gn_finalize", "gru_apply1", "gru_apply2", "conv_median", "conv_concat",
           "conv1", "conv2", "up2", "up2_out", "up3", "out_conv", "block_finalize", "head", "mosaic"] + names:
     try:
         ms, n = ctx.kernel_ms(k)
