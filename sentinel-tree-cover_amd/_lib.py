@@ -36,124 +36,15 @@ class TTCConfig(C.Structure):
                 ("one_term_layers", C.c_uint32)]
 
 
-# ttc_config.precision values and the default per-layer map of the 16-bit engine (ttc.h): with L <= 4 ConvGRU steps fp16
-# runs the gates conv (bit 0) with plain fp16 operands (max |dprob| 2e-4 on the oracle; the error grows with the number
-# of recurrent steps: 6.5e-4 at L = 12, too close to the 1e-3 contract), every other conv with three split products;
-# bf16 needs three everywhere
+# ttc_config.precision values.  The 16-bit engine multiplies three split products in every layer by default
+# (one_term_layers = 0).  Measured with as-stored-scale kernels: running only the ConvGRU gates conv (bit 0) with plain fp16
+# operands keeps max |dprob| at 2e-4 (L = 4) .. 6.5e-4 (L = 12) on white-noise windows, but reaches 3.0e-3 on a real
+# (spatially smooth) 618^2 tile, outside the 1e-3 contract -- so no layer runs one product unless the caller asks for it.
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16": 3}
 
 
 def default_one_term(precision, length):
-    return 0x1 if (precision == 2 and length <= 4) else 0
-
-
-class TTCResegWindow(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("pred_off", C.c_int64), ("weight_off", C.c_int64)]
-
-
-class TTCTensor(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32),
-                ("shape", C.c_int64 * 4)]
-
-
-_lib = None
-
-
-def load():
-    """dlopen libttc_hip.so and declare prototypes; raises if the library is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C sentinel-tree-cover_amd/csrc`).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    P, I32, F32P, VP = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p
-    lib.ttc_version.restype = C.c_char_p
-    lib.ttc_create.argtypes = [C.POINTER(P), I32, C.POINTER(TTCConfig)]
-    lib.ttc_destroy.argtypes = [P]
-    lib.ttc_destroy.restype = None
-    lib.ttc_last_error.argtypes = [P]
-    lib.ttc_last_error.restype = C.c_char_p
-    lib.ttc_device_bytes.argtypes = [P]
-    lib.ttc_device_bytes.restype = C.c_size_t
-    lib.ttc_load_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
-    lib.ttc_load_dsen2_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
-    lib.ttc_forward_windows.argtypes = [P, VP, I32, VP, VP]
-    lib.ttc_process_subtiles.argtypes = [P, VP, I32, I32, I32, F32P, C.POINTER(C.c_int32), VP, VP, VP,
-                                         C.POINTER(C.c_double), C.POINTER(C.c_double), I32, I32, VP, VP, VP]
-    lib.ttc_tile_missing_counts.argtypes = [P, VP, I32, I32, I32, VP, VP]
-    lib.ttc_tile_fix_missing.argtypes = [P, VP, I32, I32, I32, I32, I32, VP]
-    lib.ttc_mosaic.argtypes = [P, VP, I32, C.POINTER(C.c_int32), I32, I32, I32, VP, VP, VP]
-    lib.ttc_dsen2_forward.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
-    lib.ttc_superresolve_tile.argtypes = [P, VP, I32, I32, I32, I32, VP]
-    lib.ttc_upsample_20m.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
-    lib.ttc_feather.argtypes = [P, VP, I32, I32, I32, I32, I32, VP, VP]
-    lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
-    lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
-                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
-    lib.ttc_sen2cor_clean.argtypes = [P, VP, I32, I32, I32, VP, VP]
-    lib.ttc_median5.argtypes = [P, VP, I32, I32, VP, VP]
-    lib.ttc_snow_map.argtypes = [P, VP, I32, I32, I32, VP, VP, VP]
-    lib.ttc_merge_cloud_masks.argtypes = [P, VP, VP, VP, C.c_int64, VP]
-    lib.ttc_count_positive.argtypes = [P, VP, I32, I32, VP, VP]
-    lib.ttc_clip01.argtypes = [P, VP, C.c_int64, VP]
-    lib.ttc_divide.argtypes = [P, VP, C.c_int64, C.c_float, VP]
-    lib.ttc_debug_keep.argtypes = [P, I32]
-    lib.ttc_debug_clouds_stage.argtypes = [P, I32]
-    lib.ttc_identify_clouds_shadows.argtypes = [P, VP, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP]
-    lib.ttc_mosaic_features.argtypes = [P, VP, I32, VP, I32, I32, I32, I32, VP, VP]
-    lib.ttc_forward_taps.argtypes = [P, VP, I32, VP, VP, VP, VP]
-    lib.ttc_float_to_int16.argtypes = [P, VP, C.c_int64, C.c_float, VP, VP]
-    lib.ttc_u16_to_float.argtypes = [P, VP, C.c_int64, VP, VP]
-    lib.ttc_float_to_u16.argtypes = [P, VP, C.c_int64, VP, VP]
-    lib.ttc_s1_to_db.argtypes = [P, VP, I32, I32, I32, VP, VP]
-    lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.ttc_debug_timing.argtypes = [P, I32]
-    lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    for name in EXPORTS:
-        fn = getattr(lib, name)          # AttributeError here == missing export
-        if name not in ("ttc_version", "ttc_destroy", "ttc_last_error", "ttc_device_bytes"):
-            fn.restype = C.c_int
-    _lib = lib
-    return lib
-
-
-def write_geotiff_u8(path, raster, west, south, east, north):
-    """ttc_write_geotiff_u8: raster uint8 [rows, cols] (numpy) -> LZW GeoTIFF at `path` (host-side, no GPU needed)"""
-    a = np.ascontiguousarray(raster, dtype=np.uint8)
-    lib = load()
-    lib.ttc_write_geotiff_u8.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
-    st = lib.ttc_write_geotiff_u8(str(path).encode(), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], float(west), float(south),
-                                  float(east), float(north))
-    if st != 0:
-        raise RuntimeError(f"ttc_write_geotiff_u8: status {st} ({path})")
-    return str(path)
-
-
-def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError("no MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
-                           "the tree-cover hot path has no CPU fallback")
-    return torch
-
-
-def pack_tensors(weights: dict):
-    """dict name -> float32 ndarray  ==>  (ctypes array of TTCTensor, keepalive list)."""
-    arr = (TTCTensor * len(weights))()
-    keep = []
-    for i, (k, v) in enumerate(weights.items()):
-        a = np.ascontiguousarray(v, dtype=np.float32)
-        keep.append(a)
-        arr[i].name = k.encode()
-        arr[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
-        arr[i].ndim = min(a.ndim, 4)
-        for d in range(min(a.ndim, 4)):
-            arr[i].shape[d] = a.shape[d]
-    return arr, keep
+    return 0
 
 
 class Context:

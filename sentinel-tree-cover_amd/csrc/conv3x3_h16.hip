@@ -7,7 +7,7 @@
 // (split on the host).  A layer runs with TERMS = 3 products per K block,
 //     x * w ~= x_lo*w_hi + x_hi*w_lo + x_hi*w_hi          (drops x_lo*w_lo ~ 2^-22 relative for fp16),
 // or TERMS = 1 (x_hi*w_hi: plain 16-bit operands, 2^-11 relative for fp16) where the per-layer precision map allows it
-// (tools/study/precision_study.py: only the ConvGRU gates conv tolerates it inside the 1e-3 probability contract).
+// (tools/study/precision_study.py; on a real tile even the ConvGRU gates conv alone costs 3e-3: the default map is all-3).
 //
 // Layout.  Activations in HBM: [n][C8][Hp*Wp][8 ch] 16-bit, one 16-byte K vector per (channel block, position), hi and lo
 // tensors.  Same "flattened padded plane" formulation as conv3x3_mfma.hip: a workgroup (4 waves) owns 512 consecutive

@@ -5,7 +5,8 @@ real checkpoint runs in.
 
 Tolerances on probabilities (BASELINE.json's contract is 1e-3):
   fp16, three split products in every layer ("fp16x3", one_term_layers = 0): operands carry 22 mantissa bits -> fp32-class, 1e-4
-  fp16 default map (ConvGRU gates conv with plain fp16 operands):            measured on the oracle 2e-4 -> 6e-4
+  fp16 with the ConvGRU gates conv on plain fp16 operands (one_term_layers = 1, NOT the default: 3e-3 on a real tile):
+                                                                             white-noise windows 2e-4 .. 6.5e-4 -> 1e-3
   bf16, three split products (16 mantissa bits):                              2.5e-4 like the round-1 bf16x3 engine
 """
 import numpy as np
@@ -15,7 +16,7 @@ from tests.helpers import synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = [("fp16", 0, 1e-4), ("fp16", None, 6e-4), ("bf16", None, 2.5e-4)]
+MODES = [("fp16", None, 1e-4), ("fp16", 1, 1e-3), ("bf16", None, 2.5e-4)]
 
 
 def _setup(W, L, N, seed, precision, one_term, stored=True, dtype64=True):
@@ -56,7 +57,7 @@ def test_single_step_intermediates_16bit(precision):
     """L = 1, three products everywhere: every raw conv output of the first ConvGRU step and of the U-Net against the
     float64 oracle, relative to the tensor's own scale (as-stored kernels make raw outputs O(10..100))."""
     W, L, N = 44, 1, 3
-    ctx, w, x, ref, tr = _setup(W, L, N, 0, precision, 0)
+    ctx, w, x, ref, tr = _setup(W, L, N, 0, precision, None)
     ctx.keep_intermediates(True)
     out = ctx.forward_windows(x).cpu().numpy()
     rel = 5e-5 if precision == "fp16" else 3e-4      # deep layers inherit the upstream differences through GroupNorm
