@@ -85,8 +85,14 @@ def group_norm(x, gamma, beta, G=8, eps=1e-5):
 
 
 class TreeCoverNet:
-    def __init__(self, weights, zoneout=0.75, dtype=torch.float32, trace=None):
+    def __init__(self, weights, zoneout=0.75, dtype=torch.float32, trace=None, ws_restandardize=False):
+        """ws_restandardize: model.py's WSConv2D.call (:392-394) standardises the kernel on EVERY call, also at inference,
+        `(k - mean) / (std + 1e-5)` per output channel; checkpoints store the standardised kernel (training assigns it
+        back) and the frozen inference graphs use it as stored (export notebook: no-op assign), so the default
+        is False.  The two differ by a ~1e-5 per-channel rescale; True reproduces model.py's graph code exactly
+        (tests/test_oracle_model.py pins it to 2e-9 against that code run through tools/tf_shim)."""
         self.w, self.z, self.dt = weights, float(zoneout), dtype
+        self.ws_re = bool(ws_restandardize)
         self.trace = trace          # optional dict: name -> ndarray of intermediates (NCHW)
 
     def _t(self, name, x):
@@ -129,6 +135,9 @@ class TreeCoverNet:
     def block(self, name, x, padding):
         w, dt = self.w, self.dt
         k = _k(w, name + "/kernel", dt)
+        if self.ws_re:                                   # WSConv2D.standardize_weight, model.py:384-390 (OIHW here)
+            k = k - k.mean(dim=(1, 2, 3), keepdim=True)
+            k = k / (k.std(dim=(1, 2, 3), keepdim=True, unbiased=False) + 1e-5)
         if padding == "SAME":
             y = F.conv2d(x, k, padding=1)
             ones = torch.ones(1, 1, x.shape[2], x.shape[3], dtype=dt)
