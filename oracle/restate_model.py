@@ -209,9 +209,10 @@ class DSen2Lite:
         """inp [T,H,W,10], bilinear [T,H,W,6] -> [T,H,W,6]."""
         x = torch.as_tensor(np.asarray(inp)).to(self.dt).permute(0, 3, 1, 2)
         b = torch.as_tensor(np.asarray(bilinear)).to(self.dt).permute(0, 3, 1, 2)
+        c = float(np.float32(0.1))          # the graph's Const / Const_1 are float32 0x3DCCCCCD (pinned by tests/golden/dsen2_graph.npz)
         x0 = F.relu(self._conv(x, "in_conv"))
-        x1 = x0 + 0.1 * self._conv(F.relu(self._conv(x0, "01_conv")), "02_conv")
-        x2 = x1 + 0.1 * self._conv(F.relu(self._conv(x1, "11_conv")), "12_conv")
+        x1 = x0 + c * self._conv(F.relu(self._conv(x0, "01_conv")), "02_conv")
+        x2 = x1 + c * self._conv(F.relu(self._conv(x1, "11_conv")), "12_conv")
         out = b + torch.tanh(self._conv(x2, "out_conv"))
         return out.permute(0, 2, 3, 1).contiguous().numpy()
 

@@ -82,3 +82,17 @@ def test_reference_graph_uses_every_canonical_weight_once():
     for theirs in ("conv1_conv/conv1/ws_conv2d_2/kernel", "up2_out_conv/up2_out/x/ws_conv2d_5/kernel", "csse_out_conv/bias",
                    "down_16/bidirectional_rnn/bw/conv_gru_cell/candidate/kernel_1", "conv_median_norm/gamma_conv_median"):
         assert theirs in tfn
+
+
+def test_dsen2_restatement_matches_the_frozen_graph():
+    """DSen2Lite against the reference's superresolve_graph.pb INTERPRETED node by node (tools/gen_golden_dsen2.py: topology,
+    constants and weights all read from the .pb): the restatement of SURVEY A.5 is the graph."""
+    import os
+    from tests.helpers import GOLDEN, ROOT
+    g = np.load(os.path.join(GOLDEN, "dsen2_graph.npz"))
+    w = dict(np.load(os.path.join(ROOT, "sentinel-tree-cover_amd", "weights", "dsen2.npz")))
+    for tag in "abc":
+        y = M.DSen2Lite(w, dtype=torch.float64)(g[tag + "_x"].astype(np.float64), g[tag + "_bil"].astype(np.float64))
+        d = np.abs(y - g[tag + "_y"]).max()
+        print(f"[pin] DSen2 graph {tag} {g[tag + '_x'].shape}: max|d| = {d:.2e}")
+        assert d <= 1e-12
