@@ -208,6 +208,35 @@ ttc_status ttc_clip01(ttc_ctx* ctx, float* d_a, int64_t n, void* stream);
 /* x / divisor in place with an IEEE division (dem / 90, :993). */
 ttc_status ttc_divide(ttc_ctx* ctx, float* d_a, int64_t n, float divisor, void* stream);
 
+/* ---- whole tile in ONE call -------------------------------------------------------------------------------------------------
+ * The chain the job runs per tile -- process_tile's numeric flow from the raw arrays (to_float32 tof_downloading.py:64-72,
+ * convert_to_db job.py:74-89 / :699-708, the 20 m -> 10 m bilinear :734-782, [identify_clouds_shadows cloud_removal.py:1215-1677],
+ * remove_cloud_and_shadows :888-973), superresolve_large_tile (job.py:95-147), process_subtiles (:1125-1483) and
+ * load_mosaic_predictions (:1515-1641) -- enqueued on `stream` WITHOUT any host round trip: the date screening of
+ * deal_w_missing_px (job.py:1031-1037) and the 12 x T temporal operator are formed on the device, the gap-fill uses the
+ * deterministic expected-multiplicity sampler, and the two rare data-dependent host decisions of the staged path are taken
+ * speculatively and REPORTED instead:
+ *   d_status[0] != 0  a date could not be radiometrically aligned (cloud_removal.py:679-680: it marks itself fully
+ *                     interpolated, which changes every later date): the rasters are NOT the reference's; re-run this tile
+ *                     through the staged calls (ttc_remove_cloud_and_shadows takes that branch itself)
+ *   d_status[1]       dates that survived the missing-pixel screening (< 2 -> every window is 255, like job.py:1418-1422)
+ *   d_status[2] != 0  the gap-fill flagged dates as fully interpolated; the job deletes them before process_subtiles
+ *                     (job.py:964-981) -- re-run through the staged calls
+ * d_s2_10 [T, X, Y, 4] / d_s2_20 [T, X/2, Y/2, 6] / d_s1 [12, X, Y, 2] uint16 as stored in temp/raw (device memory);
+ * d_dem [X, Y] as process_tile returns it (median-filtered, / 90); d_dem_m the same in metres (detection only, may be NULL);
+ * d_mask [T, X, Y] the cloud + shadow mask (ignored with TTC_TILE_DETECT); d_dates [T] int32 day of year, DEVICE memory.
+ * d_out_u8 [X, Y] uint8 (transposed like the reference's mosaic, 255 = no data), d_out_f32 the float percent raster or NULL;
+ * d_model_in (optional) receives the model's input frames [36, L+1, 17, W+2, W+2] (planar, padded: what ttc_debug_fetch
+ * "frames" returns).  flags: TTC_TILE_*. */
+#define TTC_TILE_DETECT 1        /* run the multi-temporal cloud / shadow detection and gap-fill with its mask           */
+#define TTC_TILE_INPUTS_ONLY 2   /* stop after the model inputs are assembled: preprocessing only (BASELINE configs[2])   */
+#define TTC_TILE_NO_SUPERRES 4   /* skip the DSen2 super-resolution                                                     */
+ttc_status ttc_predict_tile(ttc_ctx* ctx, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1,
+                            const float* d_dem, const float* d_dem_m, const float* d_mask, const int32_t* d_dates,
+                            int32_t T, int32_t X, int32_t Y, const double* h_min, const double* h_max, int32_t size,
+                            int32_t flags, uint8_t* d_out_u8, float* d_out_f32, float* d_model_in, int32_t* d_status,
+                            void* stream);
+
 /* ---- Gaussian overlap mosaic --------------------------------------------------------
  * == load_mosaic_predictions(out_folder, depth=1), job.py:1515-1641, from the 36 window
  * arrays (not from .npy files).

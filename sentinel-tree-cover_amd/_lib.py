@@ -24,6 +24,7 @@ EXPORTS = [
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
+    "ttc_predict_tile",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -45,6 +46,123 @@ PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16": 3}
 
 def default_one_term(precision, length):
     return 0
+
+
+class TTCResegWindow(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("pred_off", C.c_int64), ("weight_off", C.c_int64)]
+
+
+class TTCTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 4)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libttc_hip.so and declare prototypes; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sentinel-tree-cover_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P, I32, F32P, VP = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p
+    lib.ttc_version.restype = C.c_char_p
+    lib.ttc_create.argtypes = [C.POINTER(P), I32, C.POINTER(TTCConfig)]
+    lib.ttc_destroy.argtypes = [P]
+    lib.ttc_destroy.restype = None
+    lib.ttc_last_error.argtypes = [P]
+    lib.ttc_last_error.restype = C.c_char_p
+    lib.ttc_device_bytes.argtypes = [P]
+    lib.ttc_device_bytes.restype = C.c_size_t
+    lib.ttc_load_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
+    lib.ttc_load_dsen2_weights.argtypes = [P, C.POINTER(TTCTensor), I32]
+    lib.ttc_forward_windows.argtypes = [P, VP, I32, VP, VP]
+    lib.ttc_process_subtiles.argtypes = [P, VP, I32, I32, I32, F32P, C.POINTER(C.c_int32), VP, VP, VP,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), I32, I32, VP, VP, VP]
+    lib.ttc_tile_missing_counts.argtypes = [P, VP, I32, I32, I32, VP, VP]
+    lib.ttc_tile_fix_missing.argtypes = [P, VP, I32, I32, I32, I32, I32, VP]
+    lib.ttc_mosaic.argtypes = [P, VP, I32, C.POINTER(C.c_int32), I32, I32, I32, VP, VP, VP]
+    lib.ttc_dsen2_forward.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_superresolve_tile.argtypes = [P, VP, I32, I32, I32, I32, VP]
+    lib.ttc_upsample_20m.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_feather.argtypes = [P, VP, I32, I32, I32, I32, I32, VP, VP]
+    lib.ttc_aligned_mosaic.argtypes = [P, VP, VP, I32, I32, I32, VP, VP]
+    lib.ttc_remove_cloud_and_shadows.argtypes = [P, VP, VP, VP, I32, I32, I32, SAMPLER_FN, VP, VP, VP,
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), VP]
+    lib.ttc_sen2cor_clean.argtypes = [P, VP, I32, I32, I32, VP, VP]
+    lib.ttc_median5.argtypes = [P, VP, I32, I32, VP, VP]
+    lib.ttc_snow_map.argtypes = [P, VP, I32, I32, I32, VP, VP, VP]
+    lib.ttc_merge_cloud_masks.argtypes = [P, VP, VP, VP, C.c_int64, VP]
+    lib.ttc_count_positive.argtypes = [P, VP, I32, I32, VP, VP]
+    lib.ttc_clip01.argtypes = [P, VP, C.c_int64, VP]
+    lib.ttc_divide.argtypes = [P, VP, C.c_int64, C.c_float, VP]
+    lib.ttc_debug_keep.argtypes = [P, I32]
+    lib.ttc_debug_clouds_stage.argtypes = [P, I32]
+    lib.ttc_identify_clouds_shadows.argtypes = [P, VP, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP]
+    lib.ttc_mosaic_features.argtypes = [P, VP, I32, VP, I32, I32, I32, I32, VP, VP]
+    lib.ttc_forward_taps.argtypes = [P, VP, I32, VP, VP, VP, VP]
+    lib.ttc_float_to_int16.argtypes = [P, VP, C.c_int64, C.c_float, VP, VP]
+    lib.ttc_u16_to_float.argtypes = [P, VP, C.c_int64, VP, VP]
+    lib.ttc_float_to_u16.argtypes = [P, VP, C.c_int64, VP, VP]
+    lib.ttc_s1_to_db.argtypes = [P, VP, I32, I32, I32, VP, VP]
+    F64P, I32P = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    lib.ttc_predict_tile.argtypes = [P, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, F64P, F64P, I32, I32, VP, VP, VP, VP, VP]
+    lib.ttc_border_subtiles.argtypes = [P, VP, VP, VP, I32, I32P, I32, F32P, F32P, I32, I32, VP, F32P, I32P, VP]
+    lib.ttc_smooth_strip.argtypes = [P, VP, I32, I32, I32, F32P, VP, VP]
+    lib.ttc_superresolve_windows.argtypes = [P, VP, I32, I32, I32, I32, I32, I32, VP]
+    lib.ttc_seam_adjust.argtypes = [P, VP, I32, I32, I32, F32P, VP]
+    lib.ttc_reseg_mosaic.argtypes = [P, VP, VP, I32, VP, VP, I32, I32, VP, VP, VP]
+    lib.ttc_count_equal.argtypes = [P, VP, I32, I32, C.c_float, I32P, VP]
+    lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.ttc_debug_timing.argtypes = [P, I32]
+    lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)          # AttributeError here == missing export
+        if name not in ("ttc_version", "ttc_destroy", "ttc_last_error", "ttc_device_bytes"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def write_geotiff_u8(path, raster, west, south, east, north):
+    """ttc_write_geotiff_u8: raster uint8 [rows, cols] (numpy) -> LZW GeoTIFF at `path` (host-side, no GPU needed)"""
+    a = np.ascontiguousarray(raster, dtype=np.uint8)
+    lib = load()
+    lib.ttc_write_geotiff_u8.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]
+    st = lib.ttc_write_geotiff_u8(str(path).encode(), a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], float(west), float(south),
+                                  float(east), float(north))
+    if st != 0:
+        raise RuntimeError(f"ttc_write_geotiff_u8: status {st} ({path})")
+    return str(path)
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible to PyTorch-ROCm (torch.cuda.is_available() is False); "
+                           "the tree-cover hot path has no CPU fallback")
+    return torch
+
+
+def pack_tensors(weights: dict):
+    """dict name -> float32 ndarray  ==>  (ctypes array of TTCTensor, keepalive list)."""
+    arr = (TTCTensor * len(weights))()
+    keep = []
+    for i, (k, v) in enumerate(weights.items()):
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        keep.append(a)
+        arr[i].name = k.encode()
+        arr[i].data = a.ctypes.data_as(C.POINTER(C.c_float))
+        arr[i].ndim = min(a.ndim, 4)
+        for d in range(min(a.ndim, 4)):
+            arr[i].shape[d] = a.shape[d]
+    return arr, keep
 
 
 class Context:
@@ -165,6 +283,45 @@ class Context:
             mx.ctypes.data_as(C.POINTER(C.c_double)), size, n_dates_ok, C.c_void_p(out.data_ptr()),
             C.c_void_p(raw.data_ptr()) if want_raw else None, self._stream()), "ttc_process_subtiles")
         return out, raw
+
+    TILE_DETECT, TILE_INPUTS_ONLY, TILE_NO_SUPERRES = 1, 2, 4
+
+    def predict_tile_raw(self, s2_10, s2_20, s1, dem, mask, dates, min_all, max_all, size, dem_m=None, flags=0,
+                         want_float=False, want_inputs=False, out=None, status=None):
+        """ttc_predict_tile: the whole per-tile chain in ONE enqueue, no host round trip.  s2_10 [T, X, Y, 4] / s2_20
+        [T, X/2, Y/2, 6] / s1 [12, X, Y, 2] uint16 as stored (cuda int16 / uint16 views or numpy), dem [X, Y] (/90), mask
+        [T, X, Y] float32 cloud + shadow mask (None with TILE_DETECT), dates [T] (cuda int32 tensor or sequence).
+        -> (u8 cuda [X, Y] | None, f32 | None, model inputs | None, status cuda int32[4]); read `status` after a stream
+        synchronisation: status[0] / status[2] != 0 -> the tile needs the staged calls (see ttc.h)."""
+        t = self.torch
+        dev = f"cuda:{self.device}"
+
+        def u16(a):
+            if isinstance(a, t.Tensor):
+                return a.to(dev).contiguous()
+            a = np.ascontiguousarray(a)
+            return t.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev)
+        d10, d20, ds1 = u16(s2_10), u16(s2_20), u16(s1)
+        T, X, Y = int(d10.shape[0]), int(d10.shape[1]), int(d10.shape[2])
+        ddem = self._dev(dem, t.float32)
+        dmask = self._dev(mask, t.float32) if mask is not None else None
+        ddem_m = self._dev(dem_m, t.float32) if dem_m is not None else None
+        ddates = dates if isinstance(dates, t.Tensor) else t.tensor([int(d) for d in dates], dtype=t.int32)
+        ddates = ddates.to(dev, t.int32).contiguous()
+        inputs_only = bool(flags & self.TILE_INPUTS_ONLY)
+        u8 = out if out is not None else (None if inputs_only else t.empty((X, Y), dtype=t.uint8, device=dev))
+        f32 = t.empty((X, Y), dtype=t.float32, device=dev) if (want_float and not inputs_only) else None
+        W = self.cfg.win_in
+        frames = t.empty((36, self.cfg.length + 1, 17, W + 2, W + 2), dtype=t.float32, device=dev) if want_inputs else None
+        status = status if status is not None else t.zeros(4, dtype=t.int32, device=dev)
+        mn = (C.c_double * 17)(*[float(v) for v in min_all])
+        mx = (C.c_double * 17)(*[float(v) for v in max_all])
+        ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None      # noqa: E731
+        self._check(self.lib.ttc_predict_tile(self._h, ptr(d10), ptr(d20), ptr(ds1), ptr(ddem), ptr(ddem_m), ptr(dmask), ptr(ddates),
+                                              T, X, Y, mn, mx, int(size), int(flags), ptr(u8), ptr(f32), ptr(frames), ptr(status),
+                                              self._stream()), "ttc_predict_tile")
+        self._keep = (d10, d20, ds1, ddem, dmask, ddem_m, ddates)      # inputs must outlive the enqueued work
+        return u8, f32, frames, status
 
     def mosaic(self, windows, xy, size, rows, cols, want_float=False):
         """windows [n, size, size] (numpy / cuda), xy [n, 2] int32 (folder_x, folder_y) -> (u8 [rows, cols], f32 | None)"""

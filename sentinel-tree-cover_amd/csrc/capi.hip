@@ -1,4 +1,6 @@
 // extern "C" entry points of libttc_hip.so (see include/ttc.h for the contract).
+#include <algorithm>
+
 #include "ttc_internal.h"
 
 // tile.hip / mosaic.hip / dsen2.hip
@@ -6,6 +8,9 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
                                  const int32_t* h_keep, const float* d_interp, const float* d_s1, const float* d_dem,
                                  const double* h_min, const double* h_max, int size, int n_dates_ok, float* d_windows,
                                  float* d_windows_raw, hipStream_t s);
+ttc_status tile_process_subtiles_dev(ttc_ctx* c, float* d_s2, int T, int X, int Y, const int32_t* d_dates, const float* d_interp,
+                                     const float* d_s1, const float* d_dem, const double* h_min, const double* h_max, int size,
+                                     float* d_windows, float* d_windows_raw, bool stop_after_inputs, hipStream_t s);
 ttc_status tile_missing_counts(ttc_ctx* c, const float* d_s2, int T, int X, int Y, int32_t* d_counts, hipStream_t s);
 ttc_status tile_fix_missing(ttc_ctx* c, float* d_s2, int T, int X, int Y, int do_nan, int do_zero_one, hipStream_t s);
 ttc_status mosaic_run(ttc_ctx* c, const float* d_windows, int n, const int32_t* h_xy, int size, int rows, int cols,
@@ -82,6 +87,7 @@ void ttc_destroy(ttc_ctx* c) {
     flush_timing(c);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& kv : c->scratch) (void)hipFree(kv.second.first);
+    for (auto& kv : c->pinned) (void)hipHostFree(kv.second.first);
     delete c;
 }
 
@@ -198,6 +204,72 @@ ttc_status ttc_remove_cloud_and_shadows(ttc_ctx* c, float* d_tiles, const float*
     if (!c) return TTC_ERR_ARG;
     return gapfill_remove_clouds(c, d_tiles, d_probs, d_pfcps, T, X, Y, sampler, user, d_interp, d_mosaic, h_to_remove,
                                  n_to_remove, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1, const float* d_dem,
+                            const float* d_dem_m, const float* d_mask, const int32_t* d_dates, int32_t T, int32_t X, int32_t Y,
+                            const double* h_min, const double* h_max, int32_t size, int32_t flags, uint8_t* d_out_u8,
+                            float* d_out_f32, float* d_model_in, int32_t* d_status, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool detect = (flags & TTC_TILE_DETECT) != 0, inputs_only = (flags & TTC_TILE_INPUTS_ONLY) != 0;
+    if (!d_s2_10 || !d_s2_20 || !d_s1 || !d_dem || !d_dates || !h_min || !h_max || !d_status) return c->fail(TTC_ERR_ARG, "predict_tile: null argument");
+    if (!detect && !d_mask) return c->fail(TTC_ERR_ARG, "predict_tile: a cloud / shadow mask is needed unless TTC_TILE_DETECT is set");
+    if (detect && !d_dem_m) return c->fail(TTC_ERR_ARG, "predict_tile: TTC_TILE_DETECT needs the elevation in metres");
+    if (!inputs_only && !d_out_u8) return c->fail(TTC_ERR_ARG, "predict_tile: no output raster");
+    if (T < 1 || T > 32 || X < 2 || Y < 2 || (X & 1) || (Y & 1)) return c->fail(TTC_ERR_ARG, "predict_tile: T in [1,32], even X and Y");
+    const int h = X / 2, w = Y / 2;
+    const size_t npix = (size_t)X * Y;
+    float* f10 = static_cast<float*>(c->scratch_buf("pt_f10", sizeof(float) * T * npix * 4));
+    float* f20 = static_cast<float*>(c->scratch_buf("pt_f20", sizeof(float) * (size_t)T * h * w * 6));
+    float* s1db = static_cast<float*>(c->scratch_buf("pt_s1", sizeof(float) * 12 * npix * 2));
+    float* s2 = static_cast<float*>(c->scratch_buf("pt_s2", sizeof(float) * T * npix * 10));
+    float* interp = static_cast<float*>(c->scratch_buf("pt_interp", sizeof(float) * T * npix));
+    if (!f10 || !f20 || !s1db || !s2 || !interp) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+    // window grid (job.py:1295-1316): origins of the 6 x 6 output windows, iteration order x-major
+    std::vector<int32_t> xy;
+    {
+        const int gx = (X - size + 4) / 5, gy = (Y - size + 4) / 5;                      // ceil((X - size) / 5)
+        if (X <= size || Y <= size || gx < 1 || gy < 1) return c->fail(TTC_ERR_ARG, "predict_tile: tile smaller than the window grid");
+        std::vector<int> xs, ys;
+        for (int v = 0; v < X - size; v += gx) xs.push_back(v);
+        xs.push_back(X - size);
+        for (int v = 0; v < Y - size; v += gy) ys.push_back(v);
+        ys.push_back(Y - size);
+        for (int x : xs) for (int y : ys) { xy.push_back(x); xy.push_back(y); }
+    }
+    const int n_win = (int)xy.size() / 2;
+    float* windows = static_cast<float*>(c->scratch_buf("pt_windows", sizeof(float) * (size_t)n_win * size * size));
+    if (!windows) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+    TTC_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t) * 4, s));
+    TTC_CHECK(codec_u16_to_f32(c, d_s2_10, (int64_t)T * npix * 4, f10, s));             // tof_downloading.py:64-72
+    TTC_CHECK(codec_u16_to_f32(c, d_s2_20, (int64_t)T * h * w * 6, f20, s));
+    TTC_CHECK(codec_s1_to_db(c, d_s1, 12, X, Y, s1db, s));                              // job.py:699-708
+    TTC_CHECK(upsample_20m(c, f10, f20, T, h, w, s2, s));                               // job.py:734-782
+    const float* mask = d_mask;
+    const uint8_t* pf = nullptr;
+    if (detect) {                                                                       // cloud_removal.py:1215-1677
+        float* clouds = static_cast<float*>(c->scratch_buf("pt_clouds", sizeof(float) * T * npix));
+        uint8_t* fcps = static_cast<uint8_t*>(c->scratch_buf("pt_fcps", T * npix));
+        if (!clouds || !fcps) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+        TTC_CHECK(clouds_identify(c, s2, T, X, Y, d_dem_m, nullptr, nullptr, nullptr, clouds, fcps, 0, s));
+        mask = clouds; pf = fcps;
+    }
+    c->spec_status = d_status;                     // the speculative stages report into it instead of waiting for the host
+    ttc_status st = gapfill_remove_clouds(c, s2, mask, pf, T, X, Y, nullptr, nullptr, interp, nullptr, nullptr, nullptr, s);   // cloud_removal.py:888-973
+    if (st == TTC_OK && !(flags & TTC_TILE_NO_SUPERRES)) st = dsen2_tile(c, s2, T, X, Y, 1, 110, 10, s);                       // job.py:95-147
+    if (st == TTC_OK) st = tile_process_subtiles_dev(c, s2, T, X, Y, d_dates, interp, s1db, d_dem, h_min, h_max, size, windows, nullptr,
+                                                     inputs_only, s);                                                         // job.py:1125-1483
+    c->spec_status = nullptr;
+    TTC_CHECK(st);
+    if (d_model_in) {
+        const size_t nfl = (size_t)n_win * (c->cfg.length + 1) * c->cfg.n_bands * (c->cfg.win_in + 2) * (c->cfg.win_in + 2);
+        TTC_HIP(c, hipMemcpyAsync(d_model_in, c->frames, sizeof(float) * nfl, hipMemcpyDeviceToDevice, s));
+    }
+    if (inputs_only) return TTC_OK;
+    int rows = 0, cols = 0;
+    for (int i = 0; i < n_win; ++i) { rows = std::max(rows, xy[2 * i + 1] + size); cols = std::max(cols, xy[2 * i] + size); }
+    return mosaic_run(c, windows, n_win, xy.data(), size, rows, cols, d_out_u8, d_out_f32, s);                                 // job.py:1515-1641
 }
 
 ttc_status ttc_mosaic(ttc_ctx* c, const float* d_windows, int32_t n, const int32_t* h_xy, int32_t size,

@@ -1056,6 +1056,18 @@ __global__ void k_accum_final_all(const float* __restrict__ tiles, const float* 
     mosaic[id] = m;
 }
 
+__global__ void k_count_flags(const int* __restrict__ flags, int T, int* __restrict__ out) {
+    if (threadIdx.x == 0) { int n = 0; for (int i = 0; i < T; ++i) n += flags[i] ? 1 : 0; out[0] = n; }
+}
+
+__global__ void k_redo_flag(const AlignPar* __restrict__ ap, int T, int* __restrict__ status) {
+    if (threadIdx.x == 0) {
+        int redo = 0;
+        for (int i = 0; i < T; ++i) redo |= (!ap[i].ok && ap[i].any_land) ? 1 : 0;
+        status[0] = redo;
+    }
+}
+
 ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
                                   hipStream_t s) {
     if (!d_tiles || !d_w || !d_mosaic || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "aligned_mosaic: bad argument (T in [1,32])");
@@ -1094,6 +1106,15 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     }
     // the one host decision: a date with <= 1000 usable rows on a tile that has land marks itself fully interpolated
     // and thereby changes every later date (CR.py:679-680) -> redo date by date.  T small ints, one stream wait.
+    // Single-call tile path (c->spec_status set): no wait -- the batched result is used speculatively and the condition is
+    // recorded in device memory, status[0] != 0 tells the caller afterwards that this tile needs the staged path.
+    if (c->spec_status) {
+        hipLaunchKernelGGL(k_redo_flag, dim3(1), dim3(64), 0, s, ap, T, c->spec_status);
+        KTimer kt(c, "aligned_mosaic", s);
+        GF_T(k_accum_final_all, T, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_tiles, d_w, water, ap, divisor, T, npix, d_mosaic);
+        TTC_HIP(c, hipGetLastError());
+        return TTC_OK;
+    }
     AlignPar h_ap[kMaxT];
     TTC_HIP(c, hipMemcpyAsync(h_ap, ap, sizeof(AlignPar) * T, hipMemcpyDeviceToHost, s));
     TTC_HIP(c, hipStreamSynchronize(s));
@@ -1219,6 +1240,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     hipLaunchKernelGGL(k_dilate_diamond, grid, b256, 0, s, tmp, X, Y, 8, 1, cl);               // dilate(1 - that, 8)
     hipLaunchKernelGGL(k_add_clouds, grid, b256, 0, s, d_interp, cl, T, npix);
     TTC_HIP(c, hipGetLastError());
+    if (c->spec_status) hipLaunchKernelGGL(k_count_flags, dim3(1), dim3(64), 0, s, remove_flags, T, c->spec_status + 2);
     if (h_to_remove && n_to_remove) {          // the only host read-back; skipped when the caller does not ask
         int flags[kMaxT];
         TTC_HIP(c, hipMemcpyAsync(flags, remove_flags, sizeof(int) * T, hipMemcpyDeviceToHost, s));

@@ -465,6 +465,16 @@ void* ttc_ctx::scratch_buf(const std::string& key, size_t bytes) {
     return p;
 }
 
+void* ttc_ctx::pinned_buf(const std::string& key, size_t bytes) {
+    auto it = pinned.find(key);
+    if (it != pinned.end() && it->second.second >= bytes) return it->second.first;
+    if (it != pinned.end()) (void)hipHostFree(it->second.first);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { pinned.erase(key); return nullptr; }
+    pinned[key] = {p, bytes};
+    return p;
+}
+
 ttc_status model_alloc(ttc_ctx* c) {
     const Geo g(c->cfg);
     const size_t N = c->cfg.max_windows, N2 = 2 * N;

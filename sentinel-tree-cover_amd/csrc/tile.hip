@@ -160,8 +160,9 @@ __device__ __forceinline__ void smooth_store(const float (&v)[TM], const WMat& w
 // 64 x 10 floats per date into LDS with coalesced float4 loads (all T x 3 loads of a lane in flight at once) and every
 // lane then picks its pixel's series out of LDS (40-byte lane stride: conflict-free for ds_read_b64).
 template <int TM>
-__global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ s2, WMat wm, int npix, int L,
+__global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ s2, const WMat* __restrict__ wmp, int npix, int L,
                                                       float* __restrict__ sm, float* __restrict__ med) {
+    const WMat& wm = *wmp;              // device memory (built by the host mirror or by k_build_wmat); uniform indices -> scalar loads
     extern __shared__ __attribute__((aligned(16))) float stage[];      // [T][64 px][10]
     const int lane = threadIdx.x;
     const int p0 = blockIdx.x * 64;
@@ -406,9 +407,10 @@ __global__ __launch_bounds__(1024) void k_bright_dist(const unsigned char* __res
 // post-masks + rounding; one workgroup per window
 // number of kept dates whose interpolation weight is < 0.33 (job.py:1355-1362), once per tile pixel: every pixel is
 // visited by up to four windows and twice per window, and k_post runs on 36 workgroups only
-__global__ void k_clear_map(const float* __restrict__ interp, unsigned keep, int T, int npix, unsigned char* __restrict__ cc) {
+__global__ void k_clear_map(const float* __restrict__ interp, const WMat* __restrict__ wmp, int T, int npix, unsigned char* __restrict__ cc) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
+    const unsigned keep = wmp->keep;
     int c = 0;
     for (int t = 0; t < T; ++t)
         if ((keep >> t) & 1u) c += interp[(long)t * npix + p] < 0.33f ? 1 : 0;
@@ -417,7 +419,7 @@ __global__ void k_clear_map(const float* __restrict__ interp, unsigned keep, int
 struct PostArgs {
     const float* probs; const unsigned char* cc; const unsigned char* d2;
     float* out; float* out_raw;
-    WinTable wt; unsigned keep; int T, X, Y, size, n_dates_ok;
+    WinTable wt; const WMat* wm; int T, X, Y, size, n_dates_ok;      // n_dates_ok < 0: the kept-date count of *wm
 };
 
 __device__ __forceinline__ int clear_count(const PostArgs& a, int tx, int ty) { return a.cc[(long)tx * a.Y + ty]; }
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(1024) void k_post(PostArgs a) {
     __syncthreads();
     const int n = w.lx * w.ly, k = n / 2;
     bool no_images = (n & 1) ? (s_z >= k + 1) : (s_z >= k && s_z1 >= k + 1);
-    if (a.n_dates_ok < 2) no_images = true;
+    if ((a.n_dates_ok < 0 ? a.wm->Tk : a.n_dates_ok) < 2) no_images = true;
     const int thr = size == 158 ? 400 : 192;
     for (int o = threadIdx.x; o < size * size; o += blockDim.x) {
         const long gi = (long)wi * size * size + o;
@@ -603,6 +605,131 @@ __global__ __launch_bounds__(256) void k_strip_smooth(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 12 x T temporal operator W = P (I + 100 D2'D2)^-1 R(dates) built ON THE DEVICE from the per-date missing-pixel counts
+// (deal_w_missing_px's screening, job.py:1031-1037: a date survives when fewer than X^2 / 10 pixels are missing) and the
+// acquisition days, so that the single-call tile path needs no host round trip.  Same arithmetic as the host mirror
+// sentinel-tree-cover_amd/temporal.py (calculate_and_save_best_images, src/downloading/utils.py:176-347: per 15-day grid step the
+// <= 2 images before and <= 2 after, distance weights, wrap-around / mirroring at the year ends; duplicate dates make the
+// reference raise -> all-zero operator, job.py:1073-1080).  One workgroup: thread r < 24 builds row r of R, then thread
+// k < 12 row k of W.  minv: the constant 12 x 24 matrix P (I + 100 D2'D2)^-1 in double.
+__global__ void k_build_wmat(const int* __restrict__ counts, int thr, const int* __restrict__ dates, int T,
+                             const double* __restrict__ minv, WMat* __restrict__ out, int* __restrict__ status) {
+    __shared__ float R[24][kMaxT];
+    __shared__ int dd[kMaxT], pos[kMaxT], nk, bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int n = 0;
+        unsigned keep = 0;
+        for (int t = 0; t < T; ++t)
+            if (counts[t] < thr) {
+                int d = dates[t];
+                if (d < -100) d = ((d % 365) + 365) % 365;                  // utils.py:190 (Python modulo)
+                dd[n] = d; pos[n] = t; keep |= 1u << t; ++n;
+            }
+        nk = n; bad = 0;
+        out->keep = keep; out->T = T; out->Tk = n;
+        if (status) status[1] = n;
+    }
+    for (int i = tid; i < 24 * kMaxT; i += blockDim.x) (&R[0][0])[i] = 0.f;
+    __syncthreads();
+    const int n = nk;
+    if (tid < 24 && n > 0) {
+        const int g = 15 * tid;
+        int dmin = dd[0], dmax = dd[0];
+        for (int i = 1; i < n; ++i) { dmin = min(dmin, dd[i]); dmax = max(dmax, dd[i]); }
+        // prior = d[d < 5][-2:], after = d[d >= -5][:2]   (d = dates - g, array order)
+        int P[2], A[2], np_ = 0, na = 0;
+        for (int i = 0; i < n; ++i) {
+            const int d = dd[i] - g;
+            if (d < 5) { if (np_ < 2) P[np_++] = d; else { P[0] = P[1]; P[1] = d; } }
+        }
+        for (int i = 0; i < n && na < 2; ++i) { const int d = dd[i] - g; if (d >= -5) A[na++] = d; }
+        if (np_ > 0) {                                                       // keep those within 100 days of the nearest
+            int mx = P[0]; for (int j = 1; j < np_; ++j) mx = max(mx, P[j]);
+            int m = 0; for (int j = 0; j < np_; ++j) if (P[j] > mx - 100) P[m++] = P[j];
+            np_ = m;
+        }
+        if (na > 0) {
+            int mn = A[0]; for (int j = 1; j < na; ++j) mn = min(mn, A[j]);
+            int m = 0; for (int j = 0; j < na; ++j) if (A[j] < mn + 100) A[m++] = A[j];
+            na = m;
+        }
+        int p_shift = 0, a_shift = 0;
+        if (np_ == 0) {
+            if (dmin >= 90) { P[0] = dd[n - 1] - g; np_ = 1; p_shift = 365; }
+            else { for (int j = 0; j < na; ++j) P[j] = A[j]; np_ = na; }
+        }
+        if (na == 0) {
+            if (dmax <= 270) { A[0] = dd[0] - g; na = 1; a_shift = 365; }
+            else { for (int j = 0; j < np_; ++j) A[j] = P[j]; na = np_; }
+        }
+        double pd[2], ad[2], pw[2], aw[2];
+        for (int j = 0; j < np_; ++j) pd[j] = fmax(fabs((double)(P[j] - p_shift)), 1.0);
+        for (int j = 0; j < na; ++j) ad[j] = fmax(fabs((double)(A[j] + a_shift)), 1.0);
+        const double closest = fmax(pd[np_ - 1] + ad[0], 2.0);
+        for (int j = 0; j < np_; ++j) pw[j] = fabs(1.0 - pd[j] / closest);
+        if (np_ == 2) pw[0] = fabs((pd[1] / pd[0]) * pw[1]);                 // prior: far .. near
+        for (int j = 0; j < na; ++j) aw[j] = fabs(1.0 - ad[j] / closest);
+        if (na == 2) aw[1] = fabs((ad[0] / ad[1]) * aw[0]);                  // after: near .. far
+        double total = 0.0;
+        for (int j = 0; j < np_; ++j) total += pw[j];
+        for (int j = 0; j < na; ++j) total += aw[j];
+        // indices: np.flatnonzero(np.isin(dates, g + prior))[:2], np.flatnonzero(np.isin(dates, g + after))[-2:]
+        int pi[2], ai[2], npi = 0, nai = 0, cnt_a = 0;
+        for (int i = 0; i < n; ++i) {
+            bool inp = false, ina = false;
+            for (int j = 0; j < np_; ++j) inp |= (dd[i] == g + P[j]);
+            for (int j = 0; j < na; ++j) ina |= (dd[i] == g + A[j]);
+            if (inp && npi < 2) pi[npi++] = i;
+            if (ina) { if (nai < 2) ai[nai++] = i; else { ai[0] = ai[1]; ai[1] = i; } ++cnt_a; }
+        }
+        (void)cnt_a;
+        if (npi != np_ || nai != na) bad = 1;                                // duplicate dates: the reference raises
+        else {
+            for (int j = 0; j < np_; ++j) R[tid][pi[j]] += (float)(pw[j] / total);
+            for (int j = 0; j < na; ++j) R[tid][ai[j]] += (float)(aw[j] / total);
+        }
+    }
+    __syncthreads();
+    if (tid < 12) {
+        for (int t = 0; t < kMaxT; ++t) out->w[tid * kMaxT + t] = 0.f;
+        if (!bad)
+            for (int i = 0; i < n; ++i) {
+                double acc = 0.0;
+                for (int r = 0; r < 24; ++r) acc += minv[tid * 24 + r] * (double)R[r][i];
+                out->w[tid * kMaxT + pos[i]] = (float)acc;
+            }
+    }
+}
+
+// P (I + 100 D2'D2)^-1, 12 x 24, in double on the host (whittaker_smoother.py:25-36 + the pair means of :64-67)
+static void whittaker_monthly_matrix(double (&M)[12][24]) {
+    const int n = 24;
+    double A[24][48];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 2 * n; ++j) A[i][j] = (j == i || j == n + i) ? 1.0 : 0.0;
+    for (int r = 0; r < n - 2; ++r) {                                        // + 100 * D2' D2, D2 rows [1, -2, 1]
+        const double d[3] = {1.0, -2.0, 1.0};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) A[r + a][r + b] += 100.0 * d[a] * d[b];
+    }
+    for (int col = 0; col < n; ++col) {                                      // Gauss-Jordan with partial pivoting
+        int piv = col;
+        for (int r = col + 1; r < n; ++r) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+        if (piv != col) for (int j = 0; j < 2 * n; ++j) std::swap(A[piv][j], A[col][j]);
+        const double inv = 1.0 / A[col][col];
+        for (int j = 0; j < 2 * n; ++j) A[col][j] *= inv;
+        for (int r = 0; r < n; ++r)
+            if (r != col && A[r][col] != 0.0) {
+                const double f = A[r][col];
+                for (int j = 0; j < 2 * n; ++j) A[r][j] -= f * A[col][j];
+            }
+    }
+    for (int k = 0; k < 12; ++k)
+        for (int j = 0; j < n; ++j) M[k][j] = 0.5 * (A[2 * k][n + j] + A[2 * k + 1][n + j]);
+}
+
 #define LAUNCH_T(kern, T, ...)                                                        \
     do {                                                                              \
         if ((T) <= 8) hipLaunchKernelGGL((kern<8>), __VA_ARGS__);                     \
@@ -642,13 +769,11 @@ ttc_status tile_fix_missing(ttc_ctx* c, float* d_s2, int T, int X, int Y, int do
     return TTC_OK;
 }
 
-ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat,
-                                 const int32_t* h_keep, const float* d_interp, const float* d_s1, const float* d_dem,
-                                 const double* h_min, const double* h_max, int size, int n_dates_ok, float* d_windows,
-                                 float* d_windows_raw, hipStream_t s) {
-    if (!d_s2 || !h_wmat || !d_interp || !d_s1 || !d_dem || !h_min || !h_max || !d_windows)
-        return c->fail(TTC_ERR_ARG, "process_subtiles: null argument");
-    if (T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "process_subtiles: T must be in [1, 32]");
+// core of process_subtiles with the temporal operator already in device memory (d_wm); n_dates_ok < 0: taken from *d_wm.
+// stop_after_inputs: only the preprocessing half (temporal stage, window assembly + normalisation into the model's input frames)
+static ttc_status tile_core(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const WMat* d_wm, const float* d_interp,
+                            const float* d_s1, const float* d_dem, const double* h_min, const double* h_max, int size, int n_dates_ok,
+                            float* d_windows, float* d_windows_raw, bool stop_after_inputs, hipStream_t s) {
     const int W = c->cfg.win_in, L = c->cfg.length;
     if (size != W - 14) return c->fail(TTC_ERR_ARG, "process_subtiles: size must equal win_in - 14");
     if (c->cfg.win_rows != 0 && c->cfg.win_rows != W) return c->fail(TTC_ERR_ARG, "process_subtiles: needs square windows (win_rows = 0)");
@@ -670,12 +795,6 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     c->named["tile_s1q"] = {s1q, (size_t)L * 2 * npix};
     c->named["tile_s1med"] = {s1med, (size_t)2 * npix};
     c->named["tile_probs"] = {probs, (size_t)wt.n * size * size};
-
-    WMat wm{};
-    wm.T = T; wm.keep = 0; wm.Tk = 0;
-    for (int t = 0; t < T; ++t) if (!h_keep || h_keep[t]) { wm.keep |= 1u << t; wm.Tk++; }
-    for (int k = 0; k < 12; ++k)
-        for (int t = 0; t < T; ++t) wm.w[k * kMaxT + t] = ((wm.keep >> t) & 1u) ? h_wmat[k * T + t] : 0.0f;
     Norm nm{};
     for (int i = 0; i < 17; ++i) {
         nm.lo[i] = (float)h_min[i]; nm.hi[i] = (float)h_max[i];
@@ -689,7 +808,7 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
           static LdsConfig cfg32;
           TTC_HIP(c, cfg32.ensure(&k_tile_temporal<32>, (size_t)32 * 640 * 4));
       }
-      LAUNCH_T(k_tile_temporal, T, dim3((unsigned)((npix + 63) / 64)), dim3(64), (size_t)TM * 640 * sizeof(float), s, d_s2, wm, (int)npix, L, sm, med);
+      LAUNCH_T(k_tile_temporal, T, dim3((unsigned)((npix + 63) / 64)), dim3(64), (size_t)TM * 640 * sizeof(float), s, d_s2, d_wm, (int)npix, L, sm, med);
       TTC_HIP(c, hipGetLastError()); }
     { KTimer kt(c, "tile_s1", s);
       hipLaunchKernelGGL(k_tile_s1, dim3(gp), dim3(256), 0, s, d_s1, (int)npix, L, s1q, s1med);
@@ -699,6 +818,7 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
       hipLaunchKernelGGL(k_assemble, dim3((PP + 255) / 256, L + 1, wt.n), dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm,
                          X, Y, W, L, c->frames);
       TTC_HIP(c, hipGetLastError()); }
+    if (stop_after_inputs) return TTC_OK;
     { KTimer kt(c, "bright", s);
       hipLaunchKernelGGL(k_bright_flags, dim3((W * W + 255) / 256, wt.n), dim3(256), 0, s, sm, med, wt, X, Y, W, L, flags);
       TTC_HIP(c, hipGetLastError());
@@ -711,10 +831,59 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     { KTimer kt(c, "post", s);
       unsigned char* cc = static_cast<unsigned char*>(c->scratch_buf("tile_clear", (size_t)npix));
       if (!cc) return c->fail(TTC_ERR_NOMEM, "clear-count map");
-      hipLaunchKernelGGL(k_clear_map, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, d_interp, wm.keep, T, (int)npix, cc);
-      PostArgs pa{probs, cc, d2, d_windows, d_windows_raw, wt, wm.keep, T, X, Y, size, n_dates_ok};
+      hipLaunchKernelGGL(k_clear_map, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, d_interp, d_wm, T, (int)npix, cc);
+      PostArgs pa{probs, cc, d2, d_windows, d_windows_raw, wt, d_wm, T, X, Y, size, n_dates_ok};
       const size_t lds = 2 * (size_t)(size + 2) * (size + 2);
       hipLaunchKernelGGL(k_post, dim3(wt.n), dim3(1024), lds, s, pa);
       TTC_HIP(c, hipGetLastError()); }
     return TTC_OK;
+}
+
+ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat,
+                                 const int32_t* h_keep, const float* d_interp, const float* d_s1, const float* d_dem,
+                                 const double* h_min, const double* h_max, int size, int n_dates_ok, float* d_windows,
+                                 float* d_windows_raw, hipStream_t s) {
+    if (!d_s2 || !h_wmat || !d_interp || !d_s1 || !d_dem || !h_min || !h_max || !d_windows)
+        return c->fail(TTC_ERR_ARG, "process_subtiles: null argument");
+    if (T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "process_subtiles: T must be in [1, 32]");
+    // the host-built operator travels through a small ring of pinned slots, so the copy is asynchronous and the slot of a
+    // call still in flight is not overwritten by the next ones
+    constexpr int kSlots = 8;
+    WMat* h_ring = static_cast<WMat*>(c->pinned_buf("wmat_ring", sizeof(WMat) * kSlots));
+    WMat* d_ring = static_cast<WMat*>(c->scratch_buf("wmat_ring", sizeof(WMat) * kSlots));
+    if (!h_ring || !d_ring) return c->fail(TTC_ERR_NOMEM, "operator staging");
+    const int slot = (c->wmat_slot++) % kSlots;
+    WMat& wm = h_ring[slot];
+    std::memset(&wm, 0, sizeof(WMat));
+    wm.T = T; wm.keep = 0; wm.Tk = 0;
+    for (int t = 0; t < T; ++t) if (!h_keep || h_keep[t]) { wm.keep |= 1u << t; wm.Tk++; }
+    for (int k = 0; k < 12; ++k)
+        for (int t = 0; t < T; ++t) wm.w[k * kMaxT + t] = ((wm.keep >> t) & 1u) ? h_wmat[k * T + t] : 0.0f;
+    TTC_HIP(c, hipMemcpyAsync(d_ring + slot, &wm, sizeof(WMat), hipMemcpyHostToDevice, s));
+    return tile_core(c, d_s2, T, X, Y, d_ring + slot, d_interp, d_s1, d_dem, h_min, h_max, size, n_dates_ok, d_windows, d_windows_raw,
+                     false, s);
+}
+
+// the same with the operator built on the device from the missing-pixel counts and the acquisition days: no host round trip.
+// d_dates [T] int32 in device memory.  d_status (optional, device int32): [1] <- dates kept.
+ttc_status tile_process_subtiles_dev(ttc_ctx* c, float* d_s2, int T, int X, int Y, const int32_t* d_dates, const float* d_interp,
+                                     const float* d_s1, const float* d_dem, const double* h_min, const double* h_max, int size,
+                                     float* d_windows, float* d_windows_raw, bool stop_after_inputs, hipStream_t s) {
+    if (!d_s2 || !d_dates || !d_interp || !d_s1 || !d_dem || !h_min || !h_max) return c->fail(TTC_ERR_ARG, "process_subtiles: null argument");
+    if (T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "process_subtiles: T must be in [1, 32]");
+    int32_t* counts = static_cast<int32_t*>(c->scratch_buf("miss_counts", sizeof(int32_t) * kMaxT));
+    WMat* d_wm = static_cast<WMat*>(c->scratch_buf("wmat_dev", sizeof(WMat)));
+    double* d_minv = static_cast<double*>(c->scratch_buf("wmat_minv", sizeof(double) * 12 * 24));
+    if (!counts || !d_wm || !d_minv) return c->fail(TTC_ERR_NOMEM, "operator scratch");
+    if (!c->minv_ready) {
+        double M[12][24];
+        whittaker_monthly_matrix(M);
+        TTC_HIP(c, hipMemcpy(d_minv, M, sizeof(M), hipMemcpyHostToDevice));
+        c->minv_ready = true;
+    }
+    TTC_CHECK(tile_fix_missing(c, d_s2, T, X, Y, 1, 0, s));                 // interpolate_na_vals, job.py:1149
+    TTC_CHECK(tile_missing_counts(c, d_s2, T, X, Y, counts, s));            // id_missing_px(arr, 10), job.py:1032
+    hipLaunchKernelGGL(k_build_wmat, dim3(1), dim3(64), 0, s, counts, (X * X) / 10 + ((X * X) % 10 ? 1 : 0), d_dates, T, d_minv, d_wm, c->spec_status);
+    TTC_HIP(c, hipGetLastError());
+    return tile_core(c, d_s2, T, X, Y, d_wm, d_interp, d_s1, d_dem, h_min, h_max, size, -1, d_windows, d_windows_raw, stop_after_inputs, s);
 }

@@ -194,6 +194,10 @@ struct ttc_ctx {
     bool keep_debug = false;      // ttc_debug_keep: also materialise intermediates that the fused kernels never write (test aid)
     // workspace (tile-level), grown on demand
     std::map<std::string, std::pair<void*, size_t>> scratch;
+    std::map<std::string, std::pair<void*, size_t>> pinned;    // page-locked host staging, same keyed-growth scheme
+    int* spec_status = nullptr;   // single-call tile path: device int32[4] the speculative stages report into (see ttc_predict_tile)
+    unsigned wmat_slot = 0;       // ring index of the host-built temporal operator (tile.hip)
+    bool minv_ready = false;      // the constant Whittaker matrix has been uploaded (tile.hip)
 
     Timing timing;
 
@@ -203,6 +207,7 @@ struct ttc_ctx {
     bool half() const { return cfg.precision >= 2; }      // 16-bit conv engine selected
     bool bf() const { return cfg.precision == 3; }
     void* scratch_buf(const std::string& key, size_t bytes);
+    void* pinned_buf(const std::string& key, size_t bytes);
 };
 
 // model.hip
