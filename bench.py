@@ -1,18 +1,20 @@
-"""Benchmark of the MI355X tree-cover inference hot path (BASELINE.json metric).
+"""Benchmark of the MI355X tree-cover inference hot path (BASELINE.json metric: 10 m pixels/s; max |dprob| vs the oracle).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--win 172] [--length 4] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp16|bf16|bf16x3] [--win 172] [--length 4]
+    python bench.py --preprocess-only --tiles 256          # BASELINE configs[2]: preprocessing only, HBM roofline
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = one pass of the built hot path over one synthetic 618x618 tile that is already
-resident in HBM (config.stages lists exactly what runs inside the timed region):
+A "step" = `--inflight` (default 2) synthetic 618x618 tiles per GPU, each resident in HBM as the job stores it (uint16 bands,
+cloud / shadow mask, DEM) and each pushed through the WHOLE built hot path by ONE C-ABI call (ttc_predict_tile, no host round
+trip) on its own HIP stream and context:
 
-    bilinear 20 m->10 m  ->  cloud / shadow gap-fill (feather, aligned mosaic, per-date NNLS fit, blend)
-    ->  DSen2 super-resolution (31 windows x T dates, reference tiling)
-    ->  repair / indices / 12xT temporal operator / medians  ->  36 overlapping windows
-    ->  bi-ConvGRU + U-Net forward (fp32 MFMA)  ->  post-masks  ->  Gaussian overlap mosaic
-    [-> RCCL gather of the uint8 raster to rank 0 when N > 1]
+    uint16 decode + S1 dB -> bilinear 20 m->10 m -> cloud / shadow gap-fill (feather, aligned mosaic, per-date NNLS fit, blend)
+    -> DSen2 super-resolution (31 windows x T dates, reference tiling) -> NaN repair, date screening, indices, 12xT temporal
+    operator, medians -> 36 overlapping windows -> bi-ConvGRU + U-Net forward -> post-masks -> Gaussian overlap mosaic (uint8)
+    [-> RCCL gather of the finished uint8 rasters to rank 0, batched, on a side stream, when N > 1]
 
-Tiles shard embarrassingly (one process per GPU, static assignment, weak scaling); the only
+Tiles differ from step to step (a pool of distinct seeds per rank: tile_id = k * world + rank), so the data-dependent branches of
+the gap-fill see different inputs.  Tiles shard embarrassingly (one process per GPU, static assignment, weak scaling); the only
 collective is the gather of finished rasters.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -29,40 +31,49 @@ sys.path.insert(0, ROOT)
 TILE = 618
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3        # v_mfma_f32_32x32x2_f32, dense
-
-
-def pmc_traffic(args):
-    """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the
-    timed process).  Only valid for the configuration the counters were collected on."""
-    name = "r01_c_pmc_conv_gates.json" if args.precision == "fp32" else "r01_f_pmc_conv_b3_gates.json"
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
-    if args.win != 172 or not os.path.exists(p):
-        return None
-    with open(p) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
-
-
-def roofline(args, gates_ms, gates_n):
-    """dominant kernel = the ConvGRU gates convolution (49 -> 64, both directions, 36 windows per launch)."""
-    W = args.win
-    flops = conv_gates_flops(W, 36)
-    if args.precision == "fp32":
-        ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
-        return {"kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
-                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
-                "traffic": pmc_traffic(args), "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops}
-    # split-bf16 engine: 3 bf16 MFMAs per term put the matrix floor (0.18 ms) below the HBM floor of the fp32 activations
-    nbytes = 4.0 * 72 * (49 * (W + 2) ** 2 + 64 * W * W)          # algorithmic: padded input planes + output planes
-    ach = nbytes / (gates_ms * 1e-3) / 1e9 if gates_ms > 0 else 0.0
-    return {"kernel": "conv3x3_b3<NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions, split-bf16 MFMA)",
-            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args), "launch_ms": gates_ms, "launches_timed": gates_n, "bytes_per_launch": nbytes,
-            "mfma_bf16_frac": 3.0 * flops * (56.0 / 49) * (10.0 / 9) / (gates_ms * 1e-3) / 2.5e15 if gates_ms > 0 else 0.0}
+H16_MFMA_PEAK_TF = 2500.0        # v_mfma_f32_32x32x16_{f16,bf16}, dense
+DTYPES = {
+    "fp32": "f32 (fp32 MFMA, exact fp32 FMA chains)",
+    "fp16": "fp16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
+    "bf16": "bf16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
+    "bf16x3": "f32 storage, split-bf16 (3 products) MFMA, f32 accumulate (round-1 engine)",
+}
 
 
 def conv_gates_flops(W, n_windows):
     """algorithmic FLOPs of ONE conv_gates launch: 3x3, 49 -> 64, W^2 px, both directions"""
     return 2.0 * 9 * 49 * 64 * W * W * (2 * n_windows)
+
+
+def pmc_traffic(precision, win):
+    """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the timed
+    process).  Only valid for the configuration the counters were collected on."""
+    name = {"fp32": "r01_c_pmc_conv_gates.json", "bf16x3": "r01_f_pmc_conv_b3_gates.json", "fp16": "r02_pmc_conv_h16_gates.json"}.get(precision)
+    p = os.path.join(ROOT, "profiles", name) if name else None
+    if win != 172 or not p or not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
+def roofline(precision, win, gates_ms, gates_n):
+    """dominant kernel family = the ConvGRU gates convolution (49 -> 64, both directions, 36 windows per launch)"""
+    flops = conv_gates_flops(win, 36)
+    ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
+    if precision == "fp32":
+        return {"kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
+                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
+                "traffic": pmc_traffic(precision, win), "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops}
+    # 16-bit engines: ALGORITHMIC flops against the dense 16-bit MFMA peak; the three split products and the K padding
+    # (49 -> 56 channels, 9 -> 10 tap halves) that the kernel actually issues are reported beside it
+    nbytes = 72.0 * (56 * (win + 2) ** 2 * 4 + 64 * win * (win + 2) * 4)          # hi+lo blocked input planes + fp32 raw output
+    issued = 3.0 * flops * (56.0 / 49) * (10.0 / 9)
+    name = "conv3x3_h16<TERMS=3,NCG=2,EPI_RAW>" if precision in ("fp16", "bf16") else "conv3x3_b3<NCG=2,EPI_RAW>"
+    return {"kernel": name + " (ConvGRU gates, 49->64, both directions)", "bound": "mfma", "achieved": ach, "peak": H16_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": ach / H16_MFMA_PEAK_TF, "traffic": pmc_traffic(precision, win), "launch_ms": gates_ms,
+            "launches_timed": gates_n, "flops_per_launch": flops,
+            "mfma_issue_frac": issued / (gates_ms * 1e-3) / (H16_MFMA_PEAK_TF * 1e12) if gates_ms > 0 else 0.0,
+            "hbm_frac": nbytes / (gates_ms * 1e-3) / (HBM_PEAK_GBS * 1e9) if gates_ms > 0 else 0.0, "bytes_per_launch": nbytes}
 
 
 def cpu_baseline(args, tile):
@@ -82,20 +93,17 @@ def cpu_baseline(args, tile):
     s2_10, s2_20, s1 = O.to_float32(s2_10), O.to_float32(s2_20), O.s1_to_db(s1)
     tm["codecs"] = time.time() - t0
     t0 = time.time(); s2 = O.upsample_20m(s2_10, s2_20); tm["bilinear"] = time.time() - t0
-    # gap-fill on a quarter tile (x4)
-    q = TILE // 2
+    q = TILE // 2                                       # gap-fill on a quarter tile (x4)
     random.seed(0)
     t0 = time.time()
     _, qi, _ = G.remove_cloud_and_shadows(s2[:, :q, :q].copy(), probs[:, :q, :q].copy(), np.zeros((q, q), bool))
     tm["gapfill"] = 4.0 * (time.time() - t0)
     interp = np.zeros(probs.shape, np.float32); interp[:, :q, :q] = qi
-    # DSen2 on 4 of the 31 windows (x 31/4), all T dates
-    t0 = time.time()
+    t0 = time.time()                                    # DSen2 on 4 of the 31 windows (x 31/4), all T dates
     for k in range(4):
         win = np.pad(s2[:, 110 * k:110 * k + 110, :110], ((0, 0), (4, 4), (4, 4), (0, 0)), "reflect")
         ds(win, win[..., 4:])
     tm["dsen2"] = (time.time() - t0) * 31.0 / 4.0
-    # process_subtiles numerics on the whole tile with a stub model, + the model on 6 of the 36 windows (x6)
     feeds = []
 
     def stub(x):
@@ -124,19 +132,21 @@ def main():
     ap.add_argument("--win", type=int, default=172, help="model input window (172 = reference default; 168 also legal)")
     ap.add_argument("--length", type=int, default=4, help="ConvGRU steps (reference default 4; 12 = monthly)")
     ap.add_argument("--dates", type=int, default=12, help="raw acquisition dates T")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="conv engine: exact fp32 MFMA chains (BASELINE configs[1], default) or split-bf16 MFMA (3 products per "
-                         "term, fp32 accumulate; max |dprob| 7e-5 vs fp32)")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="tiles in flight per GPU per step, each on its own HIP stream + context: one tile's latency-bound "
-                         "gap-fill / tile kernels run under another tile's convolutions")
+    ap.add_argument("--precision", choices=list(DTYPES), default="fp32",
+                    help="conv engines: exact fp32 MFMA chains (BASELINE configs[1], default), fp16 / bf16 hi+lo operand pairs on the "
+                         "16-bit engine (configs[4] / [3]), or the round-1 split-bf16 engine")
+    ap.add_argument("--inflight", type=int, default=2, help="tiles in flight per GPU per step, each on its own HIP stream + context")
+    ap.add_argument("--pool", type=int, default=4, help="distinct synthetic tiles per rank, visited round-robin")
+    ap.add_argument("--gather-batch", type=int, default=64, help="finished rasters per RCCL gather (N > 1)")
     ap.add_argument("--detect", action="store_true",
-                    help="also run the multi-temporal cloud/shadow DETECTION (cloud_removal.py:1215-1677, the row after SURVEY 8's "
-                         "a1-a20) inside the step and gap-fill with ITS mask instead of the given one")
-    ap.add_argument("--from-host", action="store_true",
-                    help="informational: every step uploads the raw tile from pinned host memory first (PCIe-inclusive rate, "
-                         "reported in DESIGN.md, never the headline value)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the informational second measurement with the other conv engine")
+                    help="also run the multi-temporal cloud/shadow DETECTION (cloud_removal.py:1215-1677) inside the step and "
+                         "gap-fill with ITS mask instead of the given one")
+    ap.add_argument("--preprocess-only", action="store_true",
+                    help="BASELINE configs[2]: decode + bilinear + gap-fill + temporal stage + window assembly only (no DSen2, no "
+                         "model), reported against the HBM roofline (404.8 MB algorithmic bytes per T=12 tile, SURVEY 8d)")
+    ap.add_argument("--tiles", type=int, default=256, help="tiles of the --preprocess-only run")
+    ap.add_argument("--no-alt", action="store_true", help="skip the informational second measurement with the other precision")
+    ap.add_argument("--no-dprob", action="store_true", help="skip max |dprob| (HIP vs the oracle on windows of the bench's own tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -163,133 +173,201 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
+    dev = f"cuda:{local}"
     size = args.win - 14
-    def make_sessions(precision):
-        return [job.TTCSession(Wt.synth_weights(0), win_in=args.win, length=args.length, max_windows=36, device=local,
-                               precision=precision) for _ in range(args.inflight)]
-    sessions = make_sessions(args.precision)
-    streams = [torch.cuda.Stream(device=local) for _ in range(args.inflight)] if args.inflight > 1 else [None]
+    weights = Wt.synth_weights(0)
 
-    # synthetic tile, seed 1234 + tile_id (tile_id = rank): 10 m bands, 20 m bands, interp, S1, DEM -> HBM
-    # (cloudy S2 stack + binary cloud/shadow mask from synth_gapfill_scene; S1 / DEM from synth_tile)
-    s2, dates, probs, _ = synth.synth_gapfill_scene(seed=1234 + rank, T=args.dates, H=TILE, W=TILE)
-    _, _, _, s1, dem = synth.synth_tile(seed=1234 + rank, T=2, H=TILE, W=TILE)
-    # the raw tile as stored (uint16, src/tof/tof_downloading.py:51-61): decoding is part of the step
+    def make_sessions(precision):
+        return [job.TTCSession(weights, win_in=args.win, length=args.length, max_windows=36, device=local, precision=precision)
+                for _ in range(args.inflight)]
+
+    # ---- the tile pool: tile_id = k * world + rank, seed 1234 + tile_id; raw arrays as stored (uint16, tof_downloading.py:51-61)
     def u16(a):
         return np.trunc(np.clip(a, 0, 1) * 65535).astype(np.uint16)
-    s2_10 = u16(s2[..., :4])
-    s2_20 = u16(s2[:, ::2, ::2, 4:])
-    s1 = u16(s1)
-    host_tile = (s2_10, s2_20, probs, dates, s1, dem)
-    dev = f"cuda:{local}"
-    d10, d20 = torch.from_numpy(s2_10.view(np.int16)).to(dev), torch.from_numpy(s2_20.view(np.int16)).to(dev)
-    dprobs, ds1, ddem = torch.from_numpy(probs).to(dev), torch.from_numpy(s1.view(np.int16)).to(dev), torch.from_numpy(dem).to(dev)
-    ddem_m = ddem * 12.0                    # metres for the detector's elevation rules (synthetic DEM is in units of 90 m)
-    gather_bufs = [[torch.empty((TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
-                   for _ in range(args.inflight)]
+
+    def make_tile(tile_id):
+        s2, dates, probs, _ = synth.synth_gapfill_scene(seed=1234 + tile_id, T=args.dates, H=TILE, W=TILE)
+        _, _, _, s1, dem = synth.synth_tile(seed=1234 + tile_id, T=2, H=TILE, W=TILE)
+        host = (u16(s2[..., :4]), u16(s2[:, ::2, ::2, 4:]), probs, np.asarray(dates), u16(s1), dem)
+        d = {"s2_10": torch.from_numpy(host[0].view(np.int16)).to(dev), "s2_20": torch.from_numpy(host[1].view(np.int16)).to(dev),
+             "mask": torch.from_numpy(probs).to(dev), "dates": torch.tensor([int(v) for v in dates], dtype=torch.int32, device=dev),
+             "s1": torch.from_numpy(host[4].view(np.int16)).to(dev), "dem": torch.from_numpy(dem).to(dev)}
+        d["dem_m"] = d["dem"] * 12.0            # metres for the detector's elevation rules (the synthetic DEM is in units of 90 m)
+        return host, d
+    pool = [make_tile(k * world + rank) for k in range(max(1, args.pool))]
+    host_tile = pool[0][0]
+    flags = 0
+    if args.detect:
+        flags |= 1
+    if args.preprocess_only:
+        flags |= 2 | 4
+
+    streams = [torch.cuda.Stream(device=local) for _ in range(args.inflight)]
+    side = torch.cuda.Stream(device=local)
+    B = max(1, min(args.gather_batch, args.inflight * max(1, args.steps)))
+    B -= B % args.inflight if B > args.inflight else 0
+    rings = [torch.empty((B, TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(2)]        # double-buffered raster batches
+    status = torch.zeros((2, B, 4), dtype=torch.int32, device=dev)
+    gather_bufs = [[torch.empty((B, TILE, TILE), dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+                   for _ in range(2)]
+    state = {"pos": 0, "ring": 0, "tile": 0, "gathers": 0, "failed": 0}
+    gathered = [None, None]                      # event: the last gather that read ring r has finished
+
+    def flush(n_valid):
+        """hand the finished batch to the gather on the side stream; compute continues into the other ring"""
+        r = state["ring"]
+        if world > 1:
+            for st in streams:
+                side.wait_stream(st)
+            with torch.cuda.stream(side):
+                shard.gather_rasters(rings[r], rank, world, 0, gather_bufs[r])        # one collective per B rasters (RCCL over xGMI)
+                gathered[r] = side.record_event()
+            state["gathers"] += 1
+        state["ring"] ^= 1
+        state["pos"] = 0
+        if gathered[state["ring"]] is not None:  # the ring we are about to overwrite was handed to a gather two flushes ago
+            for st in streams:
+                st.wait_event(gathered[state["ring"]])
 
     def step(sessions):
         for slot, (sess, st) in enumerate(zip(sessions, streams)):
-            if st is None:
-                tile_step(sess, slot)
-            else:
-                with torch.cuda.stream(st):
-                    tile_step(sess, slot)
-
-    pinned = None
-    if args.from_host:
-        pinned = [torch.from_numpy(a).pin_memory() for a in (s2_10.view(np.int16), s2_20.view(np.int16), probs, s1.view(np.int16), dem)]
-
-    def tile_step(sess, slot, gather=True):
-        ctx = sess.ctx
-        if pinned is not None:                      # H2D on the tile's own stream: overlaps the other tile's kernels
-            d10_, d20_, dprobs_, ds1_, ddem_ = (t.to(dev, non_blocking=True) for t in pinned)
-            return tile_body(sess, slot, gather, d10_, d20_, dprobs_, ds1_, ddem_)
-        return tile_body(sess, slot, gather, d10, d20, dprobs, ds1, ddem)
-
-    def tile_body(sess, slot, gather, d10, d20, dprobs, ds1, ddem):
-        ctx = sess.ctx
-        f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(ds1)   # tof_downloading.py:64-72, job.py:699-708
-        s2d = ctx.upsample_20m(f10, f20)                              # job.py:734-782
-        mask, pf = dprobs, None
-        if args.detect:                                               # cloud_removal.py:1215-1677 (process_tile: job.py:837)
-            mask, pf = ctx.identify_clouds_shadows(s2d, ddem_m, None, None)
-        dint, _, _ = ctx.remove_cloud_and_shadows(s2d, mask, pf, None)   # cloud_removal.py:888-973 (deterministic sampler)
-        ctx.superresolve_tile(s2d, quirks=True)                       # job.py:95-147
-        f32, u8 = job.predict_tile(s2d, dates, dint, s1db, ddem, sess, size=size, to_host=False)   # job.py:1125-1641
-        if world > 1 and gather:
-            shard.gather_rasters(u8, rank, world, 0, gather_bufs[slot])     # final-mosaic gather (RCCL over xGMI)
-        return u8
+            tile = pool[state["tile"] % len(pool)][1]
+            state["tile"] += 1
+            r, p = state["ring"], state["pos"]
+            with torch.cuda.stream(st):
+                try:
+                    sess.ctx.predict_tile_raw(tile["s2_10"], tile["s2_20"], tile["s1"], tile["dem"], tile["mask"], tile["dates"],
+                                              job.min_all, job.max_all, size, dem_m=tile["dem_m"], flags=flags,
+                                              out=None if args.preprocess_only else rings[r][p], status=status[r, p])
+                except RuntimeError as e:        # a failed tile must not poison the batch: record it and go on
+                    state["failed"] += 1
+                    print(f"[bench] rank {rank}: tile {state['tile'] - 1} failed: {e}", file=sys.stderr)
+            state["pos"] += 1
+            if state["pos"] == B:
+                flush(B)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(sessions):
+    def measure(sessions, steps):
         ctx = sessions[0].ctx
+        state.update(pos=0, ring=0, gathers=0)
         sync()
         for _ in range(args.warmup):
             step(sessions)
+        if state["pos"]:
+            flush(state["pos"])
+        state["gathers"] = 0
         ctx.timing(2)                 # HIP events around the conv-engine launches only (on the launch stream)
         ctx.kernel_ms(None)
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step(sessions)
+        if state["pos"]:
+            flush(state["pos"])
         sync()
         dt = time.perf_counter() - t0
         gates_ms, gates_n = ctx.kernel_ms("conv_gates")
         ctx.timing(0)
-        return shard.max_over_ranks(dt, dev, world), gates_ms, gates_n
+        bad = int(((status[..., 0] != 0) | (status[..., 2] != 0)).sum().item())
+        return shard.max_over_ranks(dt, dev, world), gates_ms, gates_n, bad
 
-    dt, gates_ms, gates_n = measure(sessions)
-    # the same kernel without a second tile competing for the CUs (informational; the roofline line uses the live number)
+    def max_dprob(sess):
+        """HIP (this precision, through the C ABI) vs the fp32 torch oracle on windows of the bench's own tile: the model inputs the
+        tile path assembled for tile 0, windows 0, 14 and 35"""
+        from oracle import restate_model as M
+        tile = pool[0][1]
+        _, _, frames, _ = sess.ctx.predict_tile_raw(tile["s2_10"], tile["s2_20"], tile["s1"], tile["dem"], tile["mask"], tile["dates"],
+                                                    job.min_all, job.max_all, size, dem_m=tile["dem_m"], flags=(flags & 1) | 2, want_inputs=True)
+        torch.cuda.synchronize()
+        x = frames[[0, 14, 35]][:, :, :, 1:-1, 1:-1].permute(0, 1, 3, 4, 2).contiguous()      # [3, L+1, W, W, 17]
+        hip = sess.ctx.forward_windows(x).cpu().numpy()
+        ref = M.TreeCoverNet(weights, dtype=torch.float32)(x.cpu().numpy())[..., 0]
+        return float(np.abs(hip.astype(np.float64) - ref).max())
+
+    sessions = make_sessions(args.precision)
+    if args.preprocess_only:
+        steps = max(1, args.tiles // args.inflight)
+        dt, _, _, bad = measure(sessions, steps)
+        if rank == 0:
+            n_tiles = world * steps * args.inflight
+            alg = (4.0 * args.dates * 15 + 4.0 * (args.length + 1) * 17) * TILE * TILE           # SURVEY 8(d): raw in + model input out
+            gbs = n_tiles / world * alg / dt / 1e9
+            print(json.dumps({
+                "metric": "10m pixels/s tree-cover preprocessing only", "value": n_tiles * TILE * TILE / dt, "unit": "px/s", "n_gpus": world,
+                "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE.json configs[2]: preprocessing only on {n_tiles} synthetic 618x618 T={args.dates} tiles "
+                                       f"({args.inflight} in flight per GPU): uint16 decode + S1 dB, bilinear 20 m->10 m, cloud gap-fill, NaN repair + "
+                                       f"date screening, indices + 12xT temporal operator + medians, window assembly + normalisation (L={args.length})",
+                           "tiles": n_tiles, "ms_per_tile": dt / (steps * args.inflight) * 1e3, "tiles_flagged_for_staged_path": bad},
+                "roofline": {"kernel": "whole preprocessing chain (per tile)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_per_tile": alg,
+                             "note": "algorithmic bytes = raw [T,15,618,618] f32-equivalent in + model input [L+1,17,618,618] out (SURVEY 8d); "
+                                     "north_star target 0.40"}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    dt, gates_ms, gates_n, bad = measure(sessions, args.steps)
     iso_ms = None
-    if args.inflight > 1 and rank == 0:
+    if args.inflight > 1 and rank == 0:         # the same kernel without a second tile competing for the CUs (informational)
         c0 = sessions[0].ctx
         c0.timing(2); c0.kernel_ms(None)
+        tile = pool[0][1]
         for _ in range(3):
-            tile_step(sessions[0], 0, gather=False)      # rank-local: no collective here
+            c0.predict_tile_raw(tile["s2_10"], tile["s2_20"], tile["s1"], tile["dem"], tile["mask"], tile["dates"], job.min_all, job.max_all,
+                                size, dem_m=tile["dem_m"], flags=flags)
         torch.cuda.synchronize()
         iso_ms, _ = c0.kernel_ms("conv_gates")
         c0.timing(0)
+    dprob = None
+    if rank == 0 and not args.no_dprob:
+        dprob = max_dprob(sessions[0])
     if world > 1:
         dist.barrier()
     alt = None
     if world == 1 and not args.no_alt:
-        other = "bf16x3" if args.precision == "fp32" else "fp32"
+        other = "fp16" if args.precision == "fp32" else "fp32"
         for sx in sessions:
             sx.close()
-        dt2, g2, _ = measure(make_sessions(other))
-        alt = {"precision": other, "value": args.inflight * TILE * TILE * args.steps / dt2, "unit": "px/s", "ms_per_step": dt2 / args.steps * 1e3,
-               "conv_gates_launch_ms": g2,
+        alt_sessions = make_sessions(other)
+        dt2, g2, _, _ = measure(alt_sessions, args.steps)
+        alt = {"precision": other, "dtype": DTYPES[other], "value": args.inflight * TILE * TILE * args.steps / dt2, "unit": "px/s",
+               "ms_per_step": dt2 / args.steps * 1e3, "conv_gates_launch_ms": g2,
+               "max_dprob": None if args.no_dprob else max_dprob(alt_sessions[0]),
                "note": "same step with the other conv engine; informational, not the headline value"}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        ach = conv_gates_flops(args.win, 36) / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
         out = {
             "metric": "10m pixels/s tree-cover inference", "value": world * args.inflight * TILE * TILE * args.steps / dt, "unit": "px/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 storage/accumulate, split-bf16 (bf16x3) MFMA products",
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[args.precision], "data": "synthetic",
+            "max_dprob": dprob,
             "config": {
                 "workload": f"{args.inflight} x 618x618 tile per GPU per step, T={args.dates} dates, 36 overlapping {args.win}x{args.win} "
                             f"windows (out {size}), L={args.length}, {args.precision} (BASELINE.json configs[1])",
-                "stages": ["u16_decode+s1_db", "bilinear_20m"] + (["cloud_shadow_detection"] if args.detect else []) + [ "cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
-                           "dsen2_superresolve(31 windows x T)", "temporal_operator+indices+medians",
+                "stages": ["u16_decode+s1_db", "bilinear_20m"] + (["cloud_shadow_detection"] if args.detect else []) +
+                          ["cloud_gapfill(feather+aligned_mosaic+NNLS fit+blend, expected-multiplicity sampler)",
+                           "dsen2_superresolve(31 windows x T)", "nan_repair+date_screening+temporal_operator+indices+medians",
                            "window_assembly+normalise", "biConvGRU+UNet forward", "post_masks", "gaussian_mosaic"]
-                          + (["rccl_gather_u8"] if world > 1 else []),
-                "not_in_timed_region": [("nothing: the raw tile is uploaded from pinned host memory every step" if args.from_host
-                                         else "H2D of the raw tile (inputs resident in HBM)"),
+                          + (["rccl_gather_u8(batched, side stream)"] if world > 1 else []),
+                "not_in_timed_region": ["H2D of the raw tile (inputs resident in HBM as stored: uint16 bands, f32 mask / DEM)",
                                         ("-" if args.detect else "cloud/shadow DETECTION (SURVEY 8f-1, built: --detect): the mask is an input")],
+                "entry": "one ttc_predict_tile call per tile (no host round trip), one HIP stream + context per tile in flight",
                 "weights": "synthetic seed 0 (ConvGRU/U-Net weights absent from the reference checkout); DSen2 real",
-                "tiles_per_step_per_gpu": args.inflight, "streams_per_gpu": args.inflight, "win_in": args.win, "length": args.length, "dates": args.dates,
+                "tiles_per_step_per_gpu": args.inflight, "streams_per_gpu": args.inflight, "distinct_tiles_per_gpu": len(pool),
+                "tile_ids": "k * world + rank", "gather_batch": B if world > 1 else None, "gathers_timed": state["gathers"] if world > 1 else None,
+                "tiles_flagged_for_staged_path": bad, "tiles_failed": state["failed"],
+                "max_dprob_sample": "HIP vs fp32 oracle on windows 0, 14, 35 of tile 0 (model inputs as the tile path assembled them)",
+                "win_in": args.win, "length": args.length, "dates": args.dates,
             },
-            "roofline": roofline(args, gates_ms, gates_n),
+            "roofline": roofline(args.precision, args.win, gates_ms, gates_n),
         }
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms

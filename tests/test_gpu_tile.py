@@ -1,6 +1,8 @@
 """GPU parity of the per-tile numeric core (through the C ABI) against
  (a) golden vectors captured from the REFERENCE (tests/golden/, tools/gen_golden.py) and
  (b) the CPU oracle on the same seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -276,3 +278,114 @@ def test_upsample_20m(h, w):
     s20 = rng.random((2, h, w, 6)).astype(np.float32)
     got = sess.ctx.upsample_20m(s10, s20).cpu().numpy()
     _report(f"bilinear 20m->10m {h}x{w}", got, O.upsample_20m(s10, s20), 1e-6)
+
+
+@pytest.mark.parametrize("seed,dates_kind", [(1234, "regular"), (77, "wrap")])
+def test_single_call_tile_matches_staged_calls(seed, dates_kind):
+    """ttc_predict_tile (one enqueue, temporal operator and date screening formed on the device, speculative gap-fill) against
+    the staged calls job.py chains for the same raw tile: identical model inputs (the device-built 12 x T operator vs the host
+    mirror temporal.py) and identical rasters; the status word reports no fallback on these tiles.  'wrap': dates that start
+    late and end early in the year exercise the year-end wrap-around / mirroring branches of the regrid."""
+    import torch
+    from ttc import job
+    sess, _ = _session(172, 4)
+    ctx = sess.ctx
+    T, X = 9, 618
+    s2, dates, probs, _ = synth.synth_gapfill_scene(seed=seed, T=T, H=X, W=X)
+    _, _, _, s1, dem = synth.synth_tile(seed=seed, T=2, H=X, W=X)
+    if dates_kind == "wrap":
+        dates = np.array([100, 118, 131, 150, 178, 200, 221, 240, 262])
+    else:
+        dates = np.asarray(dates)
+    s2[1, 100:400, :, :] = 0.0                      # > 10 % missing pixels on a cloud-free date: the device screening must drop it
+
+    def u16(a):
+        return np.trunc(np.clip(a, 0, 1) * 65535).astype(np.uint16)
+    s2_10, s2_20, s1u = u16(s2[..., :4]), u16(s2[:, ::2, ::2, 4:]), u16(s1)
+    # staged path (what bench.py / job.py drive from Python)
+    d10 = torch.from_numpy(s2_10.view(np.int16)).cuda(); d20 = torch.from_numpy(s2_20.view(np.int16)).cuda()
+    f10, f20, s1db = ctx.to_float32(d10), ctx.to_float32(d20), ctx.s1_to_db(torch.from_numpy(s1u.view(np.int16)).cuda())
+    s2d = ctx.upsample_20m(f10, f20)
+    dint, _, _ = ctx.remove_cloud_and_shadows(s2d, probs, None, None)
+    ctx.superresolve_tile(s2d, quirks=True)
+    f32_ref, u8_ref = job.predict_tile(s2d, dates, dint, s1db, dem, sess, size=158)
+    frames_ref = ctx.debug_fetch("frames", (36, 5, 17, 174, 174))
+    # single call
+    u8, f32, frames, status = ctx.predict_tile_raw(s2_10, s2_20, s1u, dem, probs, dates, job.min_all, job.max_all, 158,
+                                                   want_float=True, want_inputs=True)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    print(f"[parity] single-call tile {dates_kind}: status {st.tolist()}")
+    assert st[0] == 0 and st[2] == 0 and st[1] == T - 1
+    d_in = np.abs(frames.cpu().numpy() - frames_ref).max()
+    print(f"[parity] single-call tile {dates_kind}: model inputs max|d| = {d_in:.2e}")
+    assert d_in <= 2e-6
+    got_f = f32.cpu().numpy()
+    assert np.array_equal(np.isnan(got_f), np.isnan(f32_ref))
+    _report(f"single-call raster ({dates_kind})", np.nan_to_num(got_f), np.nan_to_num(f32_ref), 0.11)
+    d = np.abs(u8.cpu().numpy().astype(int) - u8_ref.astype(int))
+    assert (d > 1).mean() < 1e-5 and (d > 0).mean() < 2e-2
+    # preprocessing only (BASELINE configs[2]): the same model inputs, no model, no raster
+    _, _, frames2, _ = ctx.predict_tile_raw(s2_10, s2_20, s1u, dem, probs, dates, job.min_all, job.max_all, 158,
+                                            flags=ctx.TILE_INPUTS_ONLY, want_inputs=True)
+    np.testing.assert_array_equal(frames2.cpu().numpy(), frames.cpu().numpy())
+
+
+def test_device_temporal_operator_matches_host_mirror():
+    """k_build_wmat (device) against sentinel-tree-cover_amd/temporal.py on date sets that exercise every branch of the regrid
+    (utils.py:176-347): regular, late start / early end (wrap-around), mirrored sides, negative days, a duplicate pair (the
+    reference raises -> all-zero operator), through the model inputs of a tiny constant-per-date tile."""
+    import torch
+    from ttc import job, temporal
+    sess, _ = _session(44, 4)
+    ctx = sess.ctx
+    X = 100
+    rng = np.random.default_rng(3)
+    for dates in ([5, 40, 100, 160, 220, 280, 340], [-20, 12, 33, 95, 130, 171, 200, 244, 290, 301, 350, 380],
+                  [100, 130, 160, 200], [200, 230, 260, 300, 330], [10, 25, 40, 80], [15, 15, 60, 200], [-150, -120, 30, 90, 200]):
+        T = len(dates)
+        levels = rng.uniform(0.05, 0.45, (T, 1, 1, 10)).astype(np.float32)
+        s2 = np.broadcast_to(levels, (T, X, X, 10)).copy()
+        s2 += rng.normal(0, 0.002, s2.shape).astype(np.float32)
+        s2 = np.clip(s2, 0.01, 0.9)
+        s2_10 = np.trunc(s2[..., :4] * 65535).astype(np.uint16)
+        s2_20 = np.trunc(s2[:, ::2, ::2, 4:] * 65535).astype(np.uint16)
+        s1 = np.full((12, X, X, 2), 20000, np.uint16)
+        dem = np.zeros((X, X), np.float32)
+        mask = np.zeros((T, X, X), np.float32)
+        _, _, frames, status = ctx.predict_tile_raw(s2_10, s2_20, s1, dem, mask, dates, job.min_all, job.max_all, 30,
+                                                    flags=ctx.TILE_INPUTS_ONLY | ctx.TILE_NO_SUPERRES, want_inputs=True)
+        # staged: same arrays through the host mirror
+        d10 = torch.from_numpy(s2_10.view(np.int16)).cuda(); d20 = torch.from_numpy(s2_20.view(np.int16)).cuda()
+        s2d = ctx.upsample_20m(ctx.to_float32(d10), ctx.to_float32(d20))
+        dint, _, _ = ctx.remove_cloud_and_shadows(s2d, mask, None, None)
+        s1db = ctx.s1_to_db(torch.from_numpy(s1.view(np.int16)).cuda())
+        job._process_subtiles_device(s2d, np.asarray(dates), dint, s1db, dem, sess, 30)
+        ref = ctx.debug_fetch("frames", (36, 5, 17, 46, 46))
+        d = np.abs(frames.cpu().numpy() - ref).max()
+        W = temporal.temporal_operator(np.asarray(dates))
+        print(f"[parity] device operator, dates {dates}: model inputs max|d| = {d:.2e} (host operator {'zero' if not W.any() else 'ok'})")
+        assert d <= 2e-6
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 end to end on ONE device: two processes, gloo-staged collectives (TTC_BENCH_BACKEND / TTC_BENCH_DEVICE),
+    so the multi-rank control flow -- rendezvous, distinct tile ids per rank, the batched raster gather on the side stream,
+    max-over-ranks timing, rank-0-only JSON -- runs before the driver's 8-GPU job ever does"""
+    import json
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    env = dict(os.environ, TTC_BENCH_BACKEND="gloo", TTC_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pool", "2",
+           "--gather-batch", "2", "--no-cpu-baseline", "--no-dprob", "--no-alt"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert any("rccl_gather_u8" in st for st in out["config"]["stages"])
+    assert out["config"]["gathers_timed"] == 2 and out["config"]["tiles_failed"] == 0
+    assert out["value"] > 0 and abs(out["value"] - 2 * 2 * 618 * 618 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-6
