@@ -112,3 +112,46 @@ def test_gapfill_date_count_range(sess, T):
     err = np.abs(got - want)
     print(f"[parity] gap-fill T={T}: max|d| = {err.max():.3e}, mean = {err.mean():.3e}")
     assert err.max() < 2e-3 and err.mean() < 1e-5
+
+
+def test_gapfill_at_bench_size_vs_oracle_and_sampler_effect_on_probabilities():
+    """What bench.py runs, at its size: the 618^2 T=12 tile of the bench (seed 1234).
+    (i)   gap-fill with the reference's stdlib-random sample replayed, against the oracle on the same stream (oracle pinned
+          bit-exactly to the reference in tests/test_oracle_gapfill.py);
+    (ii)  the deterministic expected-multiplicity sampler the bench uses, against that replay: reflectance difference, and
+    (iii) its effect on the final probabilities: the whole tile predicted from both gap-filled stacks (fp32 engine),
+          max |dprob| before the reference's 3-decimal rounding."""
+    import torch
+    from oracle import restate_gapfill as G
+    from ttc import job, weights as Wt
+    X, T = 618, 12
+    tiles, dates, probs, pf = synth.synth_gapfill_scene(seed=1234, T=T, H=X, W=X)
+    _, _, _, s1, dem = synth.synth_tile(seed=1234, T=2, H=X, W=X)
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=172, length=4, max_windows=36)
+    random.seed(11)
+    ref, ref_i, ref_rem = G.remove_cloud_and_shadows(tiles.copy(), probs.copy(), pf)
+    random.seed(11)
+    rep, rep_i, rep_rem = job.remove_cloud_and_shadows(tiles.copy(), probs, probs, dates, pf, sess=sess, sampler="reference")
+    np.testing.assert_array_equal(rep_i, ref_i)
+    assert list(rep_rem) == list(ref_rem)
+    e = np.abs(rep - ref)
+    print(f"[parity] gap-fill 618^2 T=12, replayed sampler vs oracle: max|d| = {e.max():.3e}, mean = {e.mean():.2e}")
+    assert e.max() < 5e-4 and e.mean() < 1e-6
+    det, det_i, _ = job.remove_cloud_and_shadows(tiles.copy(), probs, probs, dates, pf, sess=sess, sampler="expected")
+    np.testing.assert_array_equal(det_i, ref_i)
+    e2 = np.abs(det - rep)
+    print(f"[parity] deterministic vs replayed sampler, reflectance: max|d| = {e2.max():.3e}, rms = {np.sqrt((e2 ** 2).mean()):.2e}")
+    assert e2.max() < 0.03
+    # (iii) propagate both stacks to probabilities
+    raws = []
+    for stack in (rep, det):
+        d = torch.from_numpy(stack.copy()).cuda()
+        sess.ctx.superresolve_tile(d, quirks=True)
+        _, raw = job.process_subtiles(0, 0, d, dates, rep_i, s1, dem, sess, size=158, return_raw=True)
+        raws.append(np.stack([raw[k] for k in sorted(raw)]))
+    ok = (raws[0] <= 1.0) & (raws[1] <= 1.0)
+    dp = np.abs(raws[0] - raws[1])[ok]
+    print(f"[parity] deterministic vs replayed sampler, probabilities of the whole tile: max |dprob| = {dp.max():.3e}, "
+          f"p99.9 = {np.quantile(dp, 0.999):.2e}, rms = {np.sqrt((dp ** 2).mean()):.2e}")
+    # the reference itself draws a different sample on every run (global stdlib RNG, SURVEY F9): this is its run-to-run spread
+    assert np.quantile(dp, 0.999) < 5e-3

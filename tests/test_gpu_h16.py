@@ -156,7 +156,8 @@ def test_tile_16bit_vs_oracle(precision, size, length):
     for k, r in zip(feeds.keys(), raw_ref):          # windows the oracle fed to the model, in call order
         worst = max(worst, float(np.abs(raw[k].astype(np.float64) - r).max()))
     print(f"[parity] tile {precision} size {size} L {length}: max |dprob| before rounding = {worst:.3e}")
-    assert worst <= 1e-3
+    # measured on MI355X: fp32 5.0e-5, fp16 4.9e-5 (L = 4) / 3.6e-5 (168-pixel windows, L = 12), bf16 3.7e-4
+    assert worst <= (1e-3 if precision == "bf16" else 2e-4)
     u8, f32 = job.load_mosaic_predictions(wins, sess=sess, size=size, return_float=True)
     assert np.array_equal(np.isnan(f32), np.isnan(ref_f))
     d = np.abs(u8.astype(int) - ref_u8.astype(int))
