@@ -391,7 +391,12 @@ def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, si
         dem = t.cat([dem, dem_n], dim=1).contiguous()
         n = min(interp.shape[0], interp_n.shape[0])
         interp = t.cat([interp[:n], interp_n[:n]], dim=2)
+    s1, s1n = match_s1_steps(s1, s1n)                                        # :1071-1097
     s1 = t.cat([s1, s1n], dim=2).contiguous()
+    if int(s1.shape[0]) != 12:
+        # process_subtiles reshapes the stack to (4, 3, ...) quarters (:408): the reference raises for a 6- or 4-step stack and its
+        # main loop skips the pair (:1826 try / except) -- the same error class here, before any GPU work is wasted on it
+        raise ValueError(f"cannot reshape array of size {int(s1.numel())} into shape (4,3,{int(s1.shape[1])},{int(s1.shape[2])},2)")
     ctx.superresolve_windows(strip, wsize=125, quirks=1)                     # :1124, on bands 4..9 of the 14-channel strip
     ta, tf = border_windows(int(s1.shape[1]), tiles_x, size, size_y)
     hist_align = not np.array_equal(np.array(dates), np.array(dates_n))     # :1140-1145
@@ -404,6 +409,20 @@ def resegment_border(tile, neighb, tile_tif, neighbor_tif, sess, min_dates=2, si
     if return_strip:
         info.update(strip=strip, s1=s1, dem=dem)
     return wins, info
+
+
+def match_s1_steps(s1, s1n):
+    """:1071-1097 -- Sentinel-1 stacks of neighbouring tiles can hold 12, 6 or 4 steps (older downloads); the longer one is
+    subsampled onto the shorter one's steps ([0, 2, .. 10] / [0, 3, 6, 9] / [0, 1, 3, 5]).  Works on numpy arrays and tensors."""
+    n, m = int(s1.shape[0]), int(s1n.shape[0])
+    if n == m:
+        return s1, s1n
+    pick = {(12, 6): [0, 2, 4, 6, 8, 10], (12, 4): [0, 3, 6, 9], (6, 4): [0, 1, 3, 5]}
+    if (n, m) in pick:
+        return s1[pick[(n, m)]], s1n
+    if (m, n) in pick:
+        return s1, s1n[pick[(m, n)]]
+    return s1, s1n               # any other combination is left alone there too (and fails at the concatenation)
 
 
 # ---- one pair of tiles, as the job's main loop handles it (:1724-1826) -----------------------------------------------------
@@ -429,14 +448,18 @@ def resegment_pair(tile, neighb, tile_tif, neighbor_tif, windows_left, windows_r
     artifact test on the existing rasters -> resegment_border -> both tiles re-mosaicked with the new border windows ->
     keep the result unless the seam got more than 20 points worse.  windows_left / windows_right: the {path: window} dicts of
     the two tiles' processed/ folders (plain windows).  tile_tif / neighbor_tif: uint8 or float rasters, > 100 = no data.
-    -> None when nothing had to be done / the result is rejected, else (predictions_left, predictions_right, info)."""
+    -> None when nothing had to be done / the result is rejected, else (predictions_left, predictions_right, info).
+    The reference's retry with histogram matching (:1773-1797, taken when the seam difference stays above 5 with only two
+    shared dates) calls resegment_border with 7 of its 8 positional arguments (:1779 vs the signature at :847): it raises a
+    TypeError inside the main loop's try block, nothing is written for the pair and the loop moves on -- so that case
+    returns None here as well (info["retry_would_raise"] is set when a caller passes `info_out`)."""
     tt, tn = np.asarray(tile_tif, dtype=np.float32).copy(), np.asarray(neighbor_tif, dtype=np.float32).copy()
     tt[tt > 100] = np.nan
     tn[tn > 100] = np.nan
     diff = diff_for_compare(tt, tn)
     if not (check_if_artifact(tt, tn) == 1 or process_all):
         return None
-    wins, info = resegment_border(tile, neighb, tt, tn, sess, **kw)
+    wins, info = resegment_border(tile, neighb, tt, tn, sess, **{k: v for k, v in kw.items() if k != "info_out"})
     shape_l = (int(tile["s2"].shape[1]), int(tile["s2"].shape[2]))            # s2.shape[1:-1], as the reference passes it
     shape_r = (int(neighb["s2"].shape[1]), int(neighb["s2"].shape[2]))
     left = dict(windows_left)
@@ -449,6 +472,10 @@ def resegment_pair(tile, neighb, tile_tif, neighbor_tif, windows_left, windows_r
     smooth = seam_difference(pl, pr)
     diff = 100 if np.isnan(diff) else diff
     info.update(diff_for_compare=float(diff), smooth_diff=float(smooth))
+    if smooth > 5 and info["min_images"] == 2:                                # :1773: the retry raises there, the pair is skipped
+        if isinstance(kw.get("info_out"), dict):
+            kw["info_out"].update(info, retry_would_raise=True)
+        return None
     if smooth < (diff + 20) or np.isnan(smooth):
         return pl, pr, info
     return None

@@ -64,13 +64,22 @@ def neighbour_strip(tile: dict, size: int):
 def exchange_border_strips(tiles: dict, n_tiles: int, rank: int, world: int, size: int, device=None):
     """tiles: {tile_id: {s2 [T, X, Y, 10], interp [T, X, Y], s1 [12, X, Y, 2], dem [X, Y] (tensors), dates (int sequence)}} for
     the tiles of this rank.  Returns {t: neighbour strip dict of tile t+1} for the borders this rank owns; strips of tiles on
-    the same rank are views, the others arrive through one batch of point-to-point operations."""
+    the same rank are views, the others arrive through one batch of point-to-point operations.
+    Strips travel RAW (process_tile's outputs): the per-tile branch of resegment_border (fewer than 3 shared dates, :1003-1110)
+    preprocesses the neighbour on its FULL tile, so for such a pair the owner of the neighbour has to run preprocess_tile first
+    and send the preprocessed strip (resegment_border(..., neighb_is_strip=True) says so too); the shared-strip branch needs
+    nothing of the kind."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return {t: neighbour_strip(tiles[t + 1], size) for t in range(n_tiles - 1)}
     keep = size // 2 + 7
     backend = dist.get_backend()
+    if backend != "gloo" and device is None:
+        raise ValueError("exchange_border_strips: `device` (the rank's GPU) is required with the nccl backend")
+    too_long = [tid for tid, tl in tiles.items() if len(tl["dates"]) > 64]
+    if too_long:
+        raise ValueError(f"exchange_border_strips: tiles {too_long} hold more than 64 dates (the strip header carries 64)")
     stage = (lambda x: x.cpu()) if backend == "gloo" else (lambda x: x)
     sends = [t + 1 for t in range(n_tiles - 1) if (t + 1) % world == rank and t % world != rank]
     recvs = [t for t in borders_for_rank(n_tiles, rank, world) if (t + 1) % world != rank]

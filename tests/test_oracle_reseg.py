@@ -142,3 +142,17 @@ def test_resegment_border_arrays(tag):
         assert o["saved"] == bool(g[f"{tag}_saved{t}"])
         if o["saved"]:
             np.testing.assert_allclose(np.asarray(o["preds"], dtype=np.float32), g[f"{tag}_preds{t}"], rtol=0, atol=2e-4)
+
+
+def test_match_s1_steps_like_the_reference():
+    """resegment_tiles_wide.py:1071-1097: index lists for 12 / 6 / 4-step Sentinel-1 stacks (host logic of the product mirror)"""
+    import ttc  # noqa: F401
+    from ttc import resegment as RG
+    mk = lambda n: np.arange(n, dtype=np.float32).reshape(n, 1, 1, 1) * np.ones((1, 2, 3, 2), np.float32)      # noqa: E731
+    for n, m, want in [(12, 6, [0, 2, 4, 6, 8, 10]), (12, 4, [0, 3, 6, 9]), (6, 4, [0, 1, 3, 5])]:
+        a, b = RG.match_s1_steps(mk(n), mk(m))
+        assert a.shape[0] == b.shape[0] == m and a[:, 0, 0, 0].tolist() == [float(v) for v in want]
+        a, b = RG.match_s1_steps(mk(m), mk(n))
+        assert a.shape[0] == b.shape[0] == m and b[:, 0, 0, 0].tolist() == [float(v) for v in want]
+    a, b = RG.match_s1_steps(mk(12), mk(12))
+    assert a.shape[0] == 12 and b.shape[0] == 12
