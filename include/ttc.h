@@ -38,7 +38,8 @@ typedef enum {
     TTC_ERR_ARG = 1,      /* bad argument / unsupported geometry */
     TTC_ERR_HIP = 2,      /* a HIP runtime call failed */
     TTC_ERR_STATE = 3,    /* e.g. forward before weights are loaded */
-    TTC_ERR_NOMEM = 4
+    TTC_ERR_NOMEM = 4,
+    TTC_ERR_IO = 5        /* a host file could not be opened / read / written */
 } ttc_status;
 
 /* Model / window geometry.  Defaults mirror src/download_and_predict_job.py:60-61, :1715
@@ -337,6 +338,18 @@ ttc_status ttc_float_to_int16(ttc_ctx* ctx, const float* d_in, int64_t n, float 
 /* Sentinel-1 preparation of process_tile (job.py:699-708): /65535, saturated (== 1) samples -> the image's
  * median, convert_to_db(., 22) (job.py:74-89).  d_u16 [T, X, Y, 2] -> d_out [T, X, Y, 2] float32. */
 ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t X, int32_t Y, float* d_out, void* stream);
+
+/* ---- on-disk formats (host code, no GPU) ----------------------------------------------------------------------------------
+ * hkl.load(path) for the numeric arrays of temp/raw (src/download_and_predict_job.py:684-714; written at :462-463, :592-633
+ * with hkl.dump(..., compression='gzip')): reads dataset `name` of the HDF5 file's root group (NULL = hickle's "data", then
+ * "data_0", then the first dataset) into h_out (raw little-endian elements, C order).  Supported: the layout h5py's default
+ * format produces -- superblock v0/v1, old-style groups, object headers v1, contiguous or chunked (B-tree v1) storage,
+ * deflate and shuffle filters.  h_out may be NULL to query shape[<= 8] / ndim / elem_size / type_class (0 integer, 1 float) /
+ * is_signed only.  ttc_read_hkl_error() returns the message of the last failure.  Parity with files written by real hickle is
+ * unpinned in this repository (no sample, no HDF5 library in the build image): see DESIGN.md. */
+ttc_status ttc_read_hkl(const char* path, const char* name, void* h_out, size_t cap_bytes, int64_t* shape, int32_t* ndim,
+                        int32_t* elem_size, int32_t* type_class, int32_t* is_signed);
+const char* ttc_read_hkl_error(void);
 
 /* ---- output file (host-side) -------------------------------
  * == write_tif (src/downloading/io.py:229-263) without rasterio: h_raster [rows, cols] uint8 host memory, already in the

@@ -24,7 +24,7 @@ EXPORTS = [
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
-    "ttc_predict_tile",
+    "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -124,7 +124,7 @@ def load():
     lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == missing export
-        if name not in ("ttc_version", "ttc_destroy", "ttc_last_error", "ttc_device_bytes"):
+        if name not in ("ttc_version", "ttc_destroy", "ttc_last_error", "ttc_device_bytes", "ttc_read_hkl_error"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -140,6 +140,28 @@ def write_geotiff_u8(path, raster, west, south, east, north):
     if st != 0:
         raise RuntimeError(f"ttc_write_geotiff_u8: status {st} ({path})")
     return str(path)
+
+
+def read_hkl(path, name=None):
+    """ttc_read_hkl: the numeric array of a hickle file (hkl.load for the raw folder's arrays, job.py:684-714) -> numpy array.
+    Host-side, no GPU needed."""
+    lib = load()
+    lib.ttc_read_hkl.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.ttc_read_hkl_error.restype = C.c_char_p
+    shape = (C.c_int64 * 8)()
+    nd, es, tc, sg = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    nm = name.encode() if name else None
+
+    def call(buf, cap):
+        st = lib.ttc_read_hkl(str(path).encode(), nm, buf, cap, shape, C.byref(nd), C.byref(es), C.byref(tc), C.byref(sg))
+        if st != 0:
+            raise RuntimeError(f"ttc_read_hkl: status {st}: {lib.ttc_read_hkl_error().decode()}")
+    call(None, 0)
+    kind = "f" if tc.value == 1 else ("i" if sg.value else "u")
+    out = np.empty(tuple(shape[i] for i in range(nd.value)), dtype=np.dtype(f"<{kind}{es.value}"))
+    call(out.ctypes.data_as(C.c_void_p), out.nbytes)
+    return out
 
 
 def _torch():

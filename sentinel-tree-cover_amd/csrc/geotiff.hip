@@ -108,10 +108,10 @@ ttc_status ttc_write_geotiff_u8(const char* path, const uint8_t* h_raster, int32
     for (const Entry& e : ifd) { append(body, e.tag); append(body, e.type); append(body, e.count); append(body, e.value); }
     append(body, (uint32_t)0);
     FILE* f = std::fopen(path, "wb");
-    if (!f) return TTC_ERR_ARG;
+    if (!f) return TTC_ERR_IO;
     const uint8_t hdr[4] = {'I', 'I', 42, 0};
     bool ok = std::fwrite(hdr, 1, 4, f) == 4 && std::fwrite(&ifd_off, 4, 1, f) == 1 &&
               std::fwrite(body.data(), 1, body.size(), f) == body.size();
     ok = (std::fclose(f) == 0) && ok;
-    return ok ? TTC_OK : TTC_ERR_ARG;
+    return ok ? TTC_OK : TTC_ERR_IO;
 }

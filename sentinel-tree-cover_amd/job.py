@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib, temporal, weights as _weights
@@ -318,6 +320,22 @@ def adjust_shape(arr, width, height):
                 sl = slice(int(np.floor(amt / 2)), -int(np.ceil(amt / 2)))
             arr = arr[:, sl] if ax == 1 else arr[:, :, sl]
     return arr.squeeze()
+
+
+def load_raw_tile(x, y, local_path):
+    """The file loads at the top of process_tile (job.py:669-714): the arrays of `{local_path}{x}/{y}/raw/` as the `raw` dict
+    that process_tile (below) takes.  hkl.load is replaced by the library's own HDF5 reader (ttc_read_hkl, host code);
+    the Sen2Cor mask is returned at its stored 20 m resolution, the clean-up of :687-694 happens on the device."""
+    x, y = str(int(x)), str(int(y))
+    folder = f"{local_path}{x}/{y}/"
+    idx = f"{x}X{y}Y"
+    rd = _lib.read_hkl
+    clm_file = f"{folder}raw/clouds/cloudmask_{idx}.hkl"
+    return {"clouds": rd(f"{folder}raw/clouds/clouds_{idx}.hkl"),
+            "clm": rd(clm_file) if os.path.exists(clm_file) else None,
+            "s1": rd(f"{folder}raw/s1/{idx}.hkl"), "s2_10": rd(f"{folder}raw/s2_10/{idx}.hkl"),
+            "s2_20": rd(f"{folder}raw/s2_20/{idx}.hkl"), "dem": rd(f"{folder}raw/misc/dem_{idx}.hkl"),
+            "dates": rd(f"{folder}raw/misc/s2_dates_{idx}.hkl")}
 
 
 def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True, sampler="reference"):
