@@ -37,6 +37,7 @@ DTYPES = {
     "fp16": "fp16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
     "bf16": "bf16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
     "bf16x3": "f32 storage, split-bf16 (3 products) MFMA, f32 accumulate (round-1 engine)",
+    "fp32b": "f32 (fp32 MFMA, exact fp32 FMA chains, channel-blocked activations + LDS-DMA staging)",
 }
 
 
@@ -60,8 +61,8 @@ def roofline(precision, win, gates_ms, gates_n):
     """dominant kernel family = the ConvGRU gates convolution (49 -> 64, both directions, 36 windows per launch)"""
     flops = conv_gates_flops(win, 36)
     ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
-    if precision == "fp32":
-        return {"kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
+    if precision in ("fp32", "fp32b"):
+        return {"kernel": ("conv3x3_f32<CK=10,NCG=2,EPI_RAW>" if precision == "fp32" else "conv3x3_f32b<NCG=2,EPI_RAW>") + " (ConvGRU gates, 49->64, both directions)",
                 "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
                 "traffic": pmc_traffic(precision, win), "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops}
     # 16-bit engines: ALGORITHMIC flops against the dense 16-bit MFMA peak; the three split products and the K padding

@@ -65,7 +65,7 @@ __global__ void k_sr_gather(const float* __restrict__ tile, int X, int Y, SRWin 
 }
 
 // 16-bit engine: the same gather, written channel-blocked (10 bands -> 2 blocks, 6 zero pad channels) as hi / lo pairs
-template <bool BF>
+template <int BF>
 __global__ void k_sr_gather_b16(const float* __restrict__ tile, int X, int Y, SRWin sw, int ws, int cs, uint4* __restrict__ ohi,
                                 uint4* __restrict__ olo) {
     const int E = ws + 8, Ep = E + 2;
@@ -270,7 +270,7 @@ static ttc_status dsen2_core(ttc_ctx* c, const float* xin, const float* bil, int
 
 // the six convs on the 16-bit engine: xin blocked [n][2][PP] hi / lo (reflect-padded), intermediates blocked [n][4][PP];
 // conv epilogues write the next conv's padded input directly (bias / ReLU / 0.1 x residual fused, reflect rim included)
-template <bool BF>
+template <int BF>
 static ttc_status dsen2_core_h16(ttc_ctx* c, const B16& xin, const float* bil, int n, int H, int W, float* out, hipStream_t s) {
     const int Hp = H + 2, Wp = W + 2;
     const long PP = (long)Hp * Wp, P = (long)H * W;
@@ -332,10 +332,13 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
         B16 x16{static_cast<uint4*>(c->scratch_buf("ds16_inh", ub)), static_cast<uint4*>(c->scratch_buf("ds16_inl", ub))};
         if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
         const dim3 g16((Hp * Wp + 255) / 256, n);
-        if (c->bf()) hipLaunchKernelGGL((k_planar_to_b16<true>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
-        else hipLaunchKernelGGL((k_planar_to_b16<false>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
+        const int m = c->blk_mode();
+        if (m == 2) hipLaunchKernelGGL((k_planar_to_b16<2>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
+        else if (m == 1) hipLaunchKernelGGL((k_planar_to_b16<1>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
+        else hipLaunchKernelGGL((k_planar_to_b16<0>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
         TTC_HIP(c, hipGetLastError());
-        TTC_CHECK(c->bf() ? dsen2_core_h16<true>(c, x16, bil, n, H, W, res, s) : dsen2_core_h16<false>(c, x16, bil, n, H, W, res, s));
+        TTC_CHECK(m == 2 ? dsen2_core_h16<2>(c, x16, bil, n, H, W, res, s)
+                         : (m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, H, W, res, s) : dsen2_core_h16<0>(c, x16, bil, n, H, W, res, s)));
     } else {
         TTC_CHECK(dsen2_core(c, xin, bil, n, H, W, res, s));
     }
@@ -391,11 +394,15 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
             if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
             { KTimer kt(c, "dsen2_gather", s);
               const dim3 gg((Ep * Ep + 255) / 256, sw.n, T);
-              if (c->bf()) hipLaunchKernelGGL((k_sr_gather_b16<true>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
-              else hipLaunchKernelGGL((k_sr_gather_b16<false>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
+              const int m = c->blk_mode();
+              if (m == 2) hipLaunchKernelGGL((k_sr_gather_b16<2>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
+              else if (m == 1) hipLaunchKernelGGL((k_sr_gather_b16<1>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
+              else hipLaunchKernelGGL((k_sr_gather_b16<0>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
               hipLaunchKernelGGL(k_sr_bil_tile, dim3((E * E + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, bil);
               TTC_HIP(c, hipGetLastError()); }
-            TTC_CHECK(c->bf() ? dsen2_core_h16<true>(c, x16, bil, n, E, E, res, s) : dsen2_core_h16<false>(c, x16, bil, n, E, E, res, s));
+            { const int m = c->blk_mode();
+              TTC_CHECK(m == 2 ? dsen2_core_h16<2>(c, x16, bil, n, E, E, res, s)
+                               : (m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, E, E, res, s) : dsen2_core_h16<0>(c, x16, bil, n, E, E, res, s))); }
         } else {
             float* xin = static_cast<float*>(c->scratch_buf("ds_in", sizeof(float) * (size_t)n * 10 * Ep * Ep));
             if (!xin) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");

@@ -427,7 +427,10 @@ __global__ void k_rows_scan(int* __restrict__ blk, int nblk, int* __restrict__ t
 __global__ void k_rows_fill(const float* __restrict__ w, const unsigned char* __restrict__ water, const float* __restrict__ tiles,
                             int npix, int t0, int nt, const DatePlan* __restrict__ plan, const int* __restrict__ blk,
                             int* __restrict__ rows, float* __restrict__ evi) {
-    if (plan) { plan += blockIdx.y; blk += (long)blockIdx.y * gridDim.x; rows += (long)blockIdx.y * 3 * npix; t0 = plan->t0; nt = plan->nt; }
+    if (plan) {
+        plan += blockIdx.y; blk += (long)blockIdx.y * gridDim.x; rows += (long)blockIdx.y * 3 * npix; t0 = plan->t0; nt = plan->nt;
+        if (evi) evi += (long)blockIdx.y * 3 * npix;
+    }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0, t = 0, p = 0;
     if (i < (long)nt * npix) { t = t0 + (int)(i / npix); p = (int)(i % npix); f = (w[(long)t * npix + p] == 0.f) && !water[p]; }
@@ -521,7 +524,7 @@ __global__ void k_gram_reduce(const double* __restrict__ partial, int nblk, doub
 struct Beta { double b[10][11]; int fitted; };
 __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restrict__ w, const float* __restrict__ mosaic,
                                 const float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date,
-                                float* __restrict__ snowp) {
+                                float* __restrict__ snowp, int T = 0) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -529,7 +532,14 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
     if (!(wd > 0.f)) return;                                   // tile * 1 + 0 * 0: unchanged
     float* tv = tiles + ((long)date * npix + p) * 10;
     const float* mv = mosaic + (long)p * 10;
-    const double sn = (double)snow[p];
+    float snf;
+    if (snow) snf = snow[p];
+    else {                                                       // mean of the cached per-date probabilities (CR.py:372)
+        snf = 0.f;
+        for (int t = 0; t < T; ++t) snf += snowp[(long)t * npix + p];
+        snf = snf / (float)T;
+    }
+    const double sn = (double)snf;
     const Beta& be = *bep;
     for (int c = 0; c < 10; ++c) {
         float pred = mv[c];
@@ -631,6 +641,235 @@ __global__ void k_row_weights_dev(const float* __restrict__ evi, const DatePlan*
         weight[i] = w;
     }
 }
+
+// ---- date-batched form of the per-date fit (device sampler) ------------------------------------------------------
+// A training row is a pixel with w_t == 0, and the blend only ever writes pixels with w_d > 0 of date d: the row
+// VALUES (targets, EVI, strata, weights) never change inside the date loop.  The only quantity that does is the mean
+// snow probability (CR.py:372), one of the 11 regressors.  So everything but the snow row / column of Z'Z is formed for
+// all dates in batched launches; a date then costs three launches: the snow products over its rows, the NNLS (which
+// first completes Z'Z), predict + blend.
+__global__ void k_sel_init_evi(SelState* __restrict__ st, const DatePlan* __restrict__ plans, int T, PctList pl) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= T * 12) return;
+    const long long n = plans[q / 12].nrows;
+    const int j = q % 12;
+    SelState ss; ss.prefix = 0; ss.mask = 0; ss.k = 0;
+    if (n > 0) {
+        const double pos = pl.pct[j >> 1] / 100.0 * (double)(n - 1);
+        const long long lo = (long long)floor(pos) + (j & 1);
+        ss.k = lo > n - 1 ? n - 1 : lo;
+    }
+    st[q] = ss;
+}
+// one radix-select pass of the 12 percentile problems of date blockIdx.y: the EVI list is read once for all 12
+__global__ __launch_bounds__(256) void k_evi_hist(const float* __restrict__ evi_all, const DatePlan* __restrict__ plans, int npix,
+                                                   const SelState* __restrict__ st, int shift, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[12 * 256];
+    __shared__ unsigned pf[12], mk[12];
+    __shared__ int same[12];                                   // first problem with the same prefix: they share one histogram
+    const int d = blockIdx.y;
+    for (int k = threadIdx.x; k < 12 * 256; k += blockDim.x) h[k] = 0;
+    if (threadIdx.x < 12) { pf[threadIdx.x] = st[d * 12 + threadIdx.x].prefix; mk[threadIdx.x] = st[d * 12 + threadIdx.x].mask; }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        int r = threadIdx.x;
+        for (int q = threadIdx.x - 1; q >= 0; --q) if (pf[q] == pf[threadIdx.x] && mk[q] == mk[threadIdx.x]) r = q;
+        same[threadIdx.x] = r;
+    }
+    __syncthreads();
+    const int n = plans[d].nrows;
+    const float* evi = evi_all + (long)d * 3 * npix;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned k = fkey(evi[i]);
+        const unsigned bin = (k >> shift) & 255u;
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+            if (same[q] == q && (k & mk[q]) == pf[q]) atomicAdd(&h[q * 256 + bin], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 12 * 256; k += blockDim.x) {
+        const unsigned v = h[same[k >> 8] * 256 + (k & 255)];
+        if (v) atomicAdd(&hist[(long)d * 12 * 256 + k], v);
+    }
+}
+__global__ void k_strata_thresholds_all(const SelState* __restrict__ st, const DatePlan* __restrict__ plans, int T, PctList pl,
+                                        StrataDev* __restrict__ sd) {
+    const int d = threadIdx.x;
+    if (d >= T) return;
+    const long long n = plans[d].nrows;
+    for (int k = 0; k < 6; ++k) {
+        const double pos = n > 0 ? pl.pct[k] / 100.0 * (double)(n - 1) : 0.0;
+        const double a = fkey_inv(st[d * 12 + 2 * k].prefix), b = fkey_inv(st[d * 12 + 2 * k + 1].prefix);
+        sd[d].b[k] = (float)(a + (b - a) * (pos - floor(pos)));
+    }
+    for (int k = 0; k < 5; ++k) sd[d].cnt[k] = 0;
+}
+__global__ void k_strata_count_all(const float* __restrict__ evi_all, const DatePlan* __restrict__ plans, int npix, StrataDev* __restrict__ sd) {
+    __shared__ int c[5];
+    const int d = blockIdx.y;
+    if (threadIdx.x < 5) c[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = plans[d].nrows;
+    const float* evi = evi_all + (long)d * 3 * npix;
+    int mine[5] = {0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int sidx = stratum_of(evi[i], sd[d].b);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) mine[k] += sidx == k;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int v = mine[k];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&c[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && c[threadIdx.x]) atomicAdd(&sd[d].cnt[threadIdx.x], c[threadIdx.x]);
+}
+__global__ void k_row_weights_all(const float* __restrict__ evi_all, const DatePlan* __restrict__ plans, int npix,
+                                  const StrataDev* __restrict__ sdv, float* __restrict__ weight_all) {
+    const int d = blockIdx.y;
+    const int n = plans[d].nrows;
+    const StrataDev* sd = sdv + d;
+    const float* evi = evi_all + (long)d * 3 * npix;
+    float* weight = weight_all + (long)d * 3 * npix;
+    const double n_i = (double)(min(90000, n) / 5);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float e = evi[i];
+        const int cn = sd->cnt[stratum_of(e, sd->b)];
+        float w = cn > 0 ? (float)fmin(1.0, n_i / (double)cn) : 0.f;
+        if (e < sd->b[0]) w += 10.f;
+        if (e >= sd->b[5]) w += 10.f;
+        weight[i] = w;
+    }
+}
+// Z'Z without the snow regressor for date blockIdx.y (columns 10 and 21 are left zero; k_gram_snow supplies them)
+__global__ __launch_bounds__(256) void k_gram_all(const float* __restrict__ tiles, const float* __restrict__ mosaic,
+                                                   const int* __restrict__ rows_all, const float* __restrict__ weight_all,
+                                                   const DatePlan* __restrict__ plans, int npix, double* __restrict__ partial) {
+    constexpr int R = 256;
+    __shared__ float zs[R][33];
+    __shared__ float ws[R];
+    const int d = blockIdx.y;
+    const int nsample = plans[d].nrows, t0 = plans[d].t0;
+    const int* rows = rows_all + (long)d * 3 * npix;
+    const float* weight = weight_all + (long)d * 3 * npix;
+    double acc[4] = {0, 0, 0, 0};
+    const int tid = threadIdx.x;
+    const int r0 = tid >> 3, c0 = (tid & 7) * 4;
+    for (int base = blockIdx.x * R; base < nsample; base += gridDim.x * R) {
+        __syncthreads();
+        {
+            const int s = base + tid;
+            float wgt = 0.f;
+            if (s < nsample) {
+                const int rr = rows[s];
+                const int t = t0 + rr / npix, p = rr % npix;
+                const float* x = mosaic + (long)p * 10;
+                const float* y = tiles + ((long)t * npix + p) * 10;
+#pragma unroll
+                for (int c = 0; c < 10; ++c) { const float xv = x[c]; zs[tid][c] = fminf(fmaxf(xv, 0.005f), 1.0f); zs[tid][11 + c] = xv; zs[tid][22 + c] = y[c]; }
+                zs[tid][10] = 0.f; zs[tid][21] = 0.f;
+                wgt = weight[s];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) zs[tid][c] = 0.f;
+            }
+            ws[tid] = wgt;
+        }
+        __syncthreads();
+        const int n = min(R, nsample - base);
+        for (int s = 0; s < n; ++s) {
+            const double zr = (double)zs[s][r0] * (double)ws[s];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += zr * (double)zs[s][c0 + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) partial[((long)d * gridDim.x + blockIdx.x) * 1024 + r0 * 32 + c0 + k] = acc[k];
+}
+__global__ void k_gram_reduce_all(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
+    __shared__ double red[16][17];
+    const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
+    partial += (long)blockIdx.y * nblk * 1024; out += (long)blockIdx.y * 1024;
+    double s = 0.0;
+    for (int b = part; b < nblk; b += 16) s += partial[(long)b * 1024 + i];
+    red[part][e] = s;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += red[k][e];
+        out[i] = t;
+    }
+}
+// snow products of ONE date over its rows: sv[i] = sum_rows w * z_i * snow (z_10 = z_21 = snow), snow = the mean of the
+// cached per-date probabilities as they stand now (same float sum, same order as k_snow_mean_cached)
+constexpr int kSnowBlocks = 512;
+__global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ tiles, const float* __restrict__ mosaic,
+                                                    const float* __restrict__ snowp, const int* __restrict__ rows,
+                                                    const float* __restrict__ weight, const DatePlan* __restrict__ plan, int T,
+                                                    int npix, double* __restrict__ partial /*[kSnowBlocks][32]*/,
+                                                    double* __restrict__ sv_out /*[32]*/, unsigned* __restrict__ ticket) {
+#pragma clang fp contract(off)
+    __shared__ double red[8][32];
+    __shared__ unsigned last;
+    const int nsample = plan->nrows, t0 = plan->t0;
+    double acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.0;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsample; s += gridDim.x * blockDim.x) {
+        const int rr = rows[s];
+        const int t = t0 + rr / npix, p = rr % npix;
+        float sn = 0.f;
+        for (int k = 0; k < T; ++k) sn += snowp[(long)k * npix + p];
+        sn = sn / (float)T;
+        const float* x = mosaic + (long)p * 10;
+        const float* y = tiles + ((long)t * npix + p) * 10;
+        const double ws = (double)weight[s] * (double)sn;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const float xv = x[c];
+            acc[c] += (double)fminf(fmaxf(xv, 0.005f), 1.0f) * ws;
+            acc[11 + c] += (double)xv * ws;
+            acc[22 + c] += (double)y[c] * ws;
+        }
+        acc[10] += (double)sn * ws;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        double v = acc[c];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        partial[blockIdx.x * 32 + c] = c == 21 ? ((red[0][10] + red[1][10]) + red[2][10]) + red[3][10]
+                                               : ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    }
+    // the workgroup that finishes last sums the partials in a fixed order (bit-reproducible) and re-arms the ticket
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    {
+        const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+        double t = 0.0;
+        for (int b = part; b < (int)gridDim.x; b += 8) t += __builtin_nontemporal_load(&partial[b * 32 + c]);
+        red[part][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        sv_out[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+}
 // Lawson-Hanson NNLS on the normal equations, ONE WAVE per band: lane r owns row r of the active system.  The
 // arithmetic per matrix element is the same as a serial active-set solver's (row operations of the Gauss-Jordan elimination
 // are independent per row); a single-lane version with fp64 arrays in scratch took 170-340 us per date, this one ~15 us.
@@ -641,8 +880,10 @@ __device__ __forceinline__ int wave_argmax_first(double v, bool eligible) {
     const unsigned long long b = __ballot(eligible && v == m);
     return b ? __ffsll((long long)b) - 1 : -1;
 }
-__global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan, Beta* __restrict__ be) {
+__global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan, Beta* __restrict__ be,
+                       const double* __restrict__ snow_partial = nullptr, int snow_blocks = 0) {
     __shared__ double G[11][11], g[11], A[11][12], x[11], sf[11];
+    __shared__ double sv[32];
     __shared__ int idx[11];
     const int band = blockIdx.x, lane = threadIdx.x;
     const int n = 11;
@@ -651,13 +892,23 @@ __global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan
         if (band == 0 && lane == 0) { be->fitted = 0; plan->fitted = 0; }
         return;
     }
+    if (snow_partial) {                                  // date-batched form: Z holds everything but the snow products
+        if (lane < 32) {
+            double t = 0.0;
+            for (int b = 0; b < snow_blocks; ++b) t += snow_partial[b * 32 + lane];       // fixed order: deterministic
+            sv[lane] = t;
+        }
+        __syncthreads();
+    }
     if (lane < n) {
         const int ci = (lane < band && lane < 10) ? lane : 11 + lane;            // CR.py:522 / :550
+        const bool si = ci == 10 || ci == 21;
         for (int j = 0; j < n; ++j) {
             const int cj = (j < band && j < 10) ? j : 11 + j;
-            G[lane][j] = Z[ci * 32 + cj];
+            const bool sj = cj == 10 || cj == 21;
+            G[lane][j] = !snow_partial ? Z[ci * 32 + cj] : (si ? sv[sj ? 10 : cj] : (sj ? sv[ci] : Z[ci * 32 + cj]));
         }
-        g[lane] = Z[ci * 32 + 22 + band];
+        g[lane] = (snow_partial && si) ? sv[22 + band] : Z[ci * 32 + 22 + band];
         x[lane] = 0.0;
     }
     __syncthreads();
@@ -1176,12 +1427,50 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, date_counts, npix, T, plans, remove_flags);
     hipLaunchKernelGGL(k_rows_count, dim3(nb3, T), b256, 0, s, d_interp, water2, npix, 0, 0, plans, blk);
     hipLaunchKernelGGL(k_rows_scan, dim3(T), dim3(1024), 0, s, blk, nb3, &plans->nrows, (int)(sizeof(DatePlan) / sizeof(int)));
-    hipLaunchKernelGGL(k_rows_fill, dim3(nb3, T), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plans, blk, rows_all, (float*)nullptr);
+    if (sampler) hipLaunchKernelGGL(k_rows_fill, dim3(nb3, T), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plans, blk, rows_all, (float*)nullptr);
     hipLaunchKernelGGL(k_snow_prob_all, dim3((unsigned)(((long)T * npix + 255) / 256)), b256, 0, s, d_tiles, T, npix, snowp);
     TTC_HIP(c, hipGetLastError());
+    if (!sampler) {
+        // device sampler: everything that does not depend on the blended stack for all dates at once (see k_gram_snow)
+        constexpr int kGramBlocks = 256;
+        float* evi_all = static_cast<float*>(c->scratch_buf("gf_evi_all", sizeof(float) * 3 * (size_t)npix * T));
+        float* weight_all = static_cast<float*>(c->scratch_buf("gf_weight_all", sizeof(float) * 3 * (size_t)npix * T));
+        double* gpart_all = static_cast<double*>(c->scratch_buf("gf_gram_all", sizeof(double) * 1024 * ((size_t)kGramBlocks * T + T) +
+                                                                                sizeof(double) * 32 * (kSnowBlocks + 1)));
+        char* ctl2 = static_cast<char*>(c->scratch_buf("gf_ctl_dates", sizeof(SelState) * 12 * kMaxT + sizeof(StrataDev) * kMaxT +
+                                                                       sizeof(unsigned) * (12 * 256 * kMaxT + 16)));
+        if (!evi_all || !weight_all || !gpart_all || !ctl2) return c->fail(TTC_ERR_NOMEM, "gap-fill scratch (date batch)");
+        double* Z0 = gpart_all + 1024L * kGramBlocks * T;              // [T][32][32]
+        double* spart = Z0 + 1024L * T;                                // [kSnowBlocks][32], then the reduced [32]
+        SelState* st_all = reinterpret_cast<SelState*>(ctl2);
+        StrataDev* sd_all = reinterpret_cast<StrataDev*>(st_all + 12 * kMaxT);
+        unsigned* hist_all = reinterpret_cast<unsigned*>(sd_all + kMaxT);
+        unsigned* ticket = hist_all + 12 * 256 * kMaxT;
+        TTC_HIP(c, hipMemsetAsync(hist_all, 0, sizeof(unsigned) * (12 * 256 * kMaxT + 16), s));
+        hipLaunchKernelGGL(k_rows_fill, dim3(nb3, T), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plans, blk, rows_all, evi_all);
+        hipLaunchKernelGGL(k_sel_init_evi, dim3((T * 12 + 63) / 64), dim3(64), 0, s, st_all, plans, T, pl6);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hipLaunchKernelGGL(k_evi_hist, dim3(64, T), b256, 0, s, evi_all, plans, npix, st_all, shift, hist_all);
+            hipLaunchKernelGGL(k_sel_pick, dim3(T * 12), dim3(64), 0, s, st_all, shift, hist_all);
+        }
+        hipLaunchKernelGGL(k_strata_thresholds_all, dim3(1), dim3(64), 0, s, st_all, plans, T, pl6, sd_all);
+        hipLaunchKernelGGL(k_strata_count_all, dim3(64, T), b256, 0, s, evi_all, plans, npix, sd_all);
+        hipLaunchKernelGGL(k_row_weights_all, dim3(128, T), b256, 0, s, evi_all, plans, npix, sd_all, weight_all);
+        hipLaunchKernelGGL(k_gram_all, dim3(kGramBlocks, T), b256, 0, s, d_tiles, mosaic, rows_all, weight_all, plans, npix, gpart_all);
+        hipLaunchKernelGGL(k_gram_reduce_all, dim3(64, T), b256, 0, s, gpart_all, kGramBlocks, Z0);
+        TTC_HIP(c, hipGetLastError());
+        for (int date = 0; date < T; ++date) {
+            DatePlan* plan = plans + date;
+            hipLaunchKernelGGL(k_gram_snow, dim3(kSnowBlocks), b256, 0, s, d_tiles, mosaic, snowp, rows_all + (size_t)date * 3 * npix,
+                               weight_all + (size_t)date * 3 * npix, plan, T, npix, spart, spart + 32 * kSnowBlocks, ticket);
+            hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Z0 + 1024L * date, plan, d_beta, spart + 32 * kSnowBlocks, 1);
+            hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, (const float*)nullptr, d_beta, npix, date, snowp, T);
+        }
+        TTC_HIP(c, hipGetLastError());
+    }
     std::vector<float> h_evi;
     std::vector<int64_t> h_idx;
-    for (int date = 0; date < T; ++date) {
+    for (int date = 0; sampler && date < T; ++date) {
         DatePlan* plan = plans + date;
         const int* rows = rows_all + (size_t)date * 3 * npix;
         hipLaunchKernelGGL(k_snow_mean_cached, grid, b256, 0, s, snowp, T, npix, snow);       // CR.py:372 (tiles mutate per date)

@@ -8,8 +8,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-template <bool BF> struct Elem;
-template <> struct Elem<false> {
+// BF: 0 = fp16 pair, 1 = bf16 pair, 2 = fp32 blocked (precision 4: the `hi` tensor holds channels 0..3 of a block as fp32,
+// the `lo` tensor channels 4..7 -- same tensors, same indexing, no splitting; see conv3x3_f32b in conv3x3_h16.hip)
+template <int BF> struct Elem;
+template <> struct Elem<0> {
     using v8 = f16x8;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float a, float b, unsigned& lo2) {
@@ -23,7 +25,7 @@ template <> struct Elem<false> {
         const f16x2 h = __builtin_bit_cast(f16x2, u); a = (float)h[0]; b = (float)h[1];
     }
 };
-template <> struct Elem<true> {
+template <> struct Elem<1> {
     using v8 = bf16x8;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float a, float b, unsigned& lo2) {
@@ -39,17 +41,29 @@ template <> struct Elem<true> {
 
 
 // one channel block (8 channels) of one position: x = hi + lo
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void b16_store8(uint4* hi, uint4* lo, long u, const float (&v)[8]) {
+    if constexpr (BF == 2) {
+        hi[u] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+        lo[u] = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+        return;
+    } else {
     using E = Elem<BF>;
     uint4 h, l;
     h.x = E::pack2(v[0], v[1], l.x); h.y = E::pack2(v[2], v[3], l.y);
     h.z = E::pack2(v[4], v[5], l.z); h.w = E::pack2(v[6], v[7], l.w);
     hi[u] = h;
     if (lo) lo[u] = l;
+    }
 }
-template <bool BF>
+template <int BF>
 __device__ __forceinline__ void b16_load8(const uint4* hi, const uint4* lo, long u, float (&v)[8]) {
+    if constexpr (BF == 2) {
+        const uint4 h = hi[u], l = lo[u];
+        v[0] = __uint_as_float(h.x); v[1] = __uint_as_float(h.y); v[2] = __uint_as_float(h.z); v[3] = __uint_as_float(h.w);
+        v[4] = __uint_as_float(l.x); v[5] = __uint_as_float(l.y); v[6] = __uint_as_float(l.z); v[7] = __uint_as_float(l.w);
+        return;
+    } else {
     using E = Elem<BF>;
     const uint4 h = hi[u];
     E::unpack2(h.x, v[0], v[1]); E::unpack2(h.y, v[2], v[3]); E::unpack2(h.z, v[4], v[5]); E::unpack2(h.w, v[6], v[7]);
@@ -60,10 +74,11 @@ __device__ __forceinline__ void b16_load8(const uint4* hi, const uint4* lo, long
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += t[k];
     }
+    }
 }
 
 // fp32 planar images [img][C][PP] -> channel-blocked hi / lo [img][C8][PP][8] (pad channels = 0)
-template <bool BF>
+template <int BF>
 __global__ void k_planar_to_b16(const float* __restrict__ src, int C, long PP, int C8, uint4* __restrict__ hi, uint4* __restrict__ lo) {
     const long img = blockIdx.y;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;

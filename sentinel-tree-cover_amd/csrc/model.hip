@@ -267,7 +267,7 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
 // 16-bit engine (cfg.precision >= 2, conv3x3_h16.hip): the same elementwise stages, reading the fp32 raw conv outputs and
 // writing the NEXT conv's input channel-blocked as hi + lo 16-bit K vectors ([n][C8][plane][8]).  The ConvGRU state lives
 // only as such a pair (fp16: 22 mantissa bits).
-template <bool BF>
+template <int BF>
 __global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm, B16 hcur, B16 rh,
                                  int H, int W, int N) {
     const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
@@ -294,7 +294,7 @@ __global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __re
     }
 }
 
-template <bool BF>
+template <int BF>
 __global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
                                  const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
                                  B16 hcur, B16 hnext, B16 gru_out, int H, int W, int N, float z) {
@@ -338,7 +338,7 @@ __global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __re
     }
 }
 
-template <bool BF, int MODE>
+template <int BF, int MODE>
 __global__ void k_block_finalize_b16(FinArgs a) {
     extern __shared__ float sm[];            // scale[C] shift[C] ssew[C]
     const int C = a.C, n = blockIdx.y;
@@ -395,7 +395,7 @@ __global__ void k_block_finalize_b16(FinArgs a) {
     }
 }
 
-template <bool BF>
+template <int BF>
 __global__ void k_tap_early_b16(B16 gru_out, int H, int W, int N, int tr, float* __restrict__ out) {
     const int Wp = W + 2;
     const long PP = (long)(H + 2) * Wp, total = (long)N * H * W * 8;
@@ -648,7 +648,7 @@ static ttc_status finalize(ttc_ctx* c, int mode, const FinArgs& a, int n, hipStr
 
 // ---------------------------------------------------------------------------------------
 // forward on the 16-bit engine: same graph, same launch order; every conv input is a channel-blocked hi / lo pair
-template <bool BF>
+template <int BF>
 static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
@@ -781,7 +781,10 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
 ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     if (!c->have_model) return c->fail(TTC_ERR_STATE, "ttc_load_weights has not been called");
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
-    if (c->half()) return c->bf() ? forward_h16<true>(c, n, d_out, s) : forward_h16<false>(c, n, d_out, s);
+    if (c->half()) {
+        const int m = c->blk_mode();
+        return m == 2 ? forward_h16<2>(c, n, d_out, s) : (m == 1 ? forward_h16<1>(c, n, d_out, s) : forward_h16<0>(c, n, d_out, s));
+    }
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
     const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
@@ -896,8 +899,11 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
     KTimer kt(c, "taps", s);
     if (d_early && c->half()) {
         const long total = (long)n * g.y.n * g.x.n * 8;
-        if (c->bf()) hipLaunchKernelGGL((k_tap_early_b16<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
-        else hipLaunchKernelGGL((k_tap_early_b16<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
+        const int m = c->blk_mode();
+        const dim3 gte((unsigned)((total + 255) / 256));
+        if (m == 2) hipLaunchKernelGGL((k_tap_early_b16<2>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
+        else if (m == 1) hipLaunchKernelGGL((k_tap_early_b16<1>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
+        else hipLaunchKernelGGL((k_tap_early_b16<0>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
     } else if (d_early) {
         const long total = (long)n * g.y.n * g.x.n * 64;
         hipLaunchKernelGGL(k_tap_early, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->gru_out, g.y.n, g.x.n, n,

@@ -146,7 +146,9 @@ hipError_t conv_launch_b3(const ConvArgs& a, const PackedConv& pw, int epi, int 
 // C0: real channels of the first input segment (its blocks are padded to a multiple of 8 on their own); bf: bf16 elements
 long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, bool bf, std::vector<uint16_t>& out,
                    int* nchunk);
-hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, bool bf, int epi, int out_kind, int n, hipStream_t s);
+hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s);   // mode: ttc_ctx::blk_mode()
+// fp32 blocked engine (precision 4): LDS images [set][cout block][chunk][tap][half][cout][4 ch] fp32; returns 16-byte units per set
+long conv_pack_f32b(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, std::vector<float>& out, int* nchunk);
 uint16_t h16_from_float(float f, bool bf);
 float h16_to_float(uint16_t h, bool bf);
 struct ttc_ctx;
@@ -204,8 +206,8 @@ struct ttc_ctx {
     ttc_status fail(ttc_status s, const std::string& m) { err = m; return s; }
     float* alloc_f(size_t n, const char* name = nullptr);
     bool alloc_b16(B16& b, size_t units);       // hi + lo tensors of `units` 16-byte K vectors each
-    bool half() const { return cfg.precision >= 2; }      // 16-bit conv engine selected
-    bool bf() const { return cfg.precision == 3; }
+    bool half() const { return cfg.precision >= 2; }      // channel-blocked conv engine selected (16-bit pairs or fp32 blocked)
+    int blk_mode() const { return cfg.precision == 3 ? 1 : (cfg.precision == 4 ? 2 : 0); }   // Elem<> mode: fp16 / bf16 / f32 blocked
     void* scratch_buf(const std::string& key, size_t bytes);
     void* pinned_buf(const std::string& key, size_t bytes);
 };

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void k_loop(float* out, int iters) {
 }
 
 int main() {
-    float* out; (void)hipMalloc(&out, 512 * 256 * 4);
+    float* out; (void)hipMalloc(&out, 8192 * 256 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 400;
     const size_t lds = 60000;
@@ -69,5 +69,31 @@ int main() {
             printf("mode %d (%s): %.3f ms -> %.1f TFLOP/s = %.1f %% of 157.3\n", mode, mode ? "ds_read_b128, 4 k-steps per read" : "ds_read_b32 per operand",
                    ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100);
         }
+    // many short workgroups (the conv's real shape: 4248 tiles of 7 chunks) versus few long ones, same total MFMA count
+    for (int wgs : {512, 1024, 4248, 4608}) {
+        const int it2 = 7;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(k_loop<1>, dim3(wgs), dim3(256), lds, 0, out, it2);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            const double flop = 2.0 * 32 * 32 * 2 * 288.0 * it2 * wgs * 4;
+            printf("b128 loop, %d workgroups x %d iterations: %.3f ms -> %.1f %% of 157.3\n", wgs, it2, ms, flop / ms / 1e9 / 157.3 * 100);
+        }
+    }
+    // residency versus the dynamic LDS request: where does the second workgroup per CU stop fitting?
+    for (size_t l2 : {(size_t)60000, (size_t)65536, (size_t)70000, (size_t)75776, (size_t)78000, (size_t)80000, (size_t)81920, (size_t)90000}) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_loop<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_loop<1>, 256, l2);
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(k_loop<1>, dim3(512), dim3(256), l2, 0, out, 100);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            const double flop = 2.0 * 32 * 32 * 2 * 288.0 * 100 * 512 * 4;
+            if (rep) printf("lds %zu B (occupancy API %d): %.3f ms -> %.1f %% of 157.3\n", l2, nb, ms, flop / ms / 1e9 / 157.3 * 100);
+        }
+    }
     return 0;
 }
