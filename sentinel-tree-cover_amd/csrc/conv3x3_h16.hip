@@ -163,17 +163,20 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
     }
 
     if (EPI <= EPI_SWISH && c.stats) {        // same deterministic GroupNorm partials as conv_common.h
+        float red[NCG * 8];
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[(g * 4 + k) * 2] = ssum[g][k]; red[(g * 4 + k) * 2 + 1] = ssq[g][k]; }
+        half_wave_sums(red);
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float s = ssum[g][k], s2 = ssq[g][k];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
                 const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
-                if (lo == 0 && quad * 4 < c.Cout) {
+                if (lo == 31 && quad * 4 < c.Cout) {
                     float* dst = c.stats + (((long)n * (c.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
-                    dst[0] = s; dst[1] = s2;
+                    dst[0] = red[(g * 4 + k) * 2]; dst[1] = red[(g * 4 + k) * 2 + 1];
                 }
             }
     }
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     };
 
     // TERMS == 3 variants: `step(kb)` runs after the MFMAs of K block kb (straight-line copy issue, see issue_in / issue_w)
+    // (fetching operands TWO K blocks ahead -- three register stages, 236 VGPRs -- measured no faster: 0.42 vs 0.40-0.41 ms)
     auto mfma_chunk_s = [&](int in_unit, int w_unit, auto&& step) {
         v8 av[2][NCG], bv[2][kQG];
         load_ab(0, in_unit, w_unit, av[0], bv[0]);
@@ -420,6 +424,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
         }
     } else {
         // LDS: HI[0] HI[1] LO W[0] W[1], W = [hi plane | lo plane]
+        // (the same plan staged through VGPRs -- global_load_dwordx4 + ds_write_b128, 36 more registers -- measured 0.425 ms for
+        // the gates launch, identical to the LDS-DMA form: the copy method is not what bounds this loop)
         const int LOU = 2 * INU, WU0 = 3 * INU;
         const int cntA = cnt_in + ((2 * WPIECES + 3) >> 2), cntB = cnt_in;
         const int perA = (cntA + kKB - 1) / kKB, perB = (cntB + kKB - 1) / kKB;
@@ -521,13 +527,31 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
         if (hipMalloc(&d, bytes) == hipSuccess) {
             (void)hipMemset(d, 0, bytes);
             H16Args b = a; b.trace = d;
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            float ms = 0.f;
             for (int rep = 0; rep < 2; ++rep) {          // second pass = warm
+                (void)hipEventRecord(e0, s);
                 hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds_req, s, b, nblk_q, pw.ncb);
+                (void)hipEventRecord(e1, s);
                 (void)hipStreamSynchronize(s);
+                (void)hipEventElapsedTime(&ms, e0, e1);
             }
             std::vector<unsigned long long> h((size_t)grid.x * 64);
             (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
             (void)hipFree(d);
+            {   // shader clock under this kernel's load: s_memtime span of ONE CU (counters of different CUs are not aligned) / event time
+                const unsigned long long id0 = (h[5] & 0xff00u) | ((h[5] >> 12) & 0xfu) << 16 | (h[6] << 24);
+                unsigned long long lo = ~0ull, hi = 0;
+                for (unsigned w = 0; w < grid.x; ++w) {
+                    const unsigned long long* t = &h[(size_t)w * 64];
+                    const unsigned long long id = (t[5] & 0xff00u) | ((t[5] >> 12) & 0xfu) << 16 | (t[6] << 24);
+                    if (id != id0 || !t[0]) continue;
+                    lo = std::min(lo, t[0]); hi = std::max(hi, t[4]);
+                }
+                fprintf(stderr, "[h16] traced launch: %.3f ms by events, one CU busy for %llu s_memtime ticks -> >= %.2f GHz shader clock\n", ms, hi - lo,
+                        (double)(hi - lo) / (ms * 1e-3) / 1e9);
+            }
             if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
             fprintf(stderr, "[h16] trace of terms %d ncg %d epi %d grid %u -> %s\n", TERMS, NCG, EPI, grid.x, trace_path);
         }

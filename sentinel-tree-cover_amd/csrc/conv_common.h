@@ -29,6 +29,28 @@ __device__ __forceinline__ void tile_index(int nblk_q, int ncb, int& bq, int& cb
     cb = rest % ncb; n = rest / ncb;
 }
 
+// Sum over the 32 lanes of each half-wave with DPP row shifts (VALU, no LDS round trips): afterwards lane 31 holds the sum of
+// lanes 0..31 and lane 63 the sum of lanes 32..63, for every one of the N values (the N chains interleave, so the DPP wait
+// states are filled).  The ds_bpermute butterfly this replaces (5 dependent LDS round trips per value, 80 per tile) took
+// 12 k cycles of a 90 k-cycle tile of the 16-bit engine.  Fixed association order: bit-reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ void half_wave_sums(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shift<0x111, 0xf>(v[i]);          // row_shr:1  (rows of 16 lanes, out-of-row sources read 0)
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shift<0x112, 0xf>(v[i]);          // row_shr:2
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shift<0x114, 0xf>(v[i]);          // row_shr:4
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shift<0x118, 0xf>(v[i]);          // row_shr:8  -> lane 15 of each row = row total
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_shift<0x142, 0xa>(v[i]);          // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63
+}
+
 // fused epilogue: EPI op, output store into the consumer's (padded) plane, deterministic GroupNorm partial sums.
 template <int NCG, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[NCG][kQG], int n, int cb, int bq,
@@ -142,17 +164,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
         // reduce over the 32 pixel-lanes of each half-wave; one partial per WAVE (no LDS, no barrier: the epilogue of one
         // wave group may run while another group of the same workgroup is still in its MFMA phase).
         // stats: [n][Cout/4][nblk_q * kWaves][2], reduced in double by k_gn_finalize -> deterministic.
+        float red[NCG * 8];
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[(g * 4 + k) * 2] = ssum[g][k]; red[(g * 4 + k) * 2 + 1] = ssq[g][k]; }
+        half_wave_sums(red);
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float s = ssum[g][k], s2 = ssq[g][k];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
                 const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
-                if (lo == 0 && quad * 4 < a.Cout) {
+                if (lo == 31 && quad * 4 < a.Cout) {
                     float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
-                    dst[0] = s; dst[1] = s2;
+                    dst[0] = red[(g * 4 + k) * 2]; dst[1] = red[(g * 4 + k) * 2 + 1];
                 }
             }
     }
@@ -212,18 +237,23 @@ __device__ __forceinline__ void conv_epilogue_flat(const ConvArgs& a, f32x16 (&a
                 if (valid) { ssum[g][r >> 2] += v; ssq[g][r >> 2] += v * v; }
             }
     }
+    if (tq) tq[6] = __builtin_amdgcn_s_memtime();
     if (a.stats) {
+        float red[NCG * 8];
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[(g * 4 + k) * 2] = ssum[g][k]; red[(g * 4 + k) * 2 + 1] = ssq[g][k]; }
+        half_wave_sums(red);
+        if (tq) tq[7] = __builtin_amdgcn_s_memtime();
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float s = ssum[g][k], s2 = ssq[g][k];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
                 const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
-                if (lo == 0 && quad * 4 < a.Cout) {
+                if (lo == 31 && quad * 4 < a.Cout) {
                     float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
-                    dst[0] = s; dst[1] = s2;
+                    dst[0] = red[(g * 4 + k) * 2]; dst[1] = red[(g * 4 + k) * 2 + 1];
                 }
             }
     }

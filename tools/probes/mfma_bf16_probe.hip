@@ -57,5 +57,17 @@ int main() {
         const double flop = 2.0 * 32 * 32 * 16 * 8.0 * iters * (256 * 2 * 4);
         printf("32x32x16 bf16: %.3f ms -> %.1f TFLOP/s (8 indep acc, 2 waves/SIMD)\n", ms, flop / ms / 1e9);
     }
+    // issue rate versus resident waves per SIMD (launch_bounds 256: 1 workgroup = 1 wave on each SIMD of a CU)
+    for (int wgs_per_cu : {1, 2, 3, 4}) {
+        const int it2 = 20000 * 2 / wgs_per_cu;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_rate<8>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, out, it2);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double flop = 2.0 * 32 * 32 * 16 * 8.0 * it2 * (256.0 * wgs_per_cu * 4);
+            if (rep) printf("32x32x16 bf16, %d wave(s) per SIMD: %.3f ms -> %.1f TFLOP/s\n", wgs_per_cu, ms, flop / ms / 1e9);
+        }
+    }
     return 0;
 }
