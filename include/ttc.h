@@ -56,7 +56,8 @@ typedef struct {
                             * engine); 2 = fp16 / 3 = bf16 operands on the 16-bit engine: activations that feed a conv are
                             * stored as hi + lo 16-bit pairs, each layer multiplies 3 split products (~fp32 accuracy for
                             * fp16 pairs) or 1 (plain 16-bit operands) per `one_term_layers`; accumulation, GroupNorm
-                            * statistics and every non-conv operation stay fp32                                        */
+                            * statistics and every non-conv operation stay fp32; 4 = exact fp32 MFMA like 0, on the same
+                            * channel-blocked activation layout as 2 / 3 with fp32 payload (LDS-DMA staging)            */
     int32_t win_rows;      /* H: window rows for the non-square border graph of
                             * src/resegment_tiles_wide.py:478 ([L+1, SIZE_Y+14, SIZE+14, 17] = 220 x 684);
                             * 0 = square (win_in).  The per-tile core needs square windows. */
