@@ -203,7 +203,8 @@ def main():
     if args.preprocess_only:
         flags |= 2 | 4
 
-    streams = [torch.cuda.Stream(device=local) for _ in range(args.inflight)]
+    prio = os.environ.get("TTC_BENCH_PRIO")        # probe: "1" = slot 0 on a high-priority stream, the others default
+    streams = [torch.cuda.Stream(device=local, priority=(-1 if (prio and i == 0) else 0)) for i in range(args.inflight)]
     side = torch.cuda.Stream(device=local)
     B = max(1, min(args.gather_batch, args.inflight * max(1, args.steps)))
     B -= B % args.inflight if B > args.inflight else 0
@@ -237,9 +238,12 @@ def main():
             r, p = state["ring"], state["pos"]
             with torch.cuda.stream(st):
                 try:
+                    t_host = time.perf_counter()
                     sess.ctx.predict_tile_raw(tile["s2_10"], tile["s2_20"], tile["s1"], tile["dem"], tile["mask"], tile["dates"],
                                               job.min_all, job.max_all, size, dem_m=tile["dem_m"], flags=flags,
                                               out=None if args.preprocess_only else rings[r][p], status=status[r, p])
+                    state["host_s"] = state.get("host_s", 0.0) + time.perf_counter() - t_host
+                    state["host_n"] = state.get("host_n", 0) + 1
                 except RuntimeError as e:        # a failed tile must not poison the batch: record it and go on
                     state["failed"] += 1
                     print(f"[bench] rank {rank}: tile {state['tile'] - 1} failed: {e}", file=sys.stderr)
@@ -271,6 +275,9 @@ def main():
             flush(state["pos"])
         sync()
         dt = time.perf_counter() - t0
+        if os.environ.get("TTC_BENCH_HOSTTIME") and rank == 0 and state.get("host_n"):
+            print(f"[bench] host time inside ttc_predict_tile: {state['host_s'] / state['host_n'] * 1e3:.3f} ms per call over {state['host_n']} calls "
+                  f"(enqueue only, no synchronisation); wall {dt / (steps * len(sessions)) * 1e3:.3f} ms per tile", file=sys.stderr)
         gates_ms, gates_n = ctx.kernel_ms("conv_gates")
         ctx.timing(0)
         bad = int(((status[..., 0] != 0) | (status[..., 2] != 0)).sum().item())

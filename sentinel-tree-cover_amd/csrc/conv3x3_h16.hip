@@ -80,6 +80,17 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
     uint4* olo = a.o_lo ? a.o_lo + (long)n * a.o_stride_n : nullptr;
     const uint2* rhi = (EPI == EPI_BIAS_RES) ? reinterpret_cast<const uint2*>(a.r_hi + (long)n * a.o_stride_n) : nullptr;
     const uint2* rlo = (EPI == EPI_BIAS_RES) ? reinterpret_cast<const uint2*>(a.r_lo + (long)n * a.o_stride_n) : nullptr;
+    float bias[NCG][16];          // fetched once, unconditionally (see conv_epilogue)
+    if (EPI >= EPI_BIAS) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float bv = aux[co < c.Cout ? co : 0];
+                bias[g][r] = co < c.Cout ? bv : 0.f;
+            }
+    }
 
 #pragma unroll
     for (int j = 0; j < kQG; ++j) {
@@ -117,7 +128,7 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
                 const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float t = acc[g][j][r];
                 if (EPI >= EPI_BIAS) {
-                    if (co < c.Cout) t += aux[co];
+                    t += bias[g][r];
                     if (EPI == EPI_BIAS_RELU) t = fmaxf(t, 0.f);
                     if (EPI == EPI_BIAS_RES) t = v[r] + 0.1f * t;
                 }
@@ -519,7 +530,8 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
     if (lds_req != lds) { if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds_req); e != hipSuccess) return e; }
     static const char* trace_path = getenv("TTC_H16_TRACE");
     static int trace_left = trace_path ? 1 : 0;
-    if (trace_left > 0 && grid.x > 4000 && NCG == 2 && EPI == EPI_RAW) {               // probe aid: per-workgroup timestamps of one big launch
+    static const int trace_epi = [] { const char* e = getenv("TTC_H16_TRACE_EPI"); return e ? atoi(e) : (int)EPI_RAW; }();   // which layer kind to trace
+    if (trace_left > 0 && grid.x > 4000 && EPI == trace_epi && (NCG == 2 || trace_epi != EPI_RAW)) {   // probe aid: per-workgroup timestamps of one big launch
         trace_left--;
         unsigned long long* d = nullptr;
         const size_t bytes = (size_t)grid.x * 64 * sizeof(unsigned long long);
@@ -589,6 +601,15 @@ __device__ __forceinline__ void f32b_epilogue_blk(const H16Args& a, f32x16 (&acc
     // which is exactly the hi-tensor / lo-tensor split of the blocked fp32 layout: no cross-lane traffic
     uint4* obase = (hi ? a.o_lo : a.o_hi) + (long)n * a.o_stride_n;
     const uint4* rbase = (EPI == EPI_BIAS_RES) ? (hi ? a.r_lo : a.r_hi) + (long)n * a.o_stride_n : nullptr;
+    float bias[NCG][16];          // fetched once, unconditionally (see conv_epilogue)
+#pragma unroll
+    for (int g = 0; g < NCG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float bv = aux[co < c.Cout ? co : 0];
+            bias[g][r] = co < c.Cout ? bv : 0.f;
+        }
 #pragma unroll
     for (int j = 0; j < kQG; ++j) {
         const int q = q0 + (wave * kQG + j) * 32 + lo;
@@ -616,8 +637,7 @@ __device__ __forceinline__ void f32b_epilogue_blk(const H16Args& a, f32x16 (&acc
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int co = cb * BN + g * 32 + i + 8 * k + 4 * hi;
-                    float t = acc[g][j][4 * k + i];
-                    if (co < c.Cout) t += aux[co];
+                    float t = acc[g][j][4 * k + i] + bias[g][4 * k + i];
                     if (EPI == EPI_BIAS_RELU) t = fmaxf(t, 0.f);
                     if (EPI == EPI_BIAS_RES) t = res[i] + 0.1f * t;
                     v[i] = co < c.Cout ? t : 0.f;               // pad channels of the last block stay zero

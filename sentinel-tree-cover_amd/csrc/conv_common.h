@@ -69,6 +69,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
 
     float* outn = a.out + (long)n * a.out_stride_n;
     const float* resn = (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_TANH_ADD) ? a.res + (long)n * a.out_stride_n : nullptr;
+    // bias of this lane's 16 output channels per cout group, fetched ONCE and unconditionally (a load under `if (co < Cout)`
+    // inside the pixel loop cost a memory round trip each: 25 k of a 40 k-cycle tile in the 16-bit DSen2 layers)
+    float bias[NCG][16];
+    if (EPI >= EPI_BIAS) {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float bv = aux[co < a.Cout ? co : 0];
+                bias[g][r] = co < a.Cout ? bv : 0.f;
+            }
+    }
 
 #pragma unroll
     for (int j = 0; j < kQG; ++j) {
@@ -121,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[N
                 if (EPI == EPI_SSE) v *= gate;
                 if (EPI == EPI_SWISH) { v *= ratio; v = v * sigmoidf_(v); }
                 if (EPI >= EPI_BIAS) {
-                    if (co < a.Cout) v += aux[co];
+                    v += bias[g][r];
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                     if (EPI == EPI_BIAS_RES) v = rv[r] + 0.1f * v;
                     if (EPI == EPI_BIAS_TANH_ADD) v = rv[r] + tanhf(v);
@@ -246,16 +259,17 @@ __device__ __forceinline__ void conv_epilogue_flat(const ConvArgs& a, f32x16 (&a
             for (int k = 0; k < 4; ++k) { red[(g * 4 + k) * 2] = ssum[g][k]; red[(g * 4 + k) * 2 + 1] = ssq[g][k]; }
         half_wave_sums(red);
         if (tq) tq[7] = __builtin_amdgcn_s_memtime();
+        if (lo == 31) {            // one exec region for the two writer lanes; (sum, sumsq) leave as one 8-byte store
+            const long slots = (long)nblk_q * kWaves;
+            float2* base = reinterpret_cast<float2*>(a.stats) + (long)n * (a.Cout / 4) * slots + bq * kWaves + wave;
 #pragma unroll
-        for (int g = 0; g < NCG; ++g)
+            for (int g = 0; g < NCG; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
-                if (lo == 31 && quad * 4 < a.Cout) {
-                    float* dst = a.stats + (((long)n * (a.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
-                    dst[0] = red[(g * 4 + k) * 2]; dst[1] = red[(g * 4 + k) * 2 + 1];
+                for (int k = 0; k < 4; ++k) {
+                    const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
+                    if (quad * 4 < a.Cout) base[quad * slots] = make_float2(red[(g * 4 + k) * 2], red[(g * 4 + k) * 2 + 1]);
                 }
-            }
+        }
     }
     if (tq) tq[1] = __builtin_amdgcn_s_memtime();
     float* outn = a.out + (long)n * a.out_stride_n;
@@ -272,20 +286,36 @@ __device__ __forceinline__ void conv_epilogue_flat(const ConvArgs& a, f32x16 (&a
         if (tq && g == 0) tq[3] = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (tq && g == 0) tq[4] = __builtin_amdgcn_s_memtime();
+        // rows leave as 16-byte vectors; only the LAST tile of a plane can run past its end, so the per-element guards live in a
+        // separate (workgroup-uniform) path -- as per-store compares they cost 96 exec-masked branches per tile
+        static_assert(kFlatRow % 4 == 0, "rows of the LDS image start on 16-byte boundaries");
+        const float4* lds4 = reinterpret_cast<const float4*>(lds);
+        const bool whole = (long)q0 + kBQ <= qend;
+        if (whole) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = wave * 8 + i, co = cb * BN + g * 32 + row;
-            if (co >= a.Cout) continue;
-            float* orow = outn + (long)co * a.out_plane;
+            for (int i = 0; i < 8; ++i) {
+                const int row = wave * 8 + i, co = cb * BN + g * 32 + row;
+                if (co >= a.Cout) continue;
+                float4* orow4 = reinterpret_cast<float4*>(outn + (long)co * a.out_plane + q0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p4 = (h * 64 + lane) * 4;
-                const float4 v = *reinterpret_cast<const float4*>(lds + row * kFlatRow + p4);
-                if (q0 + p4 + 3 < qend) *reinterpret_cast<float4*>(orow + q0 + p4) = v;
-                else {                                         // ragged end of a plane whose size is not a multiple of 4
-                    if (q0 + p4 < qend) orow[q0 + p4] = v.x;
-                    if (q0 + p4 + 1 < qend) orow[q0 + p4 + 1] = v.y;
-                    if (q0 + p4 + 2 < qend) orow[q0 + p4 + 2] = v.z;
+                for (int h = 0; h < 2; ++h) orow4[h * 64 + lane] = lds4[row * (kFlatRow / 4) + h * 64 + lane];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wave * 8 + i, co = cb * BN + g * 32 + row;
+                if (co >= a.Cout) continue;
+                float* orow = outn + (long)co * a.out_plane;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p4 = (h * 64 + lane) * 4;
+                    const float4 v = lds4[row * (kFlatRow / 4) + h * 64 + lane];
+                    if (q0 + p4 + 3 < qend) *reinterpret_cast<float4*>(orow + q0 + p4) = v;
+                    else {                                         // ragged end of a plane whose size is not a multiple of 4
+                        if (q0 + p4 < qend) orow[q0 + p4] = v.x;
+                        if (q0 + p4 + 1 < qend) orow[q0 + p4 + 1] = v.y;
+                        if (q0 + p4 + 2 < qend) orow[q0 + p4 + 2] = v.z;
+                    }
                 }
             }
         }
