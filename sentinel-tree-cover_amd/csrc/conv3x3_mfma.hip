@@ -191,6 +191,135 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     return hipGetLastError();
 }
 
+
+// Narrow-cout form for DSen2's out_conv (32 -> 6, + bilinear + tanh): v_mfma_f32_16x16x4_f32 tiles (16 couts x 16 pixels x 4
+// channels per instruction, 8 passes) instead of 32x32x2 -- with 6 real output channels a 32-row tile spends 81 % of its
+// MFMAs on padding rows, a 16-row tile 62 %, at the same matrix-pipe rate: half the MFMA time.  Same staging and LDS image
+// as conv3x3_f32 (the packed weights keep their 32-cout rows; rows 0..15 are read).  Operands: lane l -> row / column l & 15,
+// k = l >> 4 (four channels of one tap per instruction); a wave owns 8 pixel blocks of 16 = its 128 positions.
+// Accumulator: lane l holds couts 4 (l >> 4) + i, i = 0..3, of pixel l & 15.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int CK>
+__global__ __launch_bounds__(kThreads, 3) void conv3x3_f32_head(ConvArgs a, int nchunk, int nblk_q, int ncb) {
+    static_assert(CK % 4 == 0, "four channels per MFMA");
+    constexpr int BN = 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Wp = a.Wp, Hp = a.Hp;
+    const int plane = Hp * Wp;
+    const int TL = kBQ + 2 * Wp + 2;
+    const int TLp = (TL + 3) & ~3;
+    float* in_tile = smem;                   // [CK][TLp]
+    float* w_tile = smem + CK * TLp;         // [9][CK][BN]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, ln = lane & 15, lk = lane >> 4;
+    int bq, cb, n;
+    tile_index(nblk_q, ncb, bq, cb, n);
+    const int q0 = bq * kBQ;
+    const float* seg0 = a.seg[0].base + (long)n * a.seg[0].stride_n + a.seg[0].set_off[0];
+    const float* wsrc = a.w + (long)cb * nchunk * (9 * CK * BN);
+
+    f32x4m acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = (t / 3) * Wp + (t % 3);
+
+    constexpr int RCI = (CK + kWaves - 1) / kWaves;
+    constexpr int NJ = 4;
+    constexpr int NWV = (9 * CK * BN / 4 + kThreads - 1) / kThreads;
+    const int TL4 = TLp >> 2;
+    for (int c = 0; c < nchunk; ++c) {
+        float4 iv[RCI * NJ + NWV];                 // all global loads of the stage in flight before the first LDS write
+#pragma unroll
+        for (int r = 0; r < RCI; ++r) {
+            const int lc = wave + r * kWaves;
+            const int ci = c * CK + lc;
+            const float* src = (lc < CK && ci < a.Cin) ? seg0 + (long)ci * plane : nullptr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int i4 = lane + 64 * j;
+                const int q = q0 + 4 * i4;
+                const bool ok = (src != nullptr) && (i4 < TL4) && (q < plane);
+                iv[r * NJ + j] = *reinterpret_cast<const float4*>(ok ? src + q : seg0);
+            }
+        }
+        const float4* ws = reinterpret_cast<const float4*>(wsrc + (long)c * (9 * CK * BN));
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {
+            const int i = tid + k * kThreads;
+            iv[RCI * NJ + k] = ws[i < 9 * CK * BN / 4 ? i : 0];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RCI; ++r) {
+            const int lc = wave + r * kWaves;
+            if (lc < CK) {
+                const bool has = c * CK + lc < a.Cin;
+                float4* dst = reinterpret_cast<float4*>(in_tile + lc * TLp);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int i4 = lane + 64 * j;
+                    const bool ok = has && (q0 + 4 * i4 < plane);
+                    if (i4 < TL4) dst[i4] = ok ? iv[r * NJ + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        float4* wd = reinterpret_cast<float4*>(w_tile);
+#pragma unroll
+        for (int k = 0; k < NWV; ++k) {
+            const int i = tid + k * kThreads;
+            if (i < 9 * CK * BN / 4) wd[i] = iv[RCI * NJ + k];
+        }
+        __syncthreads();
+        const float* ibase = in_tile + lk * TLp + wave * (kQG * 32) + ln;
+        const float* wbase = w_tile + lk * BN + ln;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < CK / 4; ++ks) {
+                const float av = wbase[(t * CK + 4 * ks) * BN];
+                float bv[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) bv[b] = ibase[(4 * ks) * TLp + toff[t] + 16 * b];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[b], 0, 0, 0);
+            }
+    }
+    // epilogue: out = residual + tanh(conv + bias) for the couts this lane holds (lanes with l >> 4 >= 2 hold padding rows)
+    const int Hout = Hp - 2, Wout = Wp - 2;
+    float bias[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int co = 4 * lk + i; const float bvv = a.aux[co < a.Cout ? co : 0]; bias[i] = co < a.Cout ? bvv : 0.f; }
+    float* outn = a.out + (long)n * a.out_stride_n;
+    const float* resn = a.res + (long)n * a.out_stride_n;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int q = q0 + wave * (kQG * 32) + 16 * b + ln;
+        const int y = q / Wp, x = q - y * Wp;
+        const bool valid = (x < Wout) && (y < Hout);
+        const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
+        float rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const bool ok = valid && (4 * lk + i < a.Cout); rv[i] = resn[ok ? (long)(4 * lk + i) * a.out_plane + opix : 0]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (valid && 4 * lk + i < a.Cout) outn[(long)(4 * lk + i) * a.out_plane + opix] = rv[i] + tanhf(acc[b][i] + bias[i]);
+    }
+}
+
+template <int CK>
+hipError_t launch_head(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t s) {
+    const int TL = kBQ + 2 * a.Wp + 2;
+    const int TLp = (TL + 3) & ~3;
+    const size_t lds = (size_t)(CK * TLp + 9 * CK * 32) * sizeof(float);
+    static LdsConfig lds_cfg;
+    if (hipError_t e = lds_cfg.ensure(&conv3x3_f32_head<CK>, lds); e != hipSuccess) return e;
+    const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
+    hipLaunchKernelGGL((conv3x3_f32_head<CK>), dim3(nblk_q * pw.ncb * n), dim3(kThreads), lds, s, a, pw.nchunk, nblk_q, pw.ncb);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 int conv_q_blocks(int Hp, int Wp) { return ((Hp - 2) * Wp + kBQ - 1) / kBQ; }
@@ -271,6 +400,12 @@ hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, 
     TTC_CONV_CASE(10, 1, EPI_BIAS_RELU)      // DSen2 in_conv        10 -> 32
     TTC_CONV_CASE(8, 1, EPI_BIAS_RELU)       // DSen2 x1_conv        32 -> 32
     TTC_CONV_CASE(8, 1, EPI_BIAS_RES)        // DSen2 x2_conv        32 -> 32 (+ residual)
+    {   // DSen2 out_conv 32 -> 6 (+ bilinear): the 16-row MFMA form when the plane is aligned and has one input segment
+        static const int narrow = [] { const char* e = getenv("TTC_CONV_NARROW"); return e ? atoi(e) : 1; }();
+        if (narrow && pw.CK == 8 && pw.BN == 32 && epi == EPI_BIAS_TANH_ADD && pw.Cout <= 16 && pw.ncb == 1 && a.seg[1].C == 0 &&
+            ((a.Hp * a.Wp) & 3) == 0 && a.Wp <= 255 && a.n_per_set >= n)
+            return launch_head<8>(a, pw, n, s);
+    }
     TTC_CONV_CASE(8, 1, EPI_BIAS_TANH_ADD)   // DSen2 out_conv       32 -> 6  (+ bilinear)
 #undef TTC_CONV_CASE
     return hipErrorInvalidValue;
