@@ -38,9 +38,12 @@ using namespace ttcconv;
 
 namespace {
 
-template <int CK, int NCG, int EPI>
+template <int CK, int NCG, int EPI, bool TRACE = false>
 __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3x3_f32(ConvArgs a, int nchunk, int nblk_q, int ncb) {
     constexpr int BN = NCG * 32;
+    // TRACE instantiation (probe aid, env TTC_F32_TRACE): wave 0 stamps s_memtime at the phase boundaries of its tile
+    unsigned long long* tr = (TRACE && threadIdx.x == 0) ? a.trace + (long)blockIdx.x * 64 : nullptr;
+    if (TRACE && tr) tr[0] = __builtin_amdgcn_s_memtime();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Wp = a.Wp, Hp = a.Hp;
     const int plane = Hp * Wp;
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
     const bool vec_ok = ((plane & 3) == 0) && (Wp <= 255);
 
     for (int c = 0; c < nchunk; ++c) {
+        if (TRACE && tr && c < 8) tr[8 + 4 * c] = __builtin_amdgcn_s_memtime();
         if (vec_ok) {
             float4 iv[RCI * NJ + NWV];
 #pragma unroll
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
                 iv[RCI * NJ + k] = ws[i < 9 * CK * BN / 4 ? i : 0];
             }
             __syncthreads();                       // previous chunk's MFMA reads are done
+            if (TRACE && tr && c < 8) tr[8 + 4 * c + 1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int r = 0; r < RCI; ++r) {
                 const int lc = wave + r * kWaves;
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
             for (int i = tid; i < 9 * CK * BN / 4; i += kThreads) wd[i] = ws[i];
         }
         __syncthreads();
+        if (TRACE && tr && c < 8) tr[8 + 4 * c + 2] = __builtin_amdgcn_s_memtime();
         // ---- MFMA ----
         const float* ibase = in_tile + hi * TLp + wave * (kQG * 32) + lo;
         const float* wbase = w_tile + hi * BN + lo;
@@ -169,10 +175,19 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
                         acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], bv[j], acc[g][j], 0, 0, 0);
             }
         }
+        if (TRACE && tr && c < 8) tr[8 + 4 * c + 3] = __builtin_amdgcn_s_memtime();
     }
+    if (TRACE && tr) tr[2] = __builtin_amdgcn_s_memtime();
 
     if constexpr (EPI <= EPI_SWISH) {
-        conv_epilogue_flat<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid, smem); return;
+        conv_epilogue_flat<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid, smem, TRACE && tr ? tr + 52 : nullptr);
+        if (TRACE && tr) {
+            tr[3] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tr[4] = __builtin_amdgcn_s_memtime();
+            tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        }
+        return;
     }
     conv_epilogue<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
 }
@@ -187,6 +202,33 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     if (hipError_t e = lds_cfg.ensure(&conv3x3_f32<CK, NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
     dim3 grid(nblk_q * pw.ncb * n);
+    if constexpr (CK == 10 && NCG == 2 && EPI == EPI_RAW) {          // probe aid: one traced launch of the gates conv
+        static const char* trace_path = getenv("TTC_F32_TRACE");
+        static int trace_left = trace_path ? 1 : 0;
+        if (trace_left > 0 && grid.x > 4000) {
+            trace_left--;
+            static LdsConfig lds_tr;
+            (void)lds_tr.ensure(&conv3x3_f32<CK, NCG, EPI, true>, lds);
+            unsigned long long* d = nullptr;
+            const size_t bytes = (size_t)grid.x * 64 * sizeof(unsigned long long);
+            (void)hipStreamSynchronize(s);
+            if (hipMalloc(&d, bytes) == hipSuccess) {
+                (void)hipMemset(d, 0, bytes);
+                ConvArgs b = a; b.trace = d;
+                hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                float ms = 0.f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    (void)hipEventRecord(e0, s);
+                    hipLaunchKernelGGL((conv3x3_f32<CK, NCG, EPI, true>), grid, dim3(kThreads), lds, s, b, pw.nchunk, nblk_q, pw.ncb);
+                    (void)hipEventRecord(e1, s); (void)hipStreamSynchronize(s); (void)hipEventElapsedTime(&ms, e0, e1);
+                }
+                std::vector<unsigned long long> h((size_t)grid.x * 64);
+                (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost); (void)hipFree(d);
+                if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+                fprintf(stderr, "[f32] traced gates launch: %.3f ms, grid %u -> %s\n", ms, grid.x, trace_path);
+            }
+        }
+    }
     hipLaunchKernelGGL((conv3x3_f32<CK, NCG, EPI>), grid, dim3(kThreads), lds, s, a, pw.nchunk, nblk_q, pw.ncb);
     return hipGetLastError();
 }

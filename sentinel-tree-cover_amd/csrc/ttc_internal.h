@@ -66,6 +66,7 @@ struct ConvArgs {
     const float* res;    // EPI_BIAS_RES / _TANH_ADD: residual, same indexing as out
     int same_pad;        // EPI_SWISH: 1 -> multiply by the partial-conv ratio (zero-padded SAME conv)
     int reflect_out;     // EPI_BIAS*: 1 -> also write the 1-px reflect rim of the (padded) output plane
+    unsigned long long* trace;   // probe aid (TTC_F32_TRACE): per-workgroup s_memtime stamps of the traced instantiation, else nullptr
     // EPI <= EPI_SWISH (the GroupNorm layers): the output ALWAYS keeps the input pitch -- out_pitch == Wp, oy == ox == 0,
     // out_plane == (Hp-2)*Wp: out[co][q] for the tile's own flat positions q, junk columns included -- so that a tile leaves
     // through an LDS transpose as fully coalesced 16-byte stores (conv_epilogue_flat); out_pitch / oy / ox are ignored there
