@@ -213,6 +213,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
 
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (a.trace) tr0 = __builtin_amdgcn_s_memtime();
+    const bool prio = (a.desync & 2) != 0;                   // probe switch: raised issue priority outside the MFMA blocks
+    if (prio) __builtin_amdgcn_s_setprio(3);
     int bq, cb, n;
     tile_index(nblk_q, ncb, bq, cb, n);
     const int set = n / a.c.n_per_set, nn = n - set * a.c.n_per_set;
@@ -461,15 +463,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
                 else if (kb == 1) issue_w(nws, nwu, 2 * WPIECES, 0, (kMaxW + 1) / 2);
                 else if (kb == 2) issue_w(nws, nwu, 2 * WPIECES, (kMaxW + 1) / 2, kMaxW);
             };
+            if (prio) __builtin_amdgcn_s_setprio(0);
             if (!(abl & 2)) mfma_chunk_s(LOU, WU0 + b * 2 * WUNITS, stepA);          // x_lo * w_hi
             else { stepA(0); stepA(1); stepA(2); }
+            if (prio) __builtin_amdgcn_s_setprio(3);
             if (tq) tq[3] = __builtin_amdgcn_s_memtime();
             cbarrier();               // the lo tile is free
             if (tq) tq[4] = __builtin_amdgcn_s_memtime();
             const uint4* nlo = more ? in_plane(cn, true) : nullptr;
             auto stepB = [&](int kb) { if (kb == 0) issue_in(nlo, LOU); };               // next lo tile after K block 0
+            if (prio) __builtin_amdgcn_s_setprio(0);
             if (!(abl & 2)) mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, stepB);   // x_hi * w_lo + x_hi * w_hi
             else stepB(0);
+            if (prio) __builtin_amdgcn_s_setprio(3);
             if (tq) tq[5] = __builtin_amdgcn_s_memtime();
         }
     }

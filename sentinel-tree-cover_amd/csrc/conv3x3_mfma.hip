@@ -44,6 +44,10 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
     // TRACE instantiation (probe aid, env TTC_F32_TRACE): wave 0 stamps s_memtime at the phase boundaries of its tile
     unsigned long long* tr = (TRACE && threadIdx.x == 0) ? a.trace + (long)blockIdx.x * 64 : nullptr;
     if (TRACE && tr) tr[0] = __builtin_amdgcn_s_memtime();
+    // Tried: s_setprio(3) outside the MFMA blocks, 0 inside.  The per-workgroup trace shows WHY the non-MFMA phases are slow (the
+    // wave inside its MFMA block wins issue arbitration; kernel entry -> first chunk 22 k cycles, epilogue 43 k of a 272 k-cycle
+    // tile) and that priority fixes exactly that (3.6 k / 32 k) -- but the MFMA blocks then share the pipe (24.6 k -> 42 k per
+    // chunk) and the tile takes the same 272 k: two waves x 115 k cycles of MFMA issue per SIMD is 85 % of it either way.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Wp = a.Wp, Hp = a.Hp;
     const int plane = Hp * Wp;
