@@ -206,10 +206,11 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     if (hipError_t e = lds_cfg.ensure(&conv3x3_f32<CK, NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
     dim3 grid(nblk_q * pw.ncb * n);
-    if constexpr (CK == 10 && NCG == 2 && EPI == EPI_RAW) {          // probe aid: one traced launch of the gates conv
-        static const char* trace_path = getenv("TTC_F32_TRACE");
+    if constexpr (NCG == 2 && ((CK == 10 && EPI == EPI_RAW) || (CK == 8 && EPI == EPI_SWISH))) {   // probe aid: one traced launch
+        static const char* trace_path = getenv("TTC_F32_TRACE");           // of the gates conv (or, TTC_F32_TRACE_EPI=2, of the first
+        static const int trace_epi = [] { const char* e = getenv("TTC_F32_TRACE_EPI"); return e ? atoi(e) : (int)EPI_RAW; }();   // big U-Net block)
         static int trace_left = trace_path ? 1 : 0;
-        if (trace_left > 0 && grid.x > 4000) {
+        if (trace_left > 0 && grid.x > 2000 && EPI == trace_epi) {
             trace_left--;
             static LdsConfig lds_tr;
             (void)lds_tr.ensure(&conv3x3_f32<CK, NCG, EPI, true>, lds);
@@ -229,7 +230,7 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
                 std::vector<unsigned long long> h((size_t)grid.x * 64);
                 (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost); (void)hipFree(d);
                 if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
-                fprintf(stderr, "[f32] traced gates launch: %.3f ms, grid %u -> %s\n", ms, grid.x, trace_path);
+                fprintf(stderr, "[f32] traced launch (CK %d, epilogue %d, %d chunks): %.3f ms, grid %u -> %s\n", CK, EPI, pw.nchunk, ms, grid.x, trace_path);
             }
         }
     }
