@@ -1,6 +1,6 @@
 """Benchmark of the MI355X tree-cover inference hot path (BASELINE.json metric: 10 m pixels/s; max |dprob| vs the oracle).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp16|bf16|bf16x3] [--win 172] [--length 4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|fp16|bf16] [--win 172] [--length 4]
     python bench.py --preprocess-only --tiles 256          # BASELINE configs[2]: preprocessing only, HBM roofline
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
@@ -36,8 +36,6 @@ DTYPES = {
     "fp32": "f32 (fp32 MFMA, exact fp32 FMA chains)",
     "fp16": "fp16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
     "bf16": "bf16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
-    "bf16x3": "f32 storage, split-bf16 (3 products) MFMA, f32 accumulate (round-1 engine)",
-    "fp32b": "f32 (fp32 MFMA, exact fp32 FMA chains, channel-blocked activations + LDS-DMA staging)",
 }
 
 
@@ -49,7 +47,7 @@ def conv_gates_flops(W, n_windows):
 def pmc_traffic(precision, win):
     """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the timed
     process).  Only valid for the configuration the counters were collected on."""
-    name = {"fp32": "r01_c_pmc_conv_gates.json", "bf16x3": "r01_f_pmc_conv_b3_gates.json", "fp16": "r02_pmc_conv_h16_gates.json"}.get(precision)
+    name = {"fp32": "r01_c_pmc_conv_gates.json", "fp16": "r02_pmc_conv_h16_gates.json"}.get(precision)
     p = os.path.join(ROOT, "profiles", name) if name else None
     if win != 172 or not p or not os.path.exists(p):
         return None
@@ -61,15 +59,15 @@ def roofline(precision, win, gates_ms, gates_n):
     """dominant kernel family = the ConvGRU gates convolution (49 -> 64, both directions, 36 windows per launch)"""
     flops = conv_gates_flops(win, 36)
     ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
-    if precision in ("fp32", "fp32b"):
-        return {"kernel": ("conv3x3_f32<CK=10,NCG=2,EPI_RAW>" if precision == "fp32" else "conv3x3_f32b<NCG=2,EPI_RAW>") + " (ConvGRU gates, 49->64, both directions)",
+    if precision == "fp32":
+        return {"kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
                 "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
                 "traffic": pmc_traffic(precision, win), "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops}
     # 16-bit engines: ALGORITHMIC flops against the dense 16-bit MFMA peak; the three split products and the K padding
     # (49 -> 56 channels, 9 -> 10 tap halves) that the kernel actually issues are reported beside it
     nbytes = 72.0 * (56 * (win + 2) ** 2 * 4 + 64 * win * (win + 2) * 4)          # hi+lo blocked input planes + fp32 raw output
     issued = 3.0 * flops * (56.0 / 49) * (10.0 / 9)
-    name = "conv3x3_h16<TERMS=3,NCG=2,EPI_RAW>" if precision in ("fp16", "bf16") else "conv3x3_b3<NCG=2,EPI_RAW>"
+    name = "conv3x3_h16<TERMS=3,NCG=2,EPI_RAW>"
     return {"kernel": name + " (ConvGRU gates, 49->64, both directions)", "bound": "mfma", "achieved": ach, "peak": H16_MFMA_PEAK_TF,
             "unit": "TFLOP/s", "frac": ach / H16_MFMA_PEAK_TF, "traffic": pmc_traffic(precision, win), "launch_ms": gates_ms,
             "launches_timed": gates_n, "flops_per_launch": flops,
@@ -135,7 +133,7 @@ def main():
     ap.add_argument("--dates", type=int, default=12, help="raw acquisition dates T")
     ap.add_argument("--precision", choices=list(DTYPES), default="fp32",
                     help="conv engines: exact fp32 MFMA chains (BASELINE configs[1], default), fp16 / bf16 hi+lo operand pairs on the "
-                         "16-bit engine (configs[4] / [3]), or the round-1 split-bf16 engine")
+                         "16-bit engine (configs[4] / [3])")
     ap.add_argument("--inflight", type=int, default=2, help="tiles in flight per GPU per step, each on its own HIP stream + context")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic tiles per rank, visited round-robin")
     ap.add_argument("--gather-batch", type=int, default=64, help="finished rasters per RCCL gather (N > 1)")

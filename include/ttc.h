@@ -52,20 +52,20 @@ typedef struct {
     int32_t hidden;        /* 32  (ConvGRU filters per direction = base_filters / 2)    */
     int32_t base_filters;  /* 64                                                        */
     float   zoneout;       /* 0.75: state' = z*state + (1-z)*new  (model.py:571-574)    */
-    int32_t precision;     /* 0 = fp32 MFMA (exact fp32 FMA chains); 1 = split-bf16 products on fp32 activations (round-1
-                            * engine); 2 = fp16 / 3 = bf16 operands on the 16-bit engine: activations that feed a conv are
-                            * stored as hi + lo 16-bit pairs, each layer multiplies 3 split products (~fp32 accuracy for
-                            * fp16 pairs) or 1 (plain 16-bit operands) per `one_term_layers`; accumulation, GroupNorm
-                            * statistics and every non-conv operation stay fp32; 4 = exact fp32 MFMA like 0, on the same
-                            * channel-blocked activation layout as 2 / 3 with fp32 payload (LDS-DMA staging)            */
+    int32_t precision;     /* 0 = fp32 MFMA (exact fp32 FMA chains); 2 = fp16 / 3 = bf16 operands on the 16-bit engine:
+                            * activations that feed a conv are stored as hi + lo 16-bit pairs, each layer multiplies 3
+                            * split products (~fp32 accuracy for fp16 pairs) or 1 (plain 16-bit operands) per
+                            * `one_term_layers`; accumulation, GroupNorm statistics and every non-conv operation stay
+                            * fp32.  (1 and 4 were the bf16x3 / fp32-blocked engines, retired in round 3: rejected.)    */
     int32_t win_rows;      /* H: window rows for the non-square border graph of
                             * src/resegment_tiles_wide.py:478 ([L+1, SIZE_Y+14, SIZE+14, 17] = 220 x 684);
                             * 0 = square (win_in).  The per-tile core needs square windows. */
     uint32_t one_term_layers; /* precision 2 / 3 only: bit i set = conv layer i runs ONE 16-bit product (hi x hi) instead of
                             * three.  Bits: 0 ConvGRU gates, 1 ConvGRU candidate, 2..9 conv_median, conv_concat, conv1,
-                            * conv2, up2, up2_out, up3, out, 10..15 the six DSen2 convs.  Measured on the oracle with
-                            * as-stored-scale kernels (tools/study/precision_study.py): only bit 0 keeps max |dprob| well
-                            * inside the 1e-3 contract with fp16; bf16 needs 0.                                        */
+                            * conv2, up2, up2_out, up3, out, 10..15 the six DSen2 convs.  Default 0.  Measured on a real
+                            * 618^2 tile with as-stored-scale kernels (tools/probes/tile_dprob_probe.py): ANY bit set moves
+                            * max |dprob| to 3.0e-3 (bit 0) .. 2.7e-2, OUTSIDE the 1e-3 contract; all-zero: fp16 5e-5,
+                            * bf16 3.7e-4.  Set bits only for workloads with a looser accuracy budget.                 */
 } ttc_config;
 
 /* A named host tensor in TensorFlow layout (conv kernels HWIO). */

@@ -41,7 +41,7 @@ class TTCConfig(C.Structure):
 # (one_term_layers = 0).  Measured with as-stored-scale kernels: running only the ConvGRU gates conv (bit 0) with plain fp16
 # operands keeps max |dprob| at 2e-4 (L = 4) .. 6.5e-4 (L = 12) on white-noise windows, but reaches 3.0e-3 on a real
 # (spatially smooth) 618^2 tile, outside the 1e-3 contract -- so no layer runs one product unless the caller asks for it.
-PRECISIONS = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16": 3, "fp32b": 4}     # fp32b: exact fp32 MFMA on channel-blocked activations
+PRECISIONS = {"fp32": 0, "fp16": 2, "bf16": 3}     # 1 / 4 were the retired bf16x3 / fp32-blocked engines (csrc/experiments/)
 
 
 def default_one_term(precision, length):

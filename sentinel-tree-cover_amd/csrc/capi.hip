@@ -74,8 +74,9 @@ ttc_status ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg) {
     c->cfg = *cfg;
     c->device = device;
     *out = c;                       // returned even on failure so the caller can read ttc_last_error
-    if (cfg->precision < 0 || cfg->precision > 4)
-        return c->fail(TTC_ERR_ARG, "precision: 0 (exact fp32 MFMA, planar), 1 (split-bf16 'bf16x3' on fp32 activations), 2 (fp16) / 3 (bf16) 16-bit engine, 4 (exact fp32 MFMA on channel-blocked activations)");
+    if (cfg->precision != 0 && cfg->precision != 2 && cfg->precision != 3)
+        return c->fail(TTC_ERR_ARG, "precision: 0 (exact fp32 MFMA), 2 (fp16) / 3 (bf16) hi + lo pairs on the 16-bit engine; 1 and 4 named the retired "
+                                    "bf16x3 / fp32-blocked engines (csrc/experiments/)");
     if (cfg->max_windows < 1 || cfg->length < 1) return c->fail(TTC_ERR_ARG, "max_windows and length must be >= 1");
     return model_alloc(c);
 }

@@ -579,274 +579,6 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// fp32 on the same blocked layout (ttc_config.precision = 4, "fp32b").  The `hi` tensor of a channel block holds its
-// channels 0..3 as fp32, the `lo` tensor channels 4..7 (h16_common.h, Elem mode 2): one position's four channels are one
-// 16-byte vector, so (a) staging is the same pure LDS-DMA as above and (b) the LDS image is K-contiguous -- one ds_read_b128
-// feeds FOUR v_mfma_f32_32x32x2_f32 (the planar fp32 engine of conv3x3_mfma.hip needs one ds_read_b32 per operand and MFMA
-// and tops out at ~84 % of the matrix peak in a bare loop; this operand order reaches ~98 %, tools/probes/mfma_f32_loop_probe.hip).
-// One K block = one tap x 8 channels: lanes 0..31 (k = 0) read the hi plane, lanes 32..63 (k = 1) the lo plane at the SAME
-// position, MFMA m of the block multiplies channel m (k = 0) and 4 + m (k = 1); nine K blocks per 8-channel chunk, no padding
-// taps.  Exact fp32 FMA chains like the planar engine (a different, equally valid summation order).
-// LDS (<= 80 KB, 2 workgroups per CU): input tiles double-buffered [2][hi | lo][tile], ONE weight image per chunk that is
-// refreshed in two halves -- taps 0..4 of chunk c + 1 stream in while taps 5..8 of chunk c run, taps 5..8 of chunk c and the
-// input tile of chunk c + 1 while taps 0..4 of chunk c run: two barriers per chunk, every copy has >= 4 taps of MFMAs
-// (>= 8 k cycles) to land.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NCG, int EPI>
-__device__ __forceinline__ void f32b_epilogue_blk(const H16Args& a, f32x16 (&acc)[NCG][kQG], int n, int cb, int bq, const float* aux, int tid) {
-    constexpr int BN = NCG * 32;
-    const ConvArgs& c = a.c;
-    const int Wp = c.Wp, Hp = c.Hp;
-    const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
-    const int q0 = bq * kBQ;
-    const int Hout = Hp - 2, Wout = Wp - 2;
-    const int C8out = (c.Cout + 7) >> 3;
-    // accumulator rows of a lane: (r & 3) + 8 * (r >> 2) + 4 * hi -> half-wave `hi` owns channels 4 * hi .. 4 * hi + 3 of block r >> 2,
-    // which is exactly the hi-tensor / lo-tensor split of the blocked fp32 layout: no cross-lane traffic
-    uint4* obase = (hi ? a.o_lo : a.o_hi) + (long)n * a.o_stride_n;
-    const uint4* rbase = (EPI == EPI_BIAS_RES) ? (hi ? a.r_lo : a.r_hi) + (long)n * a.o_stride_n : nullptr;
-    float bias[NCG][16];          // fetched once, unconditionally (see conv_epilogue)
-#pragma unroll
-    for (int g = 0; g < NCG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float bv = aux[co < c.Cout ? co : 0];
-            bias[g][r] = co < c.Cout ? bv : 0.f;
-        }
-#pragma unroll
-    for (int j = 0; j < kQG; ++j) {
-        const int q = q0 + (wave * kQG + j) * 32 + lo;
-        const int y = q / Wp, x = q - y * Wp;
-        const bool valid = (x < Wout) && (y < Hout);
-        const long opix = (long)(y + c.oy) * c.out_pitch + (x + c.ox);
-        long dup_y = 0, dup_x = 0;
-        if (c.reflect_out && valid) {
-            dup_y = (y == 1) ? -2L * c.out_pitch : ((y == Hout - 2) ? 2L * c.out_pitch : 0L);
-            dup_x = (x == 1) ? -2L : ((x == Wout - 2) ? 2L : 0L);
-        }
-#pragma unroll
-        for (int g = 0; g < NCG; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int blk = cb * (BN / 8) + g * 4 + k;
-                const bool ok = valid && (blk < C8out);
-                const long u = ok ? (long)blk * a.o_plane + opix : 0L;
-                float res[4] = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_BIAS_RES) {
-                    const uint4 rv = rbase[u];
-                    res[0] = __uint_as_float(rv.x); res[1] = __uint_as_float(rv.y); res[2] = __uint_as_float(rv.z); res[3] = __uint_as_float(rv.w);
-                }
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int co = cb * BN + g * 32 + i + 8 * k + 4 * hi;
-                    float t = acc[g][j][4 * k + i] + bias[g][4 * k + i];
-                    if (EPI == EPI_BIAS_RELU) t = fmaxf(t, 0.f);
-                    if (EPI == EPI_BIAS_RES) t = res[i] + 0.1f * t;
-                    v[i] = co < c.Cout ? t : 0.f;               // pad channels of the last block stay zero
-                }
-                if (ok) {
-                    const uint4 o = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-                    obase[u] = o;
-                    if (dup_y) obase[u + dup_y] = o;
-                    if (dup_x) obase[u + dup_x] = o;
-                    if (dup_y && dup_x) obase[u + dup_y + dup_x] = o;
-                }
-            }
-    }
-}
-
-template <int NCG, int EPI, int OUT>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_f32b(H16Args a, int nblk_q, int ncb, int ntiles) {
-    constexpr int BN = NCG * 32;
-    constexpr int WTAP = 2 * BN;                             // 16-byte units of one tap of the weight image: [half][cout]
-    constexpr int WUNITS = 9 * WTAP;                         // one chunk (whole 1-KiB pieces for BN = 32 and 64)
-    constexpr int WA = 5 * WTAP;                             // taps 0..4 | taps 5..8
-    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    const int Wp = a.c.Wp, Hp = a.c.Hp;
-    const long plane = (long)Hp * Wp;
-    const int TL = kBQ + 2 * Wp + 2;
-    const int NIN = (TL + 63) >> 6;                          // 1-KiB pieces of one input plane of a chunk
-    const int INU = NIN * 64;
-    const int W0 = 4 * INU;                                  // LDS: IN[buf 0: hi | lo][buf 1: hi | lo] W
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Persistent workgroups: the grid is (at most) the resident set, 2 per CU, and a workgroup walks the XCD-aware tile list of
-    // conv_common.h with the stride of its XCD's workgroup count -- at any moment the workgroups of one XCD work on neighbouring
-    // tiles (shared halos meet in that XCD's L2), and the matrix pipe does not drain at workgroup turnover (a bare MFMA loop
-    // of this shape: 97.7 % of peak as 512 long workgroups, 89 % as 4248 short ones, tools/probes/mfma_f32_loop_probe.hip).
-    const int P = gridDim.x, xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
-    const int nx = (P >> 3) + (xcd < (P & 7) ? 1 : 0);                           // workgroups on this XCD
-    const int per = ntiles >> 3, rem = ntiles & 7;
-    const int tcnt = per + (xcd < rem ? 1 : 0), tstart = xcd * per + (xcd < rem ? xcd : rem);
-    const int C8_0 = a.seg[0].C8;
-    const int nchunk = a.nchunk;
-    const int abl = a.abl;                                  // probe aid, see the top of the file
-    // The two workgroups of a CU start together and their tiles take the same time, so their epilogues (no MFMAs) would
-    // coincide for the whole launch: the one in the odd wave slot starts a.desync x 3.4 us late.
-    if (a.desync > 0 && (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1u))
-        for (int i = 0; i < a.desync; ++i) __builtin_amdgcn_s_sleep(127);
-    for (int tk = wslot; tk < tcnt; tk += nx) {
-    const int lid = tstart + tk;
-    const int bq = lid % nblk_q;
-    const int cb = (lid / nblk_q) % ncb, n = (lid / nblk_q) / ncb;
-    if (tk != wslot) cbarrier();                            // the previous tile's epilogue is done with the LDS
-    const int set = n / a.c.n_per_set, nn = n - set * a.c.n_per_set;
-    const int q0 = bq * kBQ;
-    const float* aux = a.c.aux ? a.c.aux + (long)set * a.c.aux_set_stride : nullptr;
-    const uint4* wsrc = a.w + (long)set * a.w_set_stride + (long)cb * nchunk * WUNITS;
-    const long seg_off0 = (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
-    const long seg_off1 = (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set];
-
-    auto dma = [&](const char* g, int lds_unit) {
-        if (abl & 4) return;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(smem + lds_unit), 16, 0, 0);
-    };
-    constexpr int kMaxIn = 4;                                // input pieces per wave and plane: NIN <= 16 (checked at launch)
-    const int cnt_in = (NIN + 3) >> 2;
-    unsigned off_in[kMaxIn];
-    int unit_in[kMaxIn];
-#pragma unroll
-    for (int k = 0; k < kMaxIn; ++k) {
-        const int pid = wave + 4 * k;
-        long q = (long)q0 + 64 * pid + lane;
-        q = q < plane ? q : plane - 1;
-        off_in[k] = (unsigned)(q * 16);
-        unit_in[k] = 64 * pid;
-    }
-    // Copies of one phase, this wave's share (pieces wave, wave + 4, ...), issued as three straight-line steps between the MFMA
-    // blocks of the first taps: step 0 = hi plane, 1 = lo plane, 2 = weights.  (A generic "issue the next n pieces" loop with
-    // its per-piece branches cost 10 % of the kernel: the wave that runs scalar code issues no MFMAs.)
-    bool in_ok[kMaxIn];
-#pragma unroll
-    for (int k = 0; k < kMaxIn; ++k) in_ok[k] = wave + 4 * k < NIN;
-    struct Copy { const char* hi; const char* lo; int u0; const char* ws; int wu, nwp; };
-    auto copy_of = [&](const uint4* hi_p, const uint4* lo_p, int u0, const uint4* ws, int wu, int nwp) {
-        return Copy{reinterpret_cast<const char*>(hi_p), reinterpret_cast<const char*>(lo_p), u0, reinterpret_cast<const char*>(ws), wu, nwp};
-    };
-    auto issue_step = [&](const Copy& cp, int step) {          // `step` is a constant after unrolling
-        if (abl & 32) return;                                // probe: no copy-issue code at all
-        if (step < 2) {
-            if (cp.hi) {
-                const char* src = step ? cp.lo : cp.hi;
-                const int ub = cp.u0 + step * INU;
-#pragma unroll
-                for (int k = 0; k < kMaxIn; ++k)
-                    if (in_ok[k]) dma(src + off_in[k], ub + unit_in[k]);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int wp = wave + 4 * k;
-                if (wp < cp.nwp) dma(cp.ws + (unsigned)((64 * wp + lane) * 16), cp.wu + 64 * wp);
-            }
-        }
-    };
-    auto in_plane = [&](int c, bool lo_plane) -> const uint4* {
-        const bool first = c < C8_0;
-        const H16Seg& sg = a.seg[first ? 0 : 1];
-        const uint4* base = lo_plane ? sg.lo : sg.hi;
-        return base + (first ? seg_off0 : seg_off1) + (long)(first ? c : c - C8_0) * plane;
-    };
-
-    f32x16 acc[NCG][kQG];
-#pragma unroll
-    for (int g = 0; g < NCG; ++g)
-#pragma unroll
-        for (int j = 0; j < kQG; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
-
-    const int bbase = hi * INU + wave * (kQG * 32) + lo;     // this lane's position 0 inside an input buffer (its half's plane)
-    const int abase = W0 + hi * BN + lo;
-    auto load_ab = [&](int tap, int in_unit, f32x4 (&av)[NCG], f32x4 (&bv)[kQG]) {
-#pragma unroll
-        for (int g = 0; g < NCG; ++g) av[g] = *reinterpret_cast<const f32x4*>(smem + abase + tap * WTAP + g * 32);
-        const int off = in_unit + bbase + (tap / 3) * Wp + (tap % 3);
-#pragma unroll
-        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const f32x4*>(smem + off + 32 * j);
-    };
-    auto mfma_taps = [&](auto T0, auto T1, int in_unit, const Copy& cp) {
-        constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value;
-        f32x4 av[2][NCG], bv[2][kQG];
-        load_ab(t0, in_unit, av[0], bv[0]);
-        if (abl & 16) load_ab(t0 + 1, in_unit, av[1], bv[1]);      // probe: operands fetched once per tap group
-#pragma unroll
-        for (int t = t0; t < t1; ++t) {
-            const int cur = (t - t0) & 1;
-            if (t + 1 < t1 && !(abl & 16)) load_ab(t + 1, in_unit, av[cur ^ 1], bv[cur ^ 1]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int g = 0; g < NCG; ++g)
-#pragma unroll
-                    for (int j = 0; j < kQG; ++j)
-                        acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][g][m], bv[cur][j][m], acc[g][j], 0, 0, 0);
-            if (t0 == 0) { if (t - t0 < 3) issue_step(cp, t - t0); }        // taps 0..4: input planes after taps 0 and 1, weights after tap 2
-            else if (t == t0) issue_step(cp, 2);                           // taps 5..8: weights after the first
-        }
-    };
-    using I0 = std::integral_constant<int, 0>; using I5 = std::integral_constant<int, 5>; using I9 = std::integral_constant<int, 9>;
-
-    {   // prologue: input tile and taps 0..4 of chunk 0
-        const Copy p = copy_of(in_plane(0, false), in_plane(0, true), 0, wsrc, W0, WA / 64);
-        issue_step(p, 0); issue_step(p, 1); issue_step(p, 2);
-    }
-    for (int c = 0; c < nchunk; ++c) {
-        const int b = c & 1;
-        const bool more = c + 1 < nchunk;
-        const uint4* wc = wsrc + (long)c * WUNITS;
-        wait_vm(0);
-        if (!(abl & 8)) cbarrier();               // input tile c and taps 0..4 have landed for every wave; every wave is done with chunk c - 1
-        const Copy pa = copy_of(more ? in_plane(c + 1, false) : nullptr, more ? in_plane(c + 1, true) : nullptr, (b ^ 1) * 2 * INU,
-                                wc + WA, W0 + WA, (WUNITS - WA) / 64);
-        if (!(abl & 2)) mfma_taps(I0{}, I5{}, b * 2 * INU, pa);
-        else { issue_step(pa, 0); issue_step(pa, 1); issue_step(pa, 2); }
-        wait_vm(0);
-        if (!(abl & 8)) cbarrier();               // taps 5..8 (and the next input tile) have landed; taps 0..4 of the image are free
-        const Copy pb = copy_of(nullptr, nullptr, 0, wc + WUNITS, W0, more ? WA / 64 : 0);
-        if (!(abl & 2)) mfma_taps(I5{}, I9{}, b * 2 * INU, pb);
-        else issue_step(pb, 2);
-    }
-    if (abl & 1) {
-        float t = 0.f;
-        for (int g = 0; g < NCG; ++g) for (int j = 0; j < kQG; ++j) for (int r = 0; r < 16; ++r) t += acc[g][j][r];
-        if (t == 1234.5f) a.c.stats[tid] = t + __builtin_bit_cast(float, smem[tid].x);
-        continue;
-    }
-    if constexpr (OUT == OUT_B16) {
-        f32b_epilogue_blk<NCG, EPI>(a, acc, n, cb, bq, aux, tid);
-    } else if constexpr (EPI <= EPI_SWISH) {
-        conv_epilogue_flat<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid, reinterpret_cast<float*>(smem));
-    } else {
-        conv_epilogue<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid);
-    }
-    }
-}
-
-template <int NCG, int EPI, int OUT>
-hipError_t launch_f32b(const H16Args& a, const PackedConv& pw, int n, hipStream_t s) {
-    constexpr int BN = NCG * 32;
-    const int TL = kBQ + 2 * a.c.Wp + 2;
-    const int NIN = (TL + 63) >> 6;
-    const size_t lds = std::max((size_t)(4 * NIN * 64 + 18 * BN) * 16, kFlatLdsBytes);
-    if (lds > 160 * 1024 || NIN > 16) return hipErrorInvalidValue;
-    static LdsConfig lds_cfg;
-    if (hipError_t e = lds_cfg.ensure(&conv3x3_f32b<NCG, EPI, OUT>, lds); e != hipSuccess) return e;
-    const int nblk_q = conv_q_blocks(a.c.Hp, a.c.Wp);
-    const int ntiles = nblk_q * pw.ncb * n;
-    static const int persist = [] { const char* e = getenv("TTC_F32B_PERSIST"); return e ? atoi(e) : 512; }();    // 0: one workgroup per tile
-    const int grid = persist > 0 ? std::min(ntiles, persist) : ntiles;
-    hipLaunchKernelGGL((conv3x3_f32b<NCG, EPI, OUT>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles);
-    return hipGetLastError();
-}
-
 }  // namespace
 
 // ---- host: 16-bit conversions (round to nearest even), weight packing, dispatch -----------------------------------
@@ -927,46 +659,7 @@ long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cou
 }
 
 
-// fp32 blocked engine: LDS image of one (set, cout block, chunk) = [tap 0..8][half 0 | 1][cout 0..BN)[4 ch] fp32 (half h = channels
-// 4h .. 4h + 3 of the 8-channel chunk), chunks as in conv_pack_h16.  Returns 16-byte units per set.
-long conv_pack_f32b(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, std::vector<float>& out, int* nchunk_out) {
-    const int c8_0 = (C0 + 7) / 8, c8_1 = (Cin - C0 + 7) / 8, nchunk = c8_0 + c8_1, ncb = (Cout + BN - 1) / BN;
-    const long chunk_fl = 9L * 2 * BN * 4;
-    const long per_set = (long)ncb * nchunk * chunk_fl;
-    out.assign((size_t)per_set * nsets, 0.f);
-    for (int s = 0; s < nsets; ++s)
-        for (int cb = 0; cb < ncb; ++cb)
-            for (int c = 0; c < nchunk; ++c)
-                for (int tap = 0; tap < 9; ++tap)
-                    for (int co = 0; co < BN; ++co)
-                        for (int k = 0; k < 8; ++k) {
-                            const int ci = c < c8_0 ? c * 8 + k : C0 + (c - c8_0) * 8 + k;
-                            const bool real = c < c8_0 ? (c * 8 + k < C0) : (ci < Cin);
-                            const int o = cb * BN + co;
-                            if (!real || o >= Cout) continue;
-                            out[(size_t)s * per_set + ((long)cb * nchunk + c) * chunk_fl + (((long)tap * 2 + (k >> 2)) * BN + co) * 4 + (k & 3)] =
-                                hwio[s][((long)tap * Cin + ci) * Cout + o];
-                        }
-    if (nchunk_out) *nchunk_out = nchunk;
-    return per_set / 4;
-}
-
 hipError_t conv_launch_h16(const H16Args& a_in, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s) {
-    if (mode == 2) {
-        static const int abl_f = [] { const char* e = getenv("TTC_H16_ABL"); return e ? atoi(e) : 0; }();
-        static const int desync_f = [] { const char* e = getenv("TTC_F32B_DESYNC"); return e ? atoi(e) : 0; }();
-        H16Args af = a_in;
-        af.abl = abl_f; af.desync = desync_f;
-#define TTC_F32B_CASE(ncg, e, o) if (pw.BN == ncg * 32 && epi == e && out_kind == o) return launch_f32b<ncg, e, o>(af, pw, n, s);
-        TTC_F32B_CASE(2, EPI_RAW, OUT_F32)
-        TTC_F32B_CASE(1, EPI_SSE, OUT_F32)
-        TTC_F32B_CASE(2, EPI_SWISH, OUT_F32)
-        TTC_F32B_CASE(1, EPI_BIAS_RELU, OUT_B16)
-        TTC_F32B_CASE(1, EPI_BIAS_RES, OUT_B16)
-        TTC_F32B_CASE(1, EPI_BIAS_TANH_ADD, OUT_F32)
-#undef TTC_F32B_CASE
-        return hipErrorInvalidValue;
-    }
     const bool bf = mode == 1;
     const int terms = pw.terms == 1 ? 1 : 3;
     static const int desync_env = [] { const char* e = getenv("TTC_H16_DESYNC"); return e ? atoi(e) : -1; }();   // probe switches

@@ -410,21 +410,7 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
     pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);
     if (!pc.d_w && !(pc.d_w = c->alloc_f(packed.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc weights");
     TTC_HIP(c, hipMemcpy(pc.d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (pc.mode == 1) {
-        std::vector<uint16_t> p3;
-        pc.set_stride3 = conv_pack_b3(hwio, nsets, Cin, Cout, pc.BN, p3);
-        pc.nchunk3 = (Cin + 7) / 8;
-        if (!pc.d_w3 && !(pc.d_w3 = reinterpret_cast<uint16_t*>(c->alloc_f((p3.size() + 1) / 2))))
-            return c->fail(TTC_ERR_NOMEM, "hipMalloc bf16 weights");
-        TTC_HIP(c, hipMemcpy(pc.d_w3, p3.data(), p3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    }
-    if (pc.mode == 4) {                        // fp32 blocked engine: K-contiguous fp32 LDS images (conv3x3_h16.hip: conv3x3_f32b)
-        std::vector<float> pf;
-        pc.set_stride_h = conv_pack_f32b(hwio, nsets, Cin, C0 < 0 ? Cin : C0, Cout, pc.BN, pf, &pc.nchunk_h);
-        if (!pc.d_wh && !(pc.d_wh = reinterpret_cast<uint4*>(c->alloc_f(pf.size() + 256))))
-            return c->fail(TTC_ERR_NOMEM, "hipMalloc blocked fp32 weights");
-        TTC_HIP(c, hipMemcpy(pc.d_wh, pf.data(), pf.size() * sizeof(float), hipMemcpyHostToDevice));
-    } else if (pc.mode >= 2) {                 // 16-bit engine: fp16 (2) / bf16 (3) hi | lo LDS images
+    if (pc.mode >= 2) {                 // 16-bit engine: fp16 (2) / bf16 (3) hi | lo LDS images
         std::vector<uint16_t> ph;
         pc.set_stride_h = conv_pack_h16(hwio, nsets, Cin, C0 < 0 ? Cin : C0, Cout, pc.BN, pc.mode == 3, ph, &pc.nchunk_h);
         // + one DMA piece of slack: the last 1-KiB piece of a 32-cout plane is only half used
@@ -436,7 +422,6 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
 }
 
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
-    if (pw.mode == 1) return conv_launch_b3(a, pw, epi, n, s);
     // only the (CK, BN, epilogue) combinations the two graphs need are instantiated
 #define TTC_CONV_CASE(ck, ncg, e) \
     if (pw.CK == ck && pw.BN == ncg * 32 && epi == e) return launch_t<ck, ncg, e>(a, pw, n, s);

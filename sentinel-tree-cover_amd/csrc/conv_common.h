@@ -1,4 +1,4 @@
-// Shared pieces of the two conv engines (conv3x3_mfma.hip: exact fp32 MFMA; conv3x3_bf16x3.hip: split-bf16 MFMA):
+// Shared pieces of the two conv engines (conv3x3_mfma.hip: exact fp32 MFMA; conv3x3_h16.hip: fp16 / bf16 pairs):
 // tile geometry, XCD-aware tile order and the fused epilogues.  Both engines hold the same accumulator layout
 // (v_mfma 32x32 D tile: row = cout (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), column = pixel lane & 31).
 #pragma once

@@ -333,12 +333,10 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
         if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
         const dim3 g16((Hp * Wp + 255) / 256, n);
         const int m = c->blk_mode();
-        if (m == 2) hipLaunchKernelGGL((k_planar_to_b16<2>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
-        else if (m == 1) hipLaunchKernelGGL((k_planar_to_b16<1>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
+        if (m == 1) hipLaunchKernelGGL((k_planar_to_b16<1>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
         else hipLaunchKernelGGL((k_planar_to_b16<0>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
         TTC_HIP(c, hipGetLastError());
-        TTC_CHECK(m == 2 ? dsen2_core_h16<2>(c, x16, bil, n, H, W, res, s)
-                         : (m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, H, W, res, s) : dsen2_core_h16<0>(c, x16, bil, n, H, W, res, s)));
+        TTC_CHECK(m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, H, W, res, s) : dsen2_core_h16<0>(c, x16, bil, n, H, W, res, s));
     } else {
         TTC_CHECK(dsen2_core(c, xin, bil, n, H, W, res, s));
     }
@@ -395,14 +393,12 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
             { KTimer kt(c, "dsen2_gather", s);
               const dim3 gg((Ep * Ep + 255) / 256, sw.n, T);
               const int m = c->blk_mode();
-              if (m == 2) hipLaunchKernelGGL((k_sr_gather_b16<2>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
-              else if (m == 1) hipLaunchKernelGGL((k_sr_gather_b16<1>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
+              if (m == 1) hipLaunchKernelGGL((k_sr_gather_b16<1>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
               else hipLaunchKernelGGL((k_sr_gather_b16<0>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
               hipLaunchKernelGGL(k_sr_bil_tile, dim3((E * E + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, bil);
               TTC_HIP(c, hipGetLastError()); }
             { const int m = c->blk_mode();
-              TTC_CHECK(m == 2 ? dsen2_core_h16<2>(c, x16, bil, n, E, E, res, s)
-                               : (m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, E, E, res, s) : dsen2_core_h16<0>(c, x16, bil, n, E, E, res, s))); }
+              TTC_CHECK(m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, E, E, res, s) : dsen2_core_h16<0>(c, x16, bil, n, E, E, res, s)); }
         } else {
             float* xin = static_cast<float*>(c->scratch_buf("ds_in", sizeof(float) * (size_t)n * 10 * Ep * Ep));
             if (!xin) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");

@@ -8,8 +8,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// BF: 0 = fp16 pair, 1 = bf16 pair, 2 = fp32 blocked (precision 4: the `hi` tensor holds channels 0..3 of a block as fp32,
-// the `lo` tensor channels 4..7 -- same tensors, same indexing, no splitting; see conv3x3_f32b in conv3x3_h16.hip)
+// BF: 0 = fp16 pair, 1 = bf16 pair
 template <int BF> struct Elem;
 template <> struct Elem<0> {
     using v8 = f16x8;
@@ -43,27 +42,15 @@ template <> struct Elem<1> {
 // one channel block (8 channels) of one position: x = hi + lo
 template <int BF>
 __device__ __forceinline__ void b16_store8(uint4* hi, uint4* lo, long u, const float (&v)[8]) {
-    if constexpr (BF == 2) {
-        hi[u] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-        lo[u] = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
-        return;
-    } else {
     using E = Elem<BF>;
     uint4 h, l;
     h.x = E::pack2(v[0], v[1], l.x); h.y = E::pack2(v[2], v[3], l.y);
     h.z = E::pack2(v[4], v[5], l.z); h.w = E::pack2(v[6], v[7], l.w);
     hi[u] = h;
     if (lo) lo[u] = l;
-    }
 }
 template <int BF>
 __device__ __forceinline__ void b16_load8(const uint4* hi, const uint4* lo, long u, float (&v)[8]) {
-    if constexpr (BF == 2) {
-        const uint4 h = hi[u], l = lo[u];
-        v[0] = __uint_as_float(h.x); v[1] = __uint_as_float(h.y); v[2] = __uint_as_float(h.z); v[3] = __uint_as_float(h.w);
-        v[4] = __uint_as_float(l.x); v[5] = __uint_as_float(l.y); v[6] = __uint_as_float(l.z); v[7] = __uint_as_float(l.w);
-        return;
-    } else {
     using E = Elem<BF>;
     const uint4 h = hi[u];
     E::unpack2(h.x, v[0], v[1]); E::unpack2(h.y, v[2], v[3]); E::unpack2(h.z, v[4], v[5]); E::unpack2(h.w, v[6], v[7]);
@@ -73,7 +60,6 @@ __device__ __forceinline__ void b16_load8(const uint4* hi, const uint4* lo, long
         E::unpack2(l.x, t[0], t[1]); E::unpack2(l.y, t[2], t[3]); E::unpack2(l.z, t[4], t[5]); E::unpack2(l.w, t[6], t[7]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += t[k];
-    }
     }
 }
 

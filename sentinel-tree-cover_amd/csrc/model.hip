@@ -783,7 +783,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
     if (c->half()) {
         const int m = c->blk_mode();
-        return m == 2 ? forward_h16<2>(c, n, d_out, s) : (m == 1 ? forward_h16<1>(c, n, d_out, s) : forward_h16<0>(c, n, d_out, s));
+        return m == 1 ? forward_h16<1>(c, n, d_out, s) : forward_h16<0>(c, n, d_out, s);
     }
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
@@ -901,8 +901,7 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
         const long total = (long)n * g.y.n * g.x.n * 8;
         const int m = c->blk_mode();
         const dim3 gte((unsigned)((total + 255) / 256));
-        if (m == 2) hipLaunchKernelGGL((k_tap_early_b16<2>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
-        else if (m == 1) hipLaunchKernelGGL((k_tap_early_b16<1>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
+        if (m == 1) hipLaunchKernelGGL((k_tap_early_b16<1>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
         else hipLaunchKernelGGL((k_tap_early_b16<0>), gte, dim3(256), 0, s, c->gru16, g.y.n, g.x.n, n, g.tr ? 1 : 0, d_early);
     } else if (d_early) {
         const long total = (long)n * g.y.n * g.x.n * 64;

@@ -77,11 +77,7 @@ struct PackedConv {      // device copy of one layer's packed weights
     int Cin = 0, Cout = 0, CK = 0, BN = 0, nsets = 1;
     int nchunk = 0, ncb = 0;
     long set_stride = 0;
-    // split-bf16 engine (ttc_config.precision = 1): LDS-image weights, see conv3x3_bf16x3.hip
-    int mode = 0;                 // 0 = exact fp32 MFMA, 1 = bf16x3
-    uint16_t* d_w3 = nullptr;
-    int nchunk3 = 0;
-    long set_stride3 = 0;         // 16-byte units between weight sets
+    int mode = 0;                 // ttc_config.precision: 0 = exact fp32 MFMA, 2 = fp16 / 3 = bf16 pairs on the 16-bit engine
     // 16-bit engine (precision 2 = fp16, 3 = bf16): LDS-image weights hi | lo per chunk, see conv3x3_h16.hip
     uint4* d_wh = nullptr;
     int nchunk_h = 0;             // 8-channel blocks (padded per input segment)
@@ -142,14 +138,10 @@ long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, i
 int conv_q_blocks(int Hp, int Wp);   // 512-position tiles of a plane
 int conv_stat_slots(int Hp, int Wp); // GroupNorm partial sums per (window, channel quad): one per tile and wave
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
-long conv_pack_b3(const float* const* hwio, int nsets, int Cin, int Cout, int BN, std::vector<uint16_t>& out);
-hipError_t conv_launch_b3(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
 // C0: real channels of the first input segment (its blocks are padded to a multiple of 8 on their own); bf: bf16 elements
 long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, bool bf, std::vector<uint16_t>& out,
                    int* nchunk);
 hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s);   // mode: ttc_ctx::blk_mode()
-// fp32 blocked engine (precision 4): LDS images [set][cout block][chunk][tap][half][cout][4 ch] fp32; returns 16-byte units per set
-long conv_pack_f32b(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, std::vector<float>& out, int* nchunk);
 uint16_t h16_from_float(float f, bool bf);
 float h16_to_float(uint16_t h, bool bf);
 struct ttc_ctx;
@@ -207,8 +199,8 @@ struct ttc_ctx {
     ttc_status fail(ttc_status s, const std::string& m) { err = m; return s; }
     float* alloc_f(size_t n, const char* name = nullptr);
     bool alloc_b16(B16& b, size_t units);       // hi + lo tensors of `units` 16-byte K vectors each
-    bool half() const { return cfg.precision >= 2; }      // channel-blocked conv engine selected (16-bit pairs or fp32 blocked)
-    int blk_mode() const { return cfg.precision == 3 ? 1 : (cfg.precision == 4 ? 2 : 0); }   // Elem<> mode: fp16 / bf16 / f32 blocked
+    bool half() const { return cfg.precision >= 2; }      // 16-bit conv engine selected (channel-blocked hi / lo pairs)
+    int blk_mode() const { return cfg.precision == 3 ? 1 : 0; }   // Elem<> mode: fp16 / bf16
     void* scratch_buf(const std::string& key, size_t bytes);
     void* pinned_buf(const std::string& key, size_t bytes);
 };

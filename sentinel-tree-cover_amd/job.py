@@ -62,8 +62,8 @@ class TTCSession:
                  dsen2_weights="package", precision="fp32", win_rows=0, one_term_layers=None):
         """precision: "fp32" = exact fp32 MFMA chains (default); "fp16" / "bf16" = the 16-bit engine (conv inputs stored
         as hi + lo 16-bit pairs, fp32 accumulate; per layer three split products or one, `one_term_layers` bit mask as in
-        ttc.h -- default: fp16 runs only the ConvGRU gates conv with plain fp16 operands, bf16 none);
-        "bf16x3" = the round-1 split-bf16 engine on fp32 activations."""
+        ttc.h -- default 0: EVERY layer multiplies three products; any single layer on one plain fp16 product measured
+        3.0e-3 .. 2.7e-2 max |dprob| on a real tile, outside the 1e-3 contract)."""
         prec = _lib.PRECISIONS.get(precision, precision)
         # win_rows: rows of a non-square window (the 220 x 684 border graph of resegment_tiles_wide.py); 0 = square
         self.ctx = _lib.Context(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout,

@@ -7,7 +7,7 @@ Tolerances on probabilities (BASELINE.json's contract is 1e-3):
   fp16, three split products in every layer ("fp16x3", one_term_layers = 0): operands carry 22 mantissa bits -> fp32-class, 1e-4
   fp16 with the ConvGRU gates conv on plain fp16 operands (one_term_layers = 1, NOT the default: 3e-3 on a real tile):
                                                                              white-noise windows 2e-4 .. 6.5e-4 -> 1e-3
-  bf16, three split products (16 mantissa bits):                              2.5e-4 like the round-1 bf16x3 engine
+  bf16, three split products (16 mantissa bits):                              2.5e-4
 """
 import numpy as np
 import pytest
@@ -16,7 +16,7 @@ from tests.helpers import synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = [("fp16", None, 1e-4), ("fp16", 1, 1e-3), ("bf16", None, 2.5e-4), ("fp32b", None, 5e-5)]
+MODES = [("fp16", None, 1e-4), ("fp16", 1, 1e-3), ("bf16", None, 2.5e-4)]
 
 
 def _setup(W, L, N, seed, precision, one_term, stored=True, dtype64=True):
@@ -52,7 +52,7 @@ def test_forward_16bit_matches_oracle(W, L, N, precision, one_term, tol):
     np.testing.assert_array_equal(out, ctx.forward_windows(x).cpu().numpy())        # deterministic
 
 
-@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp32b"])
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_single_step_intermediates_16bit(precision):
     """L = 1, three products everywhere: every raw conv output of the first ConvGRU step and of the U-Net against the
     float64 oracle, relative to the tensor's own scale (as-stored kernels make raw outputs O(10..100))."""
@@ -103,7 +103,7 @@ def test_feature_taps_16bit(precision, one_term, tol):
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp16", 2e-5), ("bf16", 1e-4), ("fp32b", 2e-6)])
+@pytest.mark.parametrize("precision,tol", [("fp16", 2e-5), ("bf16", 1e-4)])
 def test_dsen2_16bit(precision, tol):
     """DSen2-lite (real weights) on the 16-bit engine, three products per layer: window forward, ragged / tiny windows
     (clamped DMA tails, rim kernel for planes too small for the fused reflect rim) and the whole-tile driver."""
@@ -128,7 +128,7 @@ def test_dsen2_16bit(precision, tol):
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("precision,size,length", [("fp32", 158, 4), ("fp16", 158, 4), ("bf16", 158, 4), ("fp16", 154, 12), ("fp32b", 158, 4)])
+@pytest.mark.parametrize("precision,size,length", [("fp32", 158, 4), ("fp16", 158, 4), ("bf16", 158, 4), ("fp16", 154, 12)])
 def test_tile_16bit_vs_oracle(precision, size, length):
     """Whole 618^2 tile (36 windows of size + 14, L steps) on the 16-bit engine against the fp32 oracle: window probabilities
     BEFORE the reference's 3-decimal rounding within the 1e-3 contract, identical no-data, uint8 raster within one count.

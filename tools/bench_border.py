@@ -2,7 +2,7 @@
 production size on one MI355X: two 618 x 618 tiles with T dates as process_tile returns them (resident in HBM) ->
 four re-predicted 220 x 684 windows -> both tiles' rasters re-mosaicked.  Prints one JSON line.
 
-    python tools/bench_border.py [--precision fp32|bf16x3] [--dates 12] [--iters 5] [--separate]
+    python tools/bench_border.py [--precision fp32|fp16|bf16] [--dates 12] [--iters 5] [--separate]
 """
 import argparse
 import importlib

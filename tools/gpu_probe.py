@@ -9,7 +9,7 @@ from ttc import _lib, synth, weights
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 172
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 36
-PREC = sys.argv[4] if len(sys.argv) > 4 else "fp32"        # fp32 | bf16x3 | fp16 | bf16
+PREC = sys.argv[4] if len(sys.argv) > 4 else "fp32"        # fp32 | fp16 | bf16
 MASK = int(sys.argv[5], 0) if len(sys.argv) > 5 else None     # one_term_layers of the 16-bit engine
 ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=PREC, one_term_layers=MASK)
 ctx.load_weights(weights.synth_weights(0))

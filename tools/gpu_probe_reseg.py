@@ -1,5 +1,5 @@
 """Timing probe for the border resegmentation at production size (SIZE = 670, SIZE_Y = 206, 618-row strip):
-python tools/gpu_probe_reseg.py [fp32|bf16x3]"""
+python tools/gpu_probe_reseg.py [fp32|fp16|bf16]"""
 import importlib
 import os
 import sys

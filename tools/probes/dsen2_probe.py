@@ -3,7 +3,7 @@ import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ttc import job
-for prec in sys.argv[1:] or ["fp32", "fp32b", "fp16"]:
+for prec in sys.argv[1:] or ["fp32", "fp16", "bf16"]:
     sess = job.TTCSession(None, win_in=44, length=2, max_windows=1, precision=prec)
     rng = np.random.default_rng(0)
     d = torch.from_numpy((rng.random((12, 618, 618, 10)) * 0.6).astype(np.float32)).cuda()
