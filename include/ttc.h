@@ -211,25 +211,37 @@ ttc_status ttc_clip01(ttc_ctx* ctx, float* d_a, int64_t n, void* stream);
 ttc_status ttc_divide(ttc_ctx* ctx, float* d_a, int64_t n, float divisor, void* stream);
 
 /* ---- whole tile in ONE call -------------------------------------------------------------------------------------------------
- * The chain the job runs per tile -- process_tile's numeric flow from the raw arrays (to_float32 tof_downloading.py:64-72,
- * convert_to_db job.py:74-89 / :699-708, the 20 m -> 10 m bilinear :734-782, [identify_clouds_shadows cloud_removal.py:1215-1677],
- * remove_cloud_and_shadows :888-973), superresolve_large_tile (job.py:95-147), process_subtiles (:1125-1483) and
- * load_mosaic_predictions (:1515-1641) -- enqueued on `stream` WITHOUT any host round trip: the date screening of
- * deal_w_missing_px (job.py:1031-1037) and the 12 x T temporal operator are formed on the device, the gap-fill uses the
- * deterministic expected-multiplicity sampler, and the two rare data-dependent host decisions of the staged path are taken
- * speculatively and REPORTED instead:
+ * The chain the job runs per tile (job.py:1995-2020) for a tile on which none of process_tile's date-DROPPING rules fires,
+ * enqueued on `stream` WITHOUT any host round trip:
+ *   to_float32 (tof_downloading.py:64-72), convert_to_db (job.py:74-89 / :699-708), the 20 m -> 10 m bilinear (:734-782),
+ *   [identify_clouds_shadows (cloud_removal.py:1215-1677) with TTC_TILE_DETECT, else the GIVEN mask],
+ *   remove_cloud_and_shadows (:888-973) with the deterministic expected-multiplicity sampler, the final np.clip(., 0, 1)
+ *   (job.py:993), superresolve_large_tile (:95-147), process_subtiles (:1125-1483; the date screening of deal_w_missing_px
+ *   :1031-1037 and the 12 x T temporal operator are formed on the device), load_mosaic_predictions (:1515-1641).
+ * NOT in the call: the DEM median filter / division (d_dem is passed as process_tile returns it), the Sen2Cor mask (merge
+ * it into d_mask beforehand; with TTC_TILE_DETECT a tile that has one goes through the staged calls), the snow map
+ * (an output of process_tile nothing downstream reads), and every rule of process_tile that REMOVES dates -- those change
+ * T and re-run the detection, so the call evaluates their conditions on the device, carries on speculatively with all
+ * dates, and REPORTS them.  The caller reads d_status after synchronising the stream; if d_status[0], [2] or [3] is
+ * non-zero the rasters are NOT the reference's and the tile must be re-run through the staged calls
+ * (job.predict_tile_raw_checked does exactly that):
  *   d_status[0] != 0  a date could not be radiometrically aligned (cloud_removal.py:679-680: it marks itself fully
- *                     interpolated, which changes every later date): the rasters are NOT the reference's; re-run this tile
- *                     through the staged calls (ttc_remove_cloud_and_shadows takes that branch itself)
- *   d_status[1]       dates that survived the missing-pixel screening (< 2 -> every window is 255, like job.py:1418-1422)
- *   d_status[2] != 0  the gap-fill flagged dates as fully interpolated; the job deletes them before process_subtiles
- *                     (job.py:964-981) -- re-run through the staged calls
+ *                     interpolated, which changes every later date; ttc_remove_cloud_and_shadows takes that branch itself)
+ *   d_status[1]       dates that survived the missing-pixel screening (< 2 -> every window is 255, like job.py:1418-1422);
+ *                     informational
+ *   d_status[2] != 0  number of dates the gap-fill flagged as fully interpolated; the job deletes them before
+ *                     process_subtiles (job.py:964-981)
+ *   d_status[3]       bit mask of process_tile's other date-dropping rules: 1 = a date has >= X^2 / 2 missing pixels
+ *                     (id_missing_px(., 2), job.py:786); 2 = more than 10 dates are > 25 % snow (:822); 4 = the feathered mask
+ *                     of a date covers > 90 % of the tile (:866-921; evaluated on the closing-20 weights, which bound the
+ *                     closing-15 weights of id_areas_to_interp from above: conservative, never missed)
  * d_s2_10 [T, X, Y, 4] / d_s2_20 [T, X/2, Y/2, 6] / d_s1 [12, X, Y, 2] uint16 as stored in temp/raw (device memory);
  * d_dem [X, Y] as process_tile returns it (median-filtered, / 90); d_dem_m the same in metres (detection only, may be NULL);
  * d_mask [T, X, Y] the cloud + shadow mask (ignored with TTC_TILE_DETECT); d_dates [T] int32 day of year, DEVICE memory.
  * d_out_u8 [X, Y] uint8 (transposed like the reference's mosaic, 255 = no data), d_out_f32 the float percent raster or NULL;
  * d_model_in (optional) receives the model's input frames [36, L+1, 17, W+2, W+2] (planar, padded: what ttc_debug_fetch
- * "frames" returns).  flags: TTC_TILE_*. */
+ * "frames" returns).  ttc_debug_fetch "pt_windows" / "pt_windows_raw" [36, size, size]: the per-window arrays the reference
+ * np.save()s, and the same before np.around / the bright-surface product.  flags: TTC_TILE_*. */
 #define TTC_TILE_DETECT 1        /* run the multi-temporal cloud / shadow detection and gap-fill with its mask           */
 #define TTC_TILE_INPUTS_ONLY 2   /* stop after the model inputs are assembled: preprocessing only (BASELINE configs[2])   */
 #define TTC_TILE_NO_SUPERRES 4   /* skip the DSen2 super-resolution                                                     */

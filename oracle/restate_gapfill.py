@@ -142,8 +142,29 @@ def reference_sampler(evi_vals, n_rows, rng=random):
     return sample[:n_rows]
 
 
+def expected_weights(evi_vals, n_rows):
+    """sampler = "expected" (the product's default, gapfill.hip k_row_weights_all): instead of DRAWING reference_sampler's
+    sample, every candidate row enters the fit with its EXPECTED multiplicity under that scheme -- a quintile stratum of
+    c rows is cut to n_i = min(90000, n) // 5 after a shuffle, so each of its rows survives with probability
+    min(1, n_i / c); the 2 % tails are appended ten times each.  (The final `sample[:n_rows]` cut after the last shuffle
+    scales every expectation by the same factor, which leaves a least-squares solution unchanged.)  Thresholds are the
+    reference's np.percentile values on the float32 EVI column."""
+    n_i = np.minimum(90000, n_rows) // 5
+    b2, b20, b40, b60, b80, b98 = (np.percentile(evi_vals, q) for q in (2, 20, 40, 60, 80, 98))
+    stratum = ((evi_vals >= b20).astype(int) + (evi_vals >= b40) + (evi_vals >= b60) + (evi_vals >= b80))
+    cnt = np.bincount(stratum, minlength=5)
+    w = np.minimum(1.0, n_i / np.maximum(cnt, 1).astype(np.float64))[stratum]
+    w[cnt[stratum] == 0] = 0.0
+    w = w.astype(np.float32)
+    w[evi_vals < b2] += 10.0
+    w[evi_vals >= b98] += 10.0
+    return w
+
+
 def align_date(fill, array, date, interp, mosaic, water_mask, sampler=reference_sampler):
-    """CR.py:316-575 for one date: returns (prediction [H,W,10] to blend in, flagged)."""
+    """CR.py:316-575 for one date: returns (prediction [H,W,10] to blend in, flagged).
+    sampler: a callable (evi, n_rows) -> row indices (the reference draws them with the stdlib RNG), or the string
+    "expected": weighted least squares with expected_weights() above, no RNG."""
     T, H, W, B = array.shape
     snow = np.mean(snow_prob(array), axis=0)[..., np.newaxis]
     if not (np.sum(interp[date] > 0) > 0 and np.sum(interp[date] == 0) > 0):
@@ -165,15 +186,24 @@ def align_date(fill, array, date, interp, mosaic, water_mask, sampler=reference_
         X, Y = xs[0], ys[0]
     else:
         X, Y = np.concatenate(xs, axis=0), np.concatenate(ys, axis=0)
-    idx = sampler(evi_unclipped(Y), X.shape[0])
-    X, Y = X[idx], Y[idx]
+    if isinstance(sampler, str):
+        assert sampler == "expected", sampler
+        sw = np.sqrt(expected_weights(evi_unclipped(Y), X.shape[0]).astype(np.float64))[:, np.newaxis]
+        X, Y = np.copy(X), np.copy(Y)
+    else:
+        idx = sampler(evi_unclipped(Y), X.shape[0])
+        X, Y = X[idx], Y[idx]
+        sw = None
     out = np.copy(fill)
     full = np.concatenate([fill, snow], axis=-1).reshape(H * W, B + 1)
     sel = np.logical_and(interp[date] > 0, water_mask <= 1)
     for band in range(10):
         train_x = np.copy(X)
         X[..., band] = np.clip(X[..., band], 0.005, 1)        # AFTER the copy (CR.py:550): band b is fitted on
-        beta, _ = nnls(train_x.astype(np.float64), Y[..., band].astype(np.float64))   # cols < b clipped, >= b raw
+        if sw is None:
+            beta, _ = nnls(train_x.astype(np.float64), Y[..., band].astype(np.float64))   # cols < b clipped, >= b raw
+        else:                                                                             # min sum_i w_i (y_i - x_i . beta)^2
+            beta, _ = nnls(train_x.astype(np.float64) * sw, Y[..., band].astype(np.float64) * sw[:, 0])
         pred = (full.astype(np.float64) @ beta).reshape(H, W)
         out[sel, band] = pred[sel]
     return out, []

@@ -39,19 +39,25 @@ def snow_flags(s2):
     return p > 0
 
 
-def process_tile_arrays(raw, forest=None, urban=None, sampler=G.reference_sampler):
+def process_tile_arrays(raw, forest=None, urban=None, sampler=G.reference_sampler, cloudshad=None):
     """raw: dict with s2_10 / s2_20 / s1 (uint16), dem (metres), dates, clouds, clm (20 m mask or None).
-    -> (sentinel2, dates, interp, s1, dem / 90, cloudshad, snow) like process_tile (make_shadow=True)."""
+    -> (sentinel2, dates, interp, s1, dem / 90, cloudshad, snow) like process_tile (make_shadow=True).
+    cloudshad [T, X, Y] (optional): a GIVEN cloud + shadow mask stands in for identify_clouds_shadows (job.py:839 and the
+    re-detections after dates are dropped return its surviving dates; no false-positive mask) -- the flow of the single-call
+    tile entry's staged fall-back."""
+    given = None if cloudshad is None else np.array(cloudshad, dtype=np.float32, copy=True)
     clm = clean_sen2cor_mask(np.array(raw["clm"], copy=True)) if raw.get("clm") is not None else None
     s1 = R.s1_to_db(raw["s1"])
     s2_10, s2_20 = R.to_float32(raw["s2_10"]), R.to_float32(raw["s2_20"])
     dem = ndi.median_filter(np.array(raw["dem"], copy=True), size=5)
     dates = np.array(raw["dates"], copy=True)
-    clouds = np.array(raw["clouds"], copy=True)
+    clouds = np.array(raw["clouds"], copy=True) if raw.get("clouds") is not None else np.zeros((len(dates), 1, 1), np.float32)
     s2 = R.upsample_20m(s2_10, s2_20)
 
     def drop(idx):
-        nonlocal clouds, dates, s2, clm
+        nonlocal clouds, dates, s2, clm, given
+        if given is not None:
+            given = np.delete(given, idx, axis=0)
         if clouds.shape[0] == len(dates):
             clouds = np.delete(clouds, idx, axis=0)
         dates = np.delete(dates, idx)
@@ -71,9 +77,12 @@ def process_tile_arrays(raw, forest=None, urban=None, sampler=G.reference_sample
     s2 = R.interpolate_missing_vals(s2)
 
     def detect(first):
-        cs, fc = C.identify_clouds_shadows(s2, dem, forest, urban)
+        if given is not None:
+            cs, fc = given.copy(), None
+        else:
+            cs, fc = C.identify_clouds_shadows(s2, dem, forest, urban)
         if clm is not None:
-            if first:
+            if first and fc is not None:
                 clm[fc] = 0.
             cs = np.maximum(cs, clm)
         return cs, fc
@@ -89,7 +98,7 @@ def process_tile_arrays(raw, forest=None, urban=None, sampler=G.reference_sample
             if rnd < 2:
                 interp = G.id_areas_to_interp(cloudshad)
     interp = G.id_areas_to_interp(cloudshad)
-    s2, interp, to_remove = G.remove_cloud_and_shadows(s2, cloudshad, fcps, sampler)
+    s2, interp, to_remove = G.remove_cloud_and_shadows(s2, cloudshad, fcps if fcps is not None else np.zeros(s2.shape[1:3], bool), sampler)
     if len(to_remove) > 0:
         drop(to_remove)
         interp = np.delete(interp, to_remove, axis=0)

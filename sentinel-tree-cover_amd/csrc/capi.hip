@@ -89,6 +89,7 @@ void ttc_destroy(ttc_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& kv : c->scratch) (void)hipFree(kv.second.first);
     for (auto& kv : c->pinned) (void)hipHostFree(kv.second.first);
+    for (hipEvent_t e : c->wmat_events) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -241,7 +242,10 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
     }
     const int n_win = (int)xy.size() / 2;
     float* windows = static_cast<float*>(c->scratch_buf("pt_windows", sizeof(float) * (size_t)n_win * size * size));
-    if (!windows) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+    float* windows_raw = static_cast<float*>(c->scratch_buf("pt_windows_raw", sizeof(float) * (size_t)n_win * size * size));
+    if (!windows || !windows_raw) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+    c->named["pt_windows"] = {windows, (size_t)n_win * size * size};           // what the reference np.save()s per window
+    c->named["pt_windows_raw"] = {windows_raw, (size_t)n_win * size * size};   // before np.around / the bright-surface product
     TTC_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t) * 4, s));
     TTC_CHECK(codec_u16_to_f32(c, d_s2_10, (int64_t)T * npix * 4, f10, s));             // tof_downloading.py:64-72
     TTC_CHECK(codec_u16_to_f32(c, d_s2_20, (int64_t)T * h * w * 6, f20, s));
@@ -257,9 +261,10 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
         mask = clouds; pf = fcps;
     }
     c->spec_status = d_status;                     // the speculative stages report into it instead of waiting for the host
-    ttc_status st = gapfill_remove_clouds(c, s2, mask, pf, T, X, Y, nullptr, nullptr, interp, nullptr, nullptr, nullptr, s);   // cloud_removal.py:888-973
+    // cloud_removal.py:888-973; with spec_status set the blend also applies process_tile's final np.clip(sentinel2, 0, 1) (job.py:993)
+    ttc_status st = gapfill_remove_clouds(c, s2, mask, pf, T, X, Y, nullptr, nullptr, interp, nullptr, nullptr, nullptr, s);
     if (st == TTC_OK && !(flags & TTC_TILE_NO_SUPERRES)) st = dsen2_tile(c, s2, T, X, Y, 1, 110, 10, s);                       // job.py:95-147
-    if (st == TTC_OK) st = tile_process_subtiles_dev(c, s2, T, X, Y, d_dates, interp, s1db, d_dem, h_min, h_max, size, windows, nullptr,
+    if (st == TTC_OK) st = tile_process_subtiles_dev(c, s2, T, X, Y, d_dates, interp, s1db, d_dem, h_min, h_max, size, windows, windows_raw,
                                                      inputs_only, s);                                                         // job.py:1125-1483
     c->spec_status = nullptr;
     TTC_CHECK(st);

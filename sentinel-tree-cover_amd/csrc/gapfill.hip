@@ -224,11 +224,6 @@ struct SrcMosaic {      // q = band*4 + which*2 + rank ; which 0 -> ref[p][band]
         return true;
     }
 };
-struct SrcEvi {         // every problem selects from the same EVI row list
-    const float* evi; const DatePlan* plan;
-    __device__ int count() const { return plan->nrows; }
-    __device__ bool get(int, int p, float& v) const { v = evi[p]; return true; }
-};
 struct SrcBlueRed {     // q = band2*2 + rank ; band2 0 -> mosaic blue, 1 -> mosaic red ; set = ~only1
     const float* mosaic; const unsigned char* only1; int npix;
     __device__ int count() const { return npix; }
@@ -356,10 +351,28 @@ __device__ __forceinline__ float snow_prob_px(const float* v) {           // CR.
 // The mean snow probability is re-evaluated for every date because the stack is blended in place (CR.py:372); only ONE
 // date changes between evaluations, so the per-date probabilities are cached and the mean re-sums T floats per pixel
 // (same values, same order) instead of re-reading the whole stack.
-__global__ void k_snow_prob_all(const float* __restrict__ tiles, int T, int npix, float* __restrict__ snowp) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)T * npix) return;
-    snowp[i] = snow_prob_px(tiles + i * 10);
+// screen (single-call tile path, else nullptr) [T][2]: per date, the two counts behind process_tile's date screening that
+// this pass sees for free -- pixels with snow_filter(...) true (job.py:799-818: the same ramp, as a flag) and "missing" pixels
+// (id_missing_px, interpolation.py:5-23: more than one band == 0 or >= 1)
+__global__ void k_snow_prob_all(const float* __restrict__ tiles, int npix, float* __restrict__ snowp, int* __restrict__ screen) {
+    const int t = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int sn = 0, miss = 0;
+    if (p < npix) {
+        const float* v = tiles + ((long)t * npix + p) * 10;
+        const float pr = snow_prob_px(v);
+        snowp[(long)t * npix + p] = pr;
+        if (screen) {
+            int bad = 0;
+#pragma unroll
+            for (int b = 0; b < 10; ++b) bad += (v[b] == 0.0f) + (v[b] >= 1.0f);
+            sn = pr > 0.f; miss = bad > 1;
+        }
+    }
+    if (screen) {
+        for (int k = 32; k >= 1; k >>= 1) { sn += __shfl_xor(sn, k); miss += __shfl_xor(miss, k); }
+        if ((threadIdx.x & 63) == 0) { if (sn) atomicAdd(&screen[2 * t], sn); if (miss) atomicAdd(&screen[2 * t + 1], miss); }
+    }
 }
 __global__ void k_snow_mean_cached(const float* __restrict__ snowp, int T, int npix, float* __restrict__ snow) {
 #pragma clang fp contract(off)
@@ -524,7 +537,7 @@ __global__ void k_gram_reduce(const double* __restrict__ partial, int nblk, doub
 struct Beta { double b[10][11]; int fitted; };
 __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restrict__ w, const float* __restrict__ mosaic,
                                 const float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date,
-                                float* __restrict__ snowp, int T = 0) {
+                                float* __restrict__ snowp, int T = 0, int clip01 = 0) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -541,6 +554,7 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
     }
     const double sn = (double)snf;
     const Beta& be = *bep;
+    float bl[10];
     for (int c = 0; c < 10; ++c) {
         float pred = mv[c];
         if (be.fitted) {
@@ -550,9 +564,13 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
             s += sn * be.b[c][10];
             pred = (float)s;
         }
-        tv[c] = tv[c] * (1.0f - wd) + pred * wd;
+        bl[c] = tv[c] * (1.0f - wd) + pred * wd;
     }
-    snowp[(long)date * npix + p] = snow_prob_px(tv);           // keep the cache of this date current
+    snowp[(long)date * npix + p] = snow_prob_px(bl);           // keep the cache of this date current (unclipped values)
+    // clip01 (single-call tile path): process_tile's final np.clip(sentinel2, 0, 1) (job.py:993) applied at the only place a
+    // value can leave [0, 1] -- decoded uint16 / 65535 and their bilinear means cannot, an NNLS prediction can.  Nothing in
+    // the rest of the gap-fill reads a blended pixel (training rows have w == 0), so clipping here equals clipping at the end.
+    for (int c = 0; c < 10; ++c) tv[c] = clip01 ? fminf(fmaxf(bl[c], 0.f), 1.f) : bl[c];
 }
 
 // ------------------------------------------------------------------------------------------------ a9
@@ -587,9 +605,25 @@ __global__ void k_add_clouds(float* __restrict__ w, const unsigned char* __restr
     for (int t = 0; t < T; ++t) { float v = w[(long)t * npix + p] + 1.0f; w[(long)t * npix + p] = v > 1.f ? 1.f : v; }
 }
 // ---- device-side control of the per-date fit (no host round trips) --------------------------------
-__global__ void k_date_plan(const int* __restrict__ counters, int npix, int T, DatePlan* __restrict__ plans,
-                            int* __restrict__ remove_flags) {
+// screen / spec (single-call tile path, else nullptr): the date-dropping rules of process_tile that the single call cannot
+// take (they change T and re-run the detection) are evaluated here and reported in spec[3]:
+//   1  a date has >= X^2 / 2 missing pixels                      (id_missing_px(sentinel2, 2), job.py:786)
+//   2  more than 10 dates are > 25 % snow                         (job.py:822-824)
+//   4  the feather weights of a date cover > 90 % of the tile     (job.py:866 and the two repeats; tested on the closing-20
+//      weights, which are >= the closing-15 weights of id_areas_to_interp pixel by pixel: conservative)
+__global__ void k_date_plan(const int* __restrict__ counters, int npix, int X, int T, DatePlan* __restrict__ plans,
+                            int* __restrict__ remove_flags, const int* __restrict__ screen, int* __restrict__ spec) {
     const int date = threadIdx.x;
+    if (spec && date == 0) {
+        int bits = 0, snowy = 0;
+        for (int t = 0; t < T; ++t) {
+            snowy += ((double)screen[2 * t] / (double)npix) > 0.25;
+            if ((double)screen[2 * t + 1] >= ((double)X * (double)X) / 2.0) bits |= 1;
+            if (((double)counters[4 * t] / (double)npix) > 0.9) bits |= 4;
+        }
+        if (snowy > 10) bits |= 2;
+        spec[3] = bits;
+    }
     if (date >= T) return;
     counters += date * 4;
     DatePlan* plan = plans + date;
@@ -607,40 +641,7 @@ __global__ void k_date_plan(const int* __restrict__ counters, int npix, int T, D
     remove_flags[date] = (c2 == 0);                                                // CR.py:958-959
 }
 struct StrataDev { float b[6]; int cnt[5]; };
-__global__ void k_strata_thresholds(const SelState* __restrict__ st, const DatePlan* __restrict__ plan, PctList pl,
-                                    StrataDev* __restrict__ sd) {
-    if (threadIdx.x) return;
-    const long long n = plan->nrows;
-    for (int k = 0; k < 6; ++k) {
-        const double pos = n > 0 ? pl.pct[k] / 100.0 * (double)(n - 1) : 0.0;
-        const double a = fkey_inv(st[2 * k].prefix), b = fkey_inv(st[2 * k + 1].prefix);
-        sd->b[k] = (float)(a + (b - a) * (pos - floor(pos)));
-    }
-    for (int k = 0; k < 5; ++k) sd->cnt[k] = 0;
-}
 __device__ __forceinline__ int stratum_of(float e, const float* b) { return e < b[1] ? 0 : (e < b[2] ? 1 : (e < b[3] ? 2 : (e < b[4] ? 3 : 4))); }
-__global__ void k_strata_count(const float* __restrict__ evi, const DatePlan* __restrict__ plan, StrataDev* __restrict__ sd) {
-    __shared__ int c[5];
-    if (threadIdx.x < 5) c[threadIdx.x] = 0;
-    __syncthreads();
-    const int n = plan->nrows;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&c[stratum_of(evi[i], sd->b)], 1);
-    __syncthreads();
-    if (threadIdx.x < 5 && c[threadIdx.x]) atomicAdd(&sd->cnt[threadIdx.x], c[threadIdx.x]);
-}
-__global__ void k_row_weights_dev(const float* __restrict__ evi, const DatePlan* __restrict__ plan, const StrataDev* __restrict__ sd,
-                                  float* __restrict__ weight) {
-    const int n = plan->nrows;
-    const double n_i = (double)(min(90000, n) / 5);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float e = evi[i];
-        const int cn = sd->cnt[stratum_of(e, sd->b)];
-        float w = cn > 0 ? (float)fmin(1.0, n_i / (double)cn) : 0.f;
-        if (e < sd->b[0]) w += 10.f;
-        if (e >= sd->b[5]) w += 10.f;
-        weight[i] = w;
-    }
-}
 
 // ---- date-batched form of the per-date fit (device sampler) ------------------------------------------------------
 // A training row is a pixel with w_t == 0, and the blend only ever writes pixels with w_d > 0 of date d: the row
@@ -1391,15 +1392,15 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     int* rows_all = static_cast<int*>(c->scratch_buf("gf_rows", sizeof(int) * 3 * (size_t)npix * T));
     float* snowp = static_cast<float*>(c->scratch_buf("gf_snowp", sizeof(float) * (size_t)npix * T));
     float* evi = static_cast<float*>(c->scratch_buf("gf_evi", sizeof(float) * 3 * (size_t)npix));
-    float* weight = static_cast<float*>(c->scratch_buf("gf_weight", sizeof(float) * 3 * (size_t)npix));
     const int nblk_rows = (3 * npix + 255) / 256;
-    int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * ((size_t)nblk_rows * T + 16 + 4 * kMaxT)));
+    int* blk = static_cast<int*>(c->scratch_buf("gf_blk", sizeof(int) * ((size_t)nblk_rows * T + 16 + 6 * kMaxT)));
     const int gram_blocks = 1024;
     double* gpart = static_cast<double*>(c->scratch_buf("gf_gram", sizeof(double) * 1024 * (gram_blocks + 1)));
-    if (!mosaic || !snow || !water2 || !bits || !rows_all || !snowp || !evi || !weight || !blk || !gpart)
+    if (!mosaic || !snow || !water2 || !bits || !rows_all || !snowp || !evi || !blk || !gpart)
         return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
     int* counters = blk + (size_t)nblk_rows * T;                         // a9: [3] total rows, [4] n_only
     int* date_counts = counters + 16;                                    // [T][4]: n(w > 0), n(w == 0), n(w < 1)
+    int* screen = date_counts + 4 * kMaxT;                               // [T][2]: snow-flag pixels, missing pixels (single-call path)
     if (n_to_remove) *n_to_remove = 0;
     const dim3 grid((npix + 255) / 256), b256(256);
 
@@ -1410,25 +1411,25 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     if (!ctl) return c->fail(TTC_ERR_NOMEM, "gap-fill control block");
     DatePlan* plans = reinterpret_cast<DatePlan*>(ctl + 32768);            // [kMaxT]
     Beta* d_beta = reinterpret_cast<Beta*>(ctl + 64);                      // 888 B
-    StrataDev* sd = reinterpret_cast<StrataDev*>(ctl + 1024);
     SelState* st = reinterpret_cast<SelState*>(ctl + 2048);                // 12 problems
     float* thr = reinterpret_cast<float*>(ctl + 3072);
     int* remove_flags = reinterpret_cast<int*>(ctl + 3200);                // kMaxT ints
     unsigned* hist = reinterpret_cast<unsigned*>(ctl + 4096);              // 12 * 256 * 4 = 12288 B
     double* Zdev = gpart + 1024L * gram_blocks;
     TTC_HIP(c, hipMemsetAsync(ctl, 0, 4096 + 12288, s));
-    TTC_HIP(c, hipMemsetAsync(date_counts, 0, sizeof(int) * 4 * kMaxT, s));
+    TTC_HIP(c, hipMemsetAsync(date_counts, 0, sizeof(int) * 6 * kMaxT, s));
     const PctList pl6{{2, 20, 40, 60, 80, 98, 0, 0}};
     const int nb3 = (int)((3L * npix + 255) / 256);
 
     KTimer kt(c, "gapfill_dates", s);
     // date-loop invariants, all dates at once: clear-pixel counts -> plans (which dates train which fit) -> row lists
+    int* const spec = c->spec_status;            // single-call tile path: report instead of deciding on the host
+    hipLaunchKernelGGL(k_snow_prob_all, dim3((unsigned)((npix + 255) / 256), T), b256, 0, s, d_tiles, npix, snowp, spec ? screen : nullptr);
     hipLaunchKernelGGL(k_date_counts_all, dim3(32, T), b256, 0, s, d_interp, npix, date_counts);
-    hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, date_counts, npix, T, plans, remove_flags);
+    hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, date_counts, npix, X, T, plans, remove_flags, screen, spec);
     hipLaunchKernelGGL(k_rows_count, dim3(nb3, T), b256, 0, s, d_interp, water2, npix, 0, 0, plans, blk);
     hipLaunchKernelGGL(k_rows_scan, dim3(T), dim3(1024), 0, s, blk, nb3, &plans->nrows, (int)(sizeof(DatePlan) / sizeof(int)));
     if (sampler) hipLaunchKernelGGL(k_rows_fill, dim3(nb3, T), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plans, blk, rows_all, (float*)nullptr);
-    hipLaunchKernelGGL(k_snow_prob_all, dim3((unsigned)(((long)T * npix + 255) / 256)), b256, 0, s, d_tiles, T, npix, snowp);
     TTC_HIP(c, hipGetLastError());
     if (!sampler) {
         // device sampler: everything that does not depend on the blended stack for all dates at once (see k_gram_snow)
@@ -1464,7 +1465,8 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
             hipLaunchKernelGGL(k_gram_snow, dim3(kSnowBlocks), b256, 0, s, d_tiles, mosaic, snowp, rows_all + (size_t)date * 3 * npix,
                                weight_all + (size_t)date * 3 * npix, plan, T, npix, spart, spart + 32 * kSnowBlocks, ticket);
             hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Z0 + 1024L * date, plan, d_beta, spart + 32 * kSnowBlocks, 1);
-            hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, (const float*)nullptr, d_beta, npix, date, snowp, T);
+            hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, (const float*)nullptr, d_beta, npix, date, snowp, T,
+                               spec ? 1 : 0);
         }
         TTC_HIP(c, hipGetLastError());
     }
@@ -1476,8 +1478,7 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
         hipLaunchKernelGGL(k_snow_mean_cached, grid, b256, 0, s, snowp, T, npix, snow);       // CR.py:372 (tiles mutate per date)
         hipLaunchKernelGGL(k_rows_evi, dim3(256), b256, 0, s, rows, plan, d_tiles, npix, evi);
         GramArgs ga{d_tiles, mosaic, snow, rows, nullptr, nullptr, 0, npix, 0, plan};
-        if (sampler) {
-            // reference replay: host round trip through the callback, which returns row indices
+        {   // reference replay: host round trip through the callback, which returns row indices
             DatePlan hp;
             TTC_HIP(c, hipMemcpyAsync(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost, s));
             TTC_HIP(c, hipStreamSynchronize(s));
@@ -1499,14 +1500,6 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
                 TTC_HIP(c, hipStreamSynchronize(s));
                 ga.sample = d_sample; ga.nsample = ns; ga.t0 = hp.t0; ga.plan = nullptr;
             }
-        } else {
-            // expected multiplicities: EVI percentiles by radix select, strata counts and weights, all on the device
-            hipLaunchKernelGGL(k_sel_init, dim3(1), dim3(64), 0, s, st, 12, &plan->nrows, 0, 0, 1, pl6);
-            TTC_HIP(c, radix_select(SrcEvi{evi, plan}, st, hist, 12, s));
-            hipLaunchKernelGGL(k_strata_thresholds, dim3(1), dim3(64), 0, s, st, plan, pl6, sd);
-            hipLaunchKernelGGL(k_strata_count, dim3(128), b256, 0, s, evi, plan, sd);
-            hipLaunchKernelGGL(k_row_weights_dev, dim3(256), b256, 0, s, evi, plan, sd, weight);
-            ga.weight = weight;
         }
         hipLaunchKernelGGL(k_gram, dim3(gram_blocks), b256, 0, s, ga, gpart);
         hipLaunchKernelGGL(k_gram_reduce, dim3(64), b256, 0, s, gpart, gram_blocks, Zdev);

@@ -14,7 +14,9 @@ template <> struct Elem<0> {
     using v8 = f16x8;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ unsigned pack2(float a, float b, unsigned& lo2) {
-        a = fminf(fmaxf(a, -65504.f), 65504.f); b = fminf(fmaxf(b, -65504.f), 65504.f);
+        // finite overflow saturates (the fp16 pair then stays finite); NaN must survive like it does on the fp32 engine --
+        // fmaxf(NaN, x) returns x, so the clamp alone would turn it into -65504
+        a = a != a ? a : fminf(fmaxf(a, -65504.f), 65504.f); b = b != b ? b : fminf(fmaxf(b, -65504.f), 65504.f);
         f16x2 h; h[0] = (_Float16)a; h[1] = (_Float16)b;
         f16x2 l; l[0] = (_Float16)(a - (float)h[0]); l[1] = (_Float16)(b - (float)h[1]);
         lo2 = __builtin_bit_cast(unsigned, l);

@@ -72,6 +72,8 @@ bool list_group(const File& f, uint64_t btree, uint64_t heap, std::vector<std::p
             if (f.b[a + 4] != 0) { err = "group B-tree of the wrong type"; return false; }
             const int n = (int)f.u(a + 6, 2);
             uint64_t p = a + 24;                                 // key0, child0, key1, ...
+            if (!f.ok(a, 24 + 16ull * n + 8)) { err = "group B-tree node past the end of the file"; return false; }
+            if (stack.size() + n > 1u << 20) { err = "group B-tree too large (cyclic?)"; return false; }
             for (int i = 0; i < n; ++i) { stack.push_back(f.u(p + 8, 8)); p += 16; }
         } else if (std::memcmp(&f.b[a], "SNOD", 4) == 0) {
             const int n = (int)f.u(a + 6, 2);
@@ -94,6 +96,7 @@ struct Dataset {
     int layout = -1;                   // 1 contiguous, 2 chunked
     uint64_t data_addr = kUndef, data_size = 0;
     uint32_t chunk[9] = {0};
+    int chunk_nd = 0;                  // dimensionality in the layout message (rank + 1: the last entry is the element size)
     bool deflate = false, shuffle = false;
 };
 
@@ -125,8 +128,12 @@ bool parse_dataset(const File& f, uint64_t oh, Dataset& d, std::string& err) {
             else if (d.layout == 2) {
                 const int nd = f.b[p + 2];                       // rank + 1
                 if (nd < 2 || nd > 9) { err = "bad chunk dimensionality"; return false; }
+                d.chunk_nd = nd;
                 d.data_addr = f.u(p + 3, 8);
-                for (int i = 0; i < nd; ++i) d.chunk[i] = (uint32_t)f.u(p + 11 + 4ull * i, 4);
+                for (int i = 0; i < nd; ++i) {
+                    d.chunk[i] = (uint32_t)f.u(p + 11 + 4ull * i, 4);
+                    if (d.chunk[i] == 0) { err = "chunk dimension of size 0"; return false; }
+                }
             } else { err = "compact datasets are not expected here"; return false; }
         } else if (m.type == 0xB) {                              // filter pipeline, version 1
             if (f.b[p] != 1) { err = "unsupported filter pipeline version"; return false; }
@@ -142,6 +149,8 @@ bool parse_dataset(const File& f, uint64_t oh, Dataset& d, std::string& err) {
         }
     }
     if (!have_space || !have_type || d.layout < 0) { err = "dataset header lacks dataspace / datatype / layout"; return false; }
+    if (d.layout == 2 && d.chunk_nd != d.rank + 1) { err = "chunk dimensionality does not match the dataspace rank"; return false; }
+    if (d.esize < 1 || d.esize > 16) { err = "element size outside 1..16 bytes"; return false; }
     return true;
 }
 
@@ -169,6 +178,7 @@ bool read_chunks(const File& f, const Dataset& d, uint8_t* out, std::string& err
         const int level = f.b[a + 5], n = (int)f.u(a + 6, 2);
         const uint64_t ksz = 8 + 8ull * (R + 1);
         uint64_t p = a + 24;
+        if (stack.size() + n > 1u << 22) { err = "chunk B-tree too large (cyclic?)"; return false; }
         for (int i = 0; i < n; ++i) {
             if (!f.ok(p, ksz + 8)) { err = "chunk B-tree entry past the end of the file"; return false; }
             const uint64_t csize = f.u(p, 4), mask = f.u(p + 4, 4), child = f.u(p + ksz, 8);
@@ -208,7 +218,7 @@ bool read_chunks(const File& f, const Dataset& d, uint8_t* out, std::string& err
     return true;
 }
 
-std::string g_hkl_err;
+thread_local std::string g_hkl_err;     // per thread: loaders may read files concurrently
 
 }  // namespace
 

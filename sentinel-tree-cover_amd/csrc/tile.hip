@@ -853,6 +853,11 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     WMat* d_ring = static_cast<WMat*>(c->scratch_buf("wmat_ring", sizeof(WMat) * kSlots));
     if (!h_ring || !d_ring) return c->fail(TTC_ERR_NOMEM, "operator staging");
     const int slot = (c->wmat_slot++) % kSlots;
+    // a slot is rewritten only after the copy that last read it has executed (a caller may enqueue more than kSlots calls
+    // without synchronising)
+    if (c->wmat_events.size() < (size_t)kSlots) c->wmat_events.resize(kSlots, nullptr);
+    if (c->wmat_events[slot]) TTC_HIP(c, hipEventSynchronize(c->wmat_events[slot]));
+    else TTC_HIP(c, hipEventCreateWithFlags(&c->wmat_events[slot], hipEventDisableTiming));
     WMat& wm = h_ring[slot];
     std::memset(&wm, 0, sizeof(WMat));
     wm.T = T; wm.keep = 0; wm.Tk = 0;
@@ -860,6 +865,7 @@ ttc_status tile_process_subtiles(ttc_ctx* c, const float* d_s2, int T, int X, in
     for (int k = 0; k < 12; ++k)
         for (int t = 0; t < T; ++t) wm.w[k * kMaxT + t] = ((wm.keep >> t) & 1u) ? h_wmat[k * T + t] : 0.0f;
     TTC_HIP(c, hipMemcpyAsync(d_ring + slot, &wm, sizeof(WMat), hipMemcpyHostToDevice, s));
+    TTC_HIP(c, hipEventRecord(c->wmat_events[slot], s));
     return tile_core(c, d_s2, T, X, Y, d_ring + slot, d_interp, d_s1, d_dem, h_min, h_max, size, n_dates_ok, d_windows, d_windows_raw,
                      false, s);
 }

@@ -192,6 +192,7 @@ struct ttc_ctx {
     std::map<std::string, std::pair<void*, size_t>> pinned;    // page-locked host staging, same keyed-growth scheme
     int* spec_status = nullptr;   // single-call tile path: device int32[4] the speculative stages report into (see ttc_predict_tile)
     unsigned wmat_slot = 0;       // ring index of the host-built temporal operator (tile.hip)
+    std::vector<hipEvent_t> wmat_events;   // per ring slot: the H2D copy that last read it
     bool minv_ready = false;      // the constant Whittaker matrix has been uploaded (tile.hip)
 
     Timing timing;

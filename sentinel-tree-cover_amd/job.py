@@ -338,13 +338,15 @@ def load_raw_tile(x, y, local_path):
             "dates": rd(f"{folder}raw/misc/s2_dates_{idx}.hkl")}
 
 
-def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True, sampler="reference"):
+def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True, sampler="reference", cloudshad=None):
     """The numeric flow of process_tile (job.py:641-995) on the device, from the arrays it loads from temp/raw/* :
     raw = {"s2_10": uint16 [T, X, Y, 4], "s2_20": uint16 [T, X/2, Y/2, 6], "s1": uint16 [12, X, Y, 2], "dem": float [X, Y] (m),
            "dates": int [T], "clouds": float [T, X, Y] (s2cloudless, only kept in step), "clm": 20 m Sen2Cor mask or None}.
     Host code takes the DECISIONS the reference takes (which dates to drop, when to re-run the detection); every raster
     operation runs through the C ABI.  -> (sentinel2 cuda [T', X, Y, 10], dates, interp cuda, s1 cuda, dem cuda (/90),
-    cloudshad cuda, snow cuda uint8), T' <= T."""
+    cloudshad cuda, snow cuda uint8), T' <= T.
+    cloudshad [T, X, Y] (optional): a GIVEN cloud + shadow mask replaces identify_clouds_shadows (and its re-runs after dates
+    are dropped: the surviving dates of the given mask) -- the staged twin of ttc_predict_tile without TTC_TILE_DETECT."""
     ctx, t = sess.ctx, sess.ctx.torch
     s2_20 = np.asarray(raw["s2_20"])
     if s2_20.ndim == 3:
@@ -360,11 +362,14 @@ def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True
     clouds = np.array(raw["clouds"], copy=True) if raw.get("clouds") is not None else np.zeros((len(dates), 1, 1), np.float32)
     s2 = ctx.upsample_20m(ctx.to_float32(np.ascontiguousarray(s2_10)), ctx.to_float32(np.ascontiguousarray(s2_20)))  # :727-782
     interp = None
+    given = ctx._dev(cloudshad, t.float32).clone() if cloudshad is not None else None
 
     def drop(idx):
-        nonlocal clouds, dates, s2, clm, interp
+        nonlocal clouds, dates, s2, clm, interp, given
         keep = np.setdiff1d(np.arange(len(dates)), idx)
         sel = t.as_tensor(keep, device=s2.device)
+        if given is not None:
+            given = given.index_select(0, sel).contiguous()
         if clouds.shape[0] == len(dates):
             clouds = np.delete(clouds, idx, axis=0)
         dates = np.delete(dates, idx)
@@ -389,7 +394,10 @@ def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True
         return ctx.clip01(s2), dates, z, s1, ctx.divide(dem, 90.0), z.clone(), snow
 
     def detect(first):
-        cs, fc = ctx.identify_clouds_shadows(s2, dem, forest_mask, urban_masks)               # :839
+        if given is not None:
+            cs, fc = given.clone(), None
+        else:
+            cs, fc = ctx.identify_clouds_shadows(s2, dem, forest_mask, urban_masks)           # :839
         if clm is not None:
             ctx.merge_cloud_masks(cs, clm, fc if first else None)                             # :841-846 / :880-884
         return cs, fc
@@ -424,6 +432,36 @@ def predict_tile(s2, dates, interp, s1, dem, sess, size=SIZE, to_host=True):
     if to_host:
         return f32.cpu().numpy(), u8.cpu().numpy()
     return f32, u8
+
+
+def predict_tile_raw_checked(raw, mask, sess, size=SIZE, to_host=True, sampler="expected", want_status=False):
+    """The job's per-tile chain (job.py:1995-2020) from the arrays of temp/raw, fast path first:
+
+      1. ttc_predict_tile -- ONE enqueue, no host round trip -- takes process_tile's rare data-dependent decisions
+         speculatively and reports them in its status words (include/ttc.h);
+      2. if any is set (a date that cannot be aligned, dates the gap-fill marks fully interpolated, a date with half its
+         pixels missing, > 10 snowy dates, a > 90 % clouded date), the raster of step 1 is NOT the reference's: the tile is
+         re-run through the staged mirror -- process_tile (given mask) -> superresolve_large_tile -> predict_tile -- which
+         takes those decisions on the host exactly like the reference.
+
+    raw: {"s2_10" uint16 [T, X, Y, 4], "s2_20" uint16 [T, X/2, Y/2, 6], "s1" uint16 [12, X, Y, 2], "dem" float [X, Y] in
+    METRES, "dates" int [T]} (numpy); mask [T, X, Y] the cloud + shadow mask.  sampler: "expected" (deterministic, what
+    the single call uses) or "reference" for the staged re-run only.
+    -> (float32 percent raster with NaN no-data, uint8 product) [Y, X] like load_mosaic_predictions (+ the int32[4] status
+    words and whether the staged path ran, with want_status)."""
+    ctx, t = sess.ctx, sess.ctx.torch
+    dem90 = ctx.divide(ctx.median5(np.ascontiguousarray(raw["dem"], dtype=np.float32)), 90.0)          # job.py:713, :993
+    u8, f32, _, status = ctx.predict_tile_raw(raw["s2_10"], raw["s2_20"], raw["s1"], dem90, mask, raw["dates"], min_all, max_all,
+                                              size, want_float=True)
+    st = status.cpu().numpy()                                                  # waits for the stream
+    staged = bool(st[0] or st[2] or st[3])
+    if staged:
+        s2, dates, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None, clm=None), sess, sampler=sampler, cloudshad=mask)
+        ctx.superresolve_tile(s2, quirks=True)                                                         # job.py:2001
+        f32, u8 = predict_tile(s2, dates, interp, s1, dem, sess, size=size, to_host=False)
+    if to_host:
+        f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
+    return (f32, u8, st, staged) if want_status else (f32, u8)
 
 
 def write_tif(arr, point, x, y, out_folder, suffix="_FINAL"):

@@ -1,0 +1,187 @@
+"""GPU parity of the EXACT path bench.py times -- raw uint16 arrays -> ONE ttc_predict_tile call -> rasters -- against the chained
+CPU oracle (oracle/restate_e2e.py: the pinned stage restatements in the reference's order, job.py:1995-2020), at the bench's
+size (618^2, T = 12, bench seeds 1234 / 1235) in all three precision modes, plus the status words that tell the caller when
+the single call's speculation does not hold and the checked wrapper that then re-runs the tile through the staged mirror.
+
+The oracle's gap-fill uses sampler = "expected": a restatement of the deterministic expected-multiplicity weighting
+(restate_gapfill.expected_weights), so the HIP path is checked against a specification, not against its staged twin.
+Tolerances on PRE-rounding window probabilities (BASELINE.json's contract is 1e-3): fp32 / fp16 2e-4, bf16 1e-3.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests.helpers import ROOT, synth
+
+pytestmark = pytest.mark.gpu
+
+TILE, T, SIZE = 618, 12, 158
+TOL = {"fp32": 2e-4, "fp16": 2e-4, "bf16": 1e-3}
+
+
+def u16(a):
+    return np.trunc(np.clip(a, 0, 1) * 65535).astype(np.uint16)
+
+
+def bench_tile(seed, X=TILE, dates_T=T):
+    """the raw arrays bench.py builds for tile id seed - 1234 (bench.py: make_tile)"""
+    s2, dates, probs, _ = synth.synth_gapfill_scene(seed=seed, T=dates_T, H=X, W=X)
+    _, _, _, s1, dem = synth.synth_tile(seed=seed, T=2, H=X, W=X)
+    return u16(s2[..., :4]), u16(s2[:, ::2, ::2, 4:]), probs, np.asarray(dates), u16(s1), dem
+
+
+_ORACLE = {}
+
+
+def oracle_for(seed, sampler="expected"):
+    """one whole-tile oracle pass per (seed, sampler), shared by the precision cases (~1 min of host time each)"""
+    key = (seed, sampler if isinstance(sampler, str) else "reference")
+    if key not in _ORACLE:
+        import torch
+        from oracle import restate_e2e as E, restate_gapfill as G, restate_model as M
+        from ttc import weights as Wt
+        s2_10, s2_20, mask, dates, s1, dem = bench_tile(seed)
+        net = M.TreeCoverNet(Wt.synth_weights(0), dtype=torch.float32)
+        ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+        if not isinstance(sampler, str):
+            random.seed(11)
+        _ORACLE[key] = E.single_call_chain(s2_10, s2_20, s1, dem, mask, dates, net, ds, size=SIZE, length=4,
+                                           sampler=sampler if isinstance(sampler, str) else G.reference_sampler)
+    return _ORACLE[key]
+
+
+def hip_tile(seed, precision):
+    import torch
+    from ttc import job, weights as Wt
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=SIZE + 14, length=4, max_windows=36, precision=precision)
+    s2_10, s2_20, mask, dates, s1, dem = bench_tile(seed)
+    u8, f32, frames, status = sess.ctx.predict_tile_raw(s2_10, s2_20, s1, dem, mask, dates, job.min_all, job.max_all, SIZE,
+                                                        want_float=True, want_inputs=True)
+    torch.cuda.synchronize()
+    out = {"u8": u8.cpu().numpy(), "f32": f32.cpu().numpy(), "frames": frames.cpu().numpy(), "status": status.cpu().numpy(),
+           "raw": sess.ctx.debug_fetch("pt_windows_raw", (36, SIZE, SIZE)), "win": sess.ctx.debug_fetch("pt_windows", (36, SIZE, SIZE))}
+    sess.close()
+    return out
+
+
+def window_stats(hip_raw, ref):
+    """|dprob| over every window pixel both sides predicted (<= 1: not a 255 fill)"""
+    d = []
+    for i, k in enumerate(ref["order"]):
+        if k not in ref["raw"]:
+            continue
+        a, b = hip_raw[i], ref["raw"][k]
+        ok = (a <= 1.0) & (b <= 1.0)
+        d.append(np.abs(a.astype(np.float64) - b)[ok])
+    d = np.concatenate(d)
+    return {"max": float(d.max()), "p999": float(np.quantile(d, 0.999)), "frac_gt_1e-3": float((d > 1e-3).mean()),
+            "rms": float(np.sqrt((d ** 2).mean())), "n": int(d.size)}
+
+
+@pytest.mark.parametrize("seed,precision", [(1234, "fp32"), (1234, "fp16"), (1234, "bf16"), (1235, "fp32")])
+def test_single_call_tile_vs_chained_oracle(seed, precision):
+    ref = oracle_for(seed)
+    got = hip_tile(seed, precision)
+    st = got["status"]
+    print(f"[parity] e2e seed {seed} {precision}: status {st.tolist()}")
+    assert st[0] == 0 and st[2] == 0 and st[3] == 0 and st[1] == len(ref["dates"]) == T
+    # model inputs: frames [36, L+1, 17, W+2, W+2] planar padded vs the oracle's feeds [L+1, W, W, 17]
+    fd = 0.0
+    for i, k in enumerate(ref["order"]):
+        if k in ref["feeds"]:
+            fd = max(fd, float(np.abs(got["frames"][i][:, :, 1:-1, 1:-1].transpose(0, 2, 3, 1) - ref["feeds"][k]).max()))
+    ws = window_stats(got["raw"], ref)
+    print(f"[parity] e2e seed {seed} {precision}: model inputs max|d| = {fd:.2e}; pre-rounding windows max|dprob| = {ws['max']:.2e}, "
+          f"p99.9 = {ws['p999']:.2e}, rms = {ws['rms']:.2e} over {ws['n']} px")
+    assert fd < 2e-2, fd                    # normalised units (reflectance / half-range): the NNLS fit from Gram sums vs scipy's
+    assert ws["max"] <= TOL[precision], ws
+    # what the reference saves per window (3-decimal rounding, 255 fills) and the two rasters
+    same_fill = True
+    for i, k in enumerate(ref["order"]):
+        same_fill &= np.array_equal(got["win"][i] > 1.0, ref["windows"][k] > 1.0)
+    assert same_fill
+    assert np.array_equal(np.isnan(got["f32"]), np.isnan(ref["f32"]))
+    df = np.abs(np.nan_to_num(got["f32"]) - np.nan_to_num(ref["f32"]))
+    d8 = np.abs(got["u8"].astype(int) - ref["u8"].astype(int))
+    print(f"[parity] e2e seed {seed} {precision}: percent raster max|d| = {df.max():.3f}, uint8 differing {(d8 > 0).mean():.2e}, > 1 count {(d8 > 1).mean():.2e}")
+    assert df.max() <= 0.11 + 100 * TOL[precision] and (d8 > 1).mean() < 1e-5 and (d8 > 0).mean() < 3e-2
+
+
+def test_expected_sampler_vs_seeded_reference_sampler_end_to_end():
+    """The number under the 1e-3 contract that is NOT a kernel property: the bench's deterministic expected-multiplicity
+    sampler against ONE seeded draw of the reference's stdlib-random sample (the reference itself draws a different one on
+    every run), propagated through the whole chain to pre-rounding probabilities.  Measured, printed, written to
+    gpurun_out/e2e_dprob.json (committed under profiles/ and quoted by bench.py as `max_dprob_e2e.sampler_effect`)."""
+    got = hip_tile(1234, "fp32")
+    exp = window_stats(got["raw"], oracle_for(1234))
+    ref = window_stats(got["raw"], oracle_for(1234, sampler=None))
+    print(f"[parity] HIP fp32 single call vs oracle(expected sampler): {exp}")
+    print(f"[parity] HIP fp32 single call vs oracle(reference sampler, random.seed(11)): {ref}")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "e2e_dprob.json"), "w") as f:
+        json.dump({"tile": "bench seed 1234, 618x618, T=12, W=172, L=4, fp32", "vs_oracle_expected_sampler": exp,
+                   "vs_oracle_reference_sampler_seed11": ref}, f, indent=1)
+    assert exp["max"] <= 2e-4
+    assert ref["p999"] < 5e-3               # one draw of the reference's own run-to-run spread; NOT bounded by 1e-3 at the maximum
+
+
+# ---- status words and the checked wrapper, at a size the oracle finishes in seconds ---------------------------------------
+def small_raw(seed, T=6, X=120, Y=112):
+    s2, dates, probs, _ = synth.synth_gapfill_scene(seed=seed, T=T, H=X, W=Y)
+    _, _, _, s1, dem = synth.synth_tile(seed=seed, T=2, H=X, W=Y)
+    raw = {"s2_10": u16(s2[..., :4]), "s2_20": u16(s2[:, ::2, ::2, 4:]), "s1": u16(s1), "dem": (dem * 90.0).astype(np.float32),
+           "dates": np.asarray(dates)}
+    return raw, probs.astype(np.float32)
+
+
+def force(case, raw, mask):
+    T = mask.shape[0]
+    if case == "fully_interpolated_date":            # cloud_removal.py:958-959 -> job.py:964-981
+        mask[2] = 1.0
+    elif case == "unalignable_date":                 # cloud_removal.py:679-680: <= 1000 usable rows on a tile with land
+        mask[3] = 1.0
+        mask[3, :20, :90] = 0.0                      # ~890 pixels stay below the 0.25 weight after feathering
+    elif case == "half_missing_date":                # id_missing_px(., 2), job.py:786
+        raw["s2_10"][4, :70] = 0
+    elif case == "snowy_dates":                      # > 10 dates with > 25 % snow pixels, job.py:822
+        for t in range(11):
+            raw["s2_10"][t, :50] = u16(np.float32(0.5))                 # blue / green / red / nir bright
+            raw["s2_20"][t, :25, :, 4] = u16(np.float32(0.05))         # band 8 (SWIR) dark -> NDSI high
+    return raw, mask
+
+
+@pytest.mark.parametrize("case,word,bit", [("clean", None, 0), ("fully_interpolated_date", 2, 0), ("unalignable_date", 0, 0),
+                                            ("half_missing_date", 3, 1), ("snowy_dates", 3, 2), ("heavy_cloud_date", 3, 4)])
+def test_status_words_and_checked_wrapper(case, word, bit):
+    """ttc_predict_tile flags the tiles on which process_tile would have dropped dates (status[0] / [2] / [3]);
+    job.predict_tile_raw_checked re-runs exactly those through the staged mirror, and its result equals the oracle chain that
+    takes the reference's decisions (oracle/restate_e2e.checked_chain) -- for flagged AND clean tiles."""
+    import torch
+    from oracle import restate_e2e as E, restate_model as M
+    from ttc import job, weights as Wt
+    Tn = 14 if case == "snowy_dates" else 6
+    raw, mask = small_raw(40 + Tn, T=Tn)
+    if case == "heavy_cloud_date":                   # feathered mask > 90 % of the tile but clear rows left: job.py:866
+        mask[1] = 1.0
+        mask[1, :20, :] = 0.0                        # feathered: 90.8 % covered, 1232 rows stay usable
+    raw, mask = force(case, raw, mask)
+    w = Wt.synth_weights(0)
+    sess = job.TTCSession(w, win_in=44, length=4, max_windows=36)
+    f32, u8, st, staged = job.predict_tile_raw_checked(raw, mask, sess, size=30, want_status=True)
+    print(f"[parity] status words, {case}: {st.tolist()} staged = {staged}")
+    if word is None:
+        assert not staged and st[0] == 0 and st[2] == 0 and st[3] == 0
+    else:
+        assert staged and st[word] != 0 and (bit == 0 or (st[3] & bit))
+    net = M.TreeCoverNet(w, dtype=torch.float32)
+    ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    ref = E.checked_chain({k: (v.copy() if hasattr(v, "copy") else v) for k, v in raw.items()}, mask.copy(), net, ds, size=30, length=4)
+    print(f"[parity] status words, {case}: dates kept by the oracle {len(ref['dates'])} of {Tn}")
+    assert np.array_equal(np.isnan(f32), np.isnan(ref["f32"]))
+    d = np.abs(np.nan_to_num(f32) - np.nan_to_num(ref["f32"]))
+    d8 = np.abs(u8.astype(int) - ref["u8"].astype(int))
+    print(f"[parity] status words, {case}: percent raster max|d| = {d.max():.3f}, uint8 > 1 count: {(d8 > 1).mean():.2e}")
+    assert d.max() <= 0.15 and (d8 > 1).mean() < 1e-4

@@ -62,6 +62,30 @@ def test_errors_are_loud(tmp_path):
         _lib.read_hkl(str(trunc))
 
 
+def test_malformed_chunk_layout_is_rejected(tmp_path):
+    """a chunk dimension of 0 (the copy loop would never advance) and a chunk dimensionality that does not match the dataspace
+    rank (wrong B-tree key size) are errors, not hangs / out-of-bounds reads"""
+    import struct
+    rng = np.random.default_rng(3)
+    arr = rng.integers(0, 65535, (3, 10, 12, 4)).astype(np.uint16)
+    w = WF.Writer()
+    w.finish({"data": w.chunked_dataset(arr, chunks=(1, 5, 7, 4))}, str(tmp_path / "ok.hkl"))
+    blob = bytearray((tmp_path / "ok.hkl").read_bytes())
+    np.testing.assert_array_equal(_lib.read_hkl(str(tmp_path / "ok.hkl")), arr)
+    dims = struct.pack("<5I", 1, 5, 7, 4, 2)                      # layout message: chunk dims + element size
+    at = bytes(blob).find(dims)
+    assert at > 0 and bytes(blob).find(dims, at + 1) < 0
+    zero = bytearray(blob); zero[at + 4:at + 8] = struct.pack("<I", 0)
+    (tmp_path / "zero.hkl").write_bytes(bytes(zero))
+    with pytest.raises(RuntimeError, match="chunk dimension of size 0"):
+        _lib.read_hkl(str(tmp_path / "zero.hkl"))
+    rank = bytearray(blob); rank[at - 9] = 4                      # dimensionality byte of the layout message (rank + 1 = 5)
+    assert blob[at - 9] == 5
+    (tmp_path / "rank.hkl").write_bytes(bytes(rank))
+    with pytest.raises(RuntimeError, match="does not match the dataspace rank"):
+        _lib.read_hkl(str(tmp_path / "rank.hkl"))
+
+
 def test_load_raw_tile_reads_the_raw_folder(tmp_path):
     """job.load_raw_tile: the file names of job.py:669-683, each through the HDF5 reader"""
     from ttc import job
