@@ -66,12 +66,12 @@ def _tile(tid, T, X=20, Y=40):
             "s1": torch.rand((12, X, Y, 2), generator=g), "dem": torch.rand((X, Y), generator=g), "dates": [10 * tid + 3 * i for i in range(T)]}
 
 
-def _border_worker(rank, world, port, out):
+def _border_worker(rank, world, port, out, n_tiles=5):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n_tiles, size = 5, 30                  # strips of size // 2 + 7 = 22 columns; tiles keep 3..7 dates
+        size = 30                              # strips of size // 2 + 7 = 22 columns; tiles keep 3.. dates
         mine = {t: _tile(t, 3 + t) for t in shard.tiles_for_rank(n_tiles, rank, world)}
         strips = shard.exchange_border_strips(mine, n_tiles, rank, world, size)
         ok = {}
@@ -99,3 +99,19 @@ def test_border_strip_exchange_two_ranks():
     assert shard.borders_for_rank(5, 0, 1) == [0, 1, 2, 3]
     one = shard.exchange_border_strips({t: _tile(t, 4) for t in range(3)}, 3, 0, 1, 30)
     assert sorted(one) == [0, 1] and one[0]["s2"].shape == (4, 20, 22, 10)
+
+
+def test_border_strip_exchange_three_ranks():
+    """world 3 (neither 1 nor 2): a rank both sends and receives in the same batch, every border has its two tiles on
+    different ranks, and rank 2 owns fewer tiles than the others (7 tiles -> 3 / 2 / 2)"""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_border_worker, args=(r, world, port, q, 7)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    owned = [r[1] for r in res]
+    assert owned == [[0, 3], [1, 4], [2, 5]]            # border t (tiles t, t + 1) belongs to rank t % 3
+    assert all(all(r[2].values()) for r in res)
