@@ -238,7 +238,8 @@ ttc_status ttc_divide(ttc_ctx* ctx, float* d_a, int64_t n, float divisor, void* 
  * d_s2_10 [T, X, Y, 4] / d_s2_20 [T, X/2, Y/2, 6] / d_s1 [12, X, Y, 2] uint16 as stored in temp/raw (device memory);
  * d_dem [X, Y] as process_tile returns it (median-filtered, / 90); d_dem_m the same in metres (detection only, may be NULL);
  * d_mask [T, X, Y] the cloud + shadow mask (ignored with TTC_TILE_DETECT); d_dates [T] int32 day of year, DEVICE memory.
- * d_out_u8 [X, Y] uint8 (transposed like the reference's mosaic, 255 = no data), d_out_f32 the float percent raster or NULL;
+ * d_out_u8 [Y, X] uint8 (transposed like the reference's mosaic, job.py:1578; 255 = no data), d_out_f32 the float percent raster
+ * of the same shape or NULL;
  * d_model_in (optional) receives the model's input frames [36, L+1, 17, W+2, W+2] (planar, padded: what ttc_debug_fetch
  * "frames" returns).  ttc_debug_fetch "pt_windows" / "pt_windows_raw" [36, size, size]: the per-window arrays the reference
  * np.save()s, and the same before np.around / the bright-surface product.  flags: TTC_TILE_*. */

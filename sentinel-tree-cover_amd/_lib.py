@@ -313,7 +313,7 @@ class Context:
         """ttc_predict_tile: the whole per-tile chain in ONE enqueue, no host round trip.  s2_10 [T, X, Y, 4] / s2_20
         [T, X/2, Y/2, 6] / s1 [12, X, Y, 2] uint16 as stored (cuda int16 / uint16 views or numpy), dem [X, Y] (/90), mask
         [T, X, Y] float32 cloud + shadow mask (None with TILE_DETECT), dates [T] (cuda int32 tensor or sequence).
-        -> (u8 cuda [X, Y] | None, f32 | None, model inputs | None, status cuda int32[4]); read `status` after a stream
+        -> (u8 cuda [Y, X] | None, f32 | None, model inputs | None, status cuda int32[4]); read `status` after a stream
         synchronisation: status[0] / status[2] != 0 -> the tile needs the staged calls (see ttc.h)."""
         t = self.torch
         dev = f"cuda:{self.device}"
@@ -331,8 +331,9 @@ class Context:
         ddates = dates if isinstance(dates, t.Tensor) else t.tensor([int(d) for d in dates], dtype=t.int32)
         ddates = ddates.to(dev, t.int32).contiguous()
         inputs_only = bool(flags & self.TILE_INPUTS_ONLY)
-        u8 = out if out is not None else (None if inputs_only else t.empty((X, Y), dtype=t.uint8, device=dev))
-        f32 = t.empty((X, Y), dtype=t.float32, device=dev) if (want_float and not inputs_only) else None
+        # rasters are [Y, X]: transposed like load_mosaic_predictions' (job.py:1578)
+        u8 = out if out is not None else (None if inputs_only else t.empty((Y, X), dtype=t.uint8, device=dev))
+        f32 = t.empty((Y, X), dtype=t.float32, device=dev) if (want_float and not inputs_only) else None
         W = self.cfg.win_in
         frames = t.empty((36, self.cfg.length + 1, 17, W + 2, W + 2), dtype=t.float32, device=dev) if want_inputs else None
         status = status if status is not None else t.zeros(4, dtype=t.int32, device=dev)
