@@ -25,14 +25,26 @@
 //   TERMS = 3: hi tiles double-buffered, lo tile single (it is read by one of the three products only: that product
 //              runs first, a mid-chunk barrier frees the buffer and the next chunk's lo tile streams in under the other
 //              two products), weights (hi | lo) double-buffered.
+//
+// Round 3: what separated the round-2 kernel from its matrix-pipe floor was not the chunk loop (two co-resident waves keep
+// the pipe of a SIMD busy while both are inside it) but the 35 % of a workgroup's life spent OUTSIDE it -- kernel entry,
+// index math, the first copies' round trip, and an epilogue that transposed the tile through LDS behind four barriers
+// (per-workgroup s_memtime traces).  Two structural changes attack exactly that:
+//   * PERSISTENT workgroups (grid = the resident set, 2 per CU) walk the XCD-aware tile list, and the chunk stream runs
+//     ACROSS tiles: while the last chunk of tile i is being multiplied, the copies of chunk 0 of tile i + 1 are already in
+//     flight into the free halves of the double buffers, so they land under tile i's epilogue instead of after a new
+//     workgroup's start-up;
+//   * NO LDS in any epilogue: the GroupNorm layers' raw outputs leave straight from the accumulators as 16-byte vectors in
+//     the same channel-blocked layout as every other tensor of this engine -- EXACT fp32, stored as a plane of top and a
+//     plane of bottom 16-bit halves (cross-half v_permlane32_swap assembles 8 consecutive channels per lane) -- which is
+//     what lets the prefetch above own the LDS during the epilogue, and removes 256 ds_write_b32 + 32 ds_read_b128 +
+//     4 barriers per tile.  The consumers (k_gru_apply*_b16, k_block_finalize_b16, k_head, k_tap_late) read those planes
+//     as 16-byte vectors (raw_load8, h16_common.h).
 #include <algorithm>
 
 #include "h16_common.h"
 
 using namespace ttcconv;
-
-// probe aid: H16Args.abl (env TTC_H16_ABL) switches parts of the kernel off at run time -- bit 0: no epilogue / output
-// stores, bit 1: no MFMAs, bit 2: no LDS-DMA.  0 in production; results are garbage otherwise.
 
 namespace {
 
@@ -45,32 +57,27 @@ __device__ __forceinline__ void cbarrier() {
     asm volatile("" ::: "memory");
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
-__device__ __forceinline__ void wait_vm(int n) {
-    switch (n) {
-#define TTC_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        TTC_W(1) TTC_W(2) TTC_W(3) TTC_W(4) TTC_W(5) TTC_W(6) TTC_W(7) TTC_W(8) TTC_W(9) TTC_W(10) TTC_W(11) TTC_W(12)
-        TTC_W(13) TTC_W(14) TTC_W(15) TTC_W(16)
-#undef TTC_W
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // 0 and anything unexpected: wait for all
-    }
-}
-
-// fused epilogue of the OUT_B16 kernels: EPI op, then the fp32 accumulators leave as channel-blocked 16-bit hi (+ lo)
-// K vectors in the consumer's padded plane.  A lane holds 4 of a block's 8 channels (rows (r & 3) + 8 * (r >> 2) + 4 * hi):
-// v_permlane32_swap exchanges halves between lane and lane + 32, after which the low half-wave owns channel block 2k
-// and the high half-wave block 2k + 1 of 32 consecutive positions -> 512 contiguous bytes per half-wave and store.
+// Fused epilogue: EPI op, then the fp32 accumulators leave as channel-blocked 16-byte K vectors.  A lane holds 4 of a
+// block's 8 channels (rows (r & 3) + 8 * (r >> 2) + 4 * hi): v_permlane32_swap exchanges halves between lane and lane + 32,
+// after which the low half-wave owns channel block 2k and the high half-wave block 2k + 1 of 32 consecutive positions
+// -> 512 contiguous bytes per half-wave and store.
+//   EPI >= EPI_BIAS (DSen2): the NEXT layer's input, hi + lo 16-bit pair, in its padded plane (reflect rim duplicated);
+//   EPI <= EPI_SWISH (GroupNorm layers): the RAW output, exact fp32 as top / bottom 16-bit halves (o_hi = top plane,
+//   o_lo = bottom plane), at the tile's own flat positions q (the output keeps the input pitch; the two junk columns per
+//   row are written and never read), plus the deterministic GroupNorm partial sums of conv_common.h.
 template <int BF, int NCG, int EPI>
 __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)[NCG][kQG], int n, int cb, int bq, int nblk_q,
                                                  const float* aux, int tid) {
     using E = Elem<BF>;
     constexpr int BN = NCG * 32;
+    constexpr bool GN = EPI <= EPI_SWISH;
     const ConvArgs& c = a.c;
     const int Wp = c.Wp, Hp = c.Hp;
     const int lane = tid & 63, wave = tid >> 6, lo = lane & 31, hi = lane >> 5;
     const int q0 = bq * kBQ;
     const int Hout = Hp - 2, Wout = Wp - 2;
     const int C8out = (c.Cout + 7) >> 3;
+    const long qend = (long)Hout * Wp;            // GN layers: flat positions of the rows that exist
     float ssum[NCG][4], ssq[NCG][4];
 #pragma unroll
     for (int g = 0; g < NCG; ++g)
@@ -91,13 +98,19 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
                 bias[g][r] = co < c.Cout ? bv : 0.f;
             }
     }
+    float k1[16];                 // EPI_SSE: the in-cell sSE kernel of this lane's 16 channels
+    if (EPI == EPI_SSE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k1[r] = aux[(r & 3) + 8 * (r >> 2) + 4 * hi];
+    }
 
 #pragma unroll
     for (int j = 0; j < kQG; ++j) {
         const int q = q0 + (wave * kQG + j) * 32 + lo;
         const int y = q / Wp, x = q - y * Wp;
         const bool valid = (x < Wout) && (y < Hout);
-        const long opix = (long)(y + c.oy) * c.out_pitch + (x + c.ox);
+        const long opix = GN ? (long)q : (long)(y + c.oy) * c.out_pitch + (x + c.ox);
+        const bool okpix = GN ? ((long)q < qend) : valid;
         long dup_y = 0, dup_x = 0;
         bool any_dup = false;
         if (EPI >= EPI_BIAS && c.reflect_out) {
@@ -106,6 +119,19 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
                 dup_x = (x == 1) ? -2L : ((x == Wout - 2) ? 2L : 0L);
             }
             any_dup = __any((dup_y != 0) || (dup_x != 0));
+        }
+        float gate = 1.0f;
+        if (EPI == EPI_SSE) {
+            float dot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot += k1[r] * acc[0][j][r];
+            dot += __shfl_xor(dot, 32);
+            gate = sigmoidf_(dot);
+        }
+        float ratio = 1.0f;
+        if (EPI == EPI_SWISH && c.same_pad) {
+            const bool ey = (y == 0) || (y == Hout - 1), ex = (x == 0) || (x == Wout - 1);
+            ratio = (ey && ex) ? 2.25f : ((ey || ex) ? 1.5f : 1.0f);
         }
 #pragma unroll
         for (int g = 0; g < NCG; ++g) {
@@ -127,6 +153,8 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
             for (int r = 0; r < 16; ++r) {
                 const int co = cb * BN + g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 float t = acc[g][j][r];
+                if (EPI == EPI_SSE) t *= gate;
+                if (EPI == EPI_SWISH) { t *= ratio; t = t * sigmoidf_(t); }
                 if (EPI >= EPI_BIAS) {
                     t += bias[g][r];
                     if (EPI == EPI_BIAS_RELU) t = fmaxf(t, 0.f);
@@ -134,18 +162,25 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
                 }
                 if (co >= c.Cout) t = 0.f;                      // pad channels of the last block stay zero
                 v[r] = t;
-                if (EPI <= EPI_SWISH && valid) { ssum[g][r >> 2] += t; ssq[g][r >> 2] += t * t; }
+                if (GN && valid) { ssum[g][r >> 2] += t; ssq[g][r >> 2] += t * t; }
             }
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {                    // block pairs (2kp, 2kp + 1) of this cout group
-                unsigned xl0, xl1, yl0, yl1;
-                unsigned xh0 = E::pack2(v[8 * kp + 0], v[8 * kp + 1], xl0), xh1 = E::pack2(v[8 * kp + 2], v[8 * kp + 3], xl1);
-                unsigned yh0 = E::pack2(v[8 * kp + 4], v[8 * kp + 5], yl0), yh1 = E::pack2(v[8 * kp + 6], v[8 * kp + 7], yl1);
+                unsigned xl0, xl1, yl0, yl1, xh0, xh1, yh0, yh1;
+                if (GN) {
+                    xh0 = raw_top2(v[8 * kp + 0], v[8 * kp + 1]); xl0 = raw_bot2(v[8 * kp + 0], v[8 * kp + 1]);
+                    xh1 = raw_top2(v[8 * kp + 2], v[8 * kp + 3]); xl1 = raw_bot2(v[8 * kp + 2], v[8 * kp + 3]);
+                    yh0 = raw_top2(v[8 * kp + 4], v[8 * kp + 5]); yl0 = raw_bot2(v[8 * kp + 4], v[8 * kp + 5]);
+                    yh1 = raw_top2(v[8 * kp + 6], v[8 * kp + 7]); yl1 = raw_bot2(v[8 * kp + 6], v[8 * kp + 7]);
+                } else {
+                    xh0 = E::pack2(v[8 * kp + 0], v[8 * kp + 1], xl0); xh1 = E::pack2(v[8 * kp + 2], v[8 * kp + 3], xl1);
+                    yh0 = E::pack2(v[8 * kp + 4], v[8 * kp + 5], yl0); yh1 = E::pack2(v[8 * kp + 6], v[8 * kp + 7], yl1);
+                }
                 // lanes 32-63 of X <-> lanes 0-31 of Y: afterwards [X | Y] = the 8 channels of block 2kp + hi
                 auto s0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false); xh0 = s0[0]; yh0 = s0[1];
                 auto s1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false); xh1 = s1[0]; yh1 = s1[1];
                 const int blk = cb * (BN / 8) + g * 4 + 2 * kp + hi;
-                const bool ok = valid && (blk < C8out);
+                const bool ok = okpix && (blk < C8out);
                 const long u = (long)blk * a.o_plane + opix;
                 const uint4 vh = make_uint4(xh0, xh1, yh0, yh1);
                 if (ok) {
@@ -173,36 +208,45 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
         }
     }
 
-    if (EPI <= EPI_SWISH && c.stats) {        // same deterministic GroupNorm partials as conv_common.h
+    if (GN && c.stats) {        // same deterministic GroupNorm partials as conv_common.h
         float red[NCG * 8];
 #pragma unroll
         for (int g = 0; g < NCG; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { red[(g * 4 + k) * 2] = ssum[g][k]; red[(g * 4 + k) * 2 + 1] = ssq[g][k]; }
         half_wave_sums(red);
+        if (lo == 31) {           // one exec region for the two writer lanes; (sum, sumsq) leave as one 8-byte store
+            const long slots = (long)nblk_q * kWaves;
+            float2* base = reinterpret_cast<float2*>(c.stats) + (long)n * (c.Cout / 4) * slots + bq * kWaves + wave;
 #pragma unroll
-        for (int g = 0; g < NCG; ++g)
+            for (int g = 0; g < NCG; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
-                if (lo == 31 && quad * 4 < c.Cout) {
-                    float* dst = c.stats + (((long)n * (c.Cout / 4) + quad) * (nblk_q * kWaves) + bq * kWaves + wave) * 2;
-                    dst[0] = red[(g * 4 + k) * 2]; dst[1] = red[(g * 4 + k) * 2 + 1];
+                for (int k = 0; k < 4; ++k) {
+                    const int quad = cb * (BN / 4) + g * 8 + 2 * k + hi;
+                    if (quad * 4 < c.Cout) base[quad * slots] = make_float2(red[(g * 4 + k) * 2], red[(g * 4 + k) * 2 + 1]);
                 }
-            }
+        }
     }
 }
 
 template <int BF, int TERMS, int NCG, int EPI, int OUT>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb) {
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb, int ntiles) {
     using E = Elem<BF>;
     using v8 = typename E::v8;
     constexpr int BN = NCG * 32;
     constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;     // 1-KiB DMA pieces of one weight plane of a chunk
     constexpr int WUNITS = WPIECES * 64;                     // 16-byte units of that plane (padded)
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    const int Wp = a.c.Wp, Hp = a.c.Hp;
-    const long plane = (long)Hp * Wp;
+    // Persistent loop + ~100 dwords of arguments: if the loop body reads `a` directly, hipcc keeps every field it uses anywhere
+    // live in SGPRs across the whole walk (measured: 124 SGPR + 166 VGPR spills).  The arguments are therefore re-read from the
+    // kernarg segment (scalar loads, constant cache) at the start of each phase, through a pointer the optimiser cannot see
+    // through: a phase's fields die with it.
+    typedef const __attribute__((address_space(4))) H16Args* KArgs;
+    const KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();                       // `a` is the first kernel argument
+    auto args = [&]() { KArgs q = kp; asm volatile("" : "+s"(q)); return q; };
+    auto opaque = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    const int Wp = args()->c.Wp, Hp = args()->c.Hp;
+    const int plane = Hp * Wp;
     const int TL = kBQ + 2 * Wp + 2;
     const int NIN = (TL + 63) >> 6;                          // 1-KiB pieces of one input plane of a chunk (<= 16, checked at launch)
     const int INU = NIN * 64;                                // 16-byte units
@@ -211,197 +255,154 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     const int lane = tid & 63, lo = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-    if (a.trace) tr0 = __builtin_amdgcn_s_memtime();
-    const bool prio = (a.desync & 2) != 0;                   // probe switch: raised issue priority outside the MFMA blocks
-    if (prio) __builtin_amdgcn_s_setprio(3);
-    int bq, cb, n;
-    tile_index(nblk_q, ncb, bq, cb, n);
-    const int set = n / a.c.n_per_set, nn = n - set * a.c.n_per_set;
-    const int q0 = bq * kBQ;
-    const int C8_0 = a.seg[0].C8;
-    const int nchunk = a.nchunk;
-    const float* aux = a.c.aux ? a.c.aux + (long)set * a.c.aux_set_stride : nullptr;
-    const uint4* wsrc = a.w + (long)set * a.w_set_stride + (long)cb * nchunk * (2 * WUNITS);
+    // persistent walk: workgroup id -> (id % 8) owns a contiguous slice of the logical tile list (the dispatcher deals ids
+    // round-robin over the 8 XCDs), and the workgroups of one XCD step through it together with stride nx: at any moment they
+    // work on neighbouring tiles, whose 2 * Wp + 2 halos meet in that XCD's L2.  With grid == ntiles this is tile_index().
+    const int P = gridDim.x, xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
+    const int nx = (P >> 3) + (xcd < (P & 7) ? 1 : 0);                           // workgroups on this XCD
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int tcnt = per + (xcd < rem ? 1 : 0), tstart = xcd * per + (xcd < rem ? xcd : rem);
+    if (wslot >= tcnt) return;
+    const int C8_0 = args()->seg[0].C8;
+    const int nchunk = args()->nchunk;
 
-    // per-lane source position of an input piece p: q0 + 64 * p + lane, clamped into the plane (positions past the end
-    // only feed outputs that the epilogue drops)
-    const long seg_off0 = (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
-    const long seg_off1 = (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set];
-
-    const int abl = a.abl;
-    auto dma = [&](const uint4* g, int lds_unit) {
-        if (abl & 4) return;
+    // DMA-source state of the tile whose chunks are being STAGED (the current tile, or -- during a tile's last chunk -- the
+    // workgroup's next tile) and epilogue state of the tile being MULTIPLIED; both live in SGPRs
+    struct Src {
+        int bq, cb, n;
+        const uint4 *hi0, *lo0, *hi1, *lo1;   // this sequence's first plane in segment 0 / 1 (hi and lo tensors)
+        const uint4* wsrc;                    // weight images of (set, cout block)
+    };
+    struct Ep { int bq, cb, n; const float* aux; };
+    constexpr int kMaxIn = 4;                                // input pieces per wave: NIN <= 16 (Wp <= 254)
+    constexpr int kMaxW = (2 * WPIECES + 3) / 4;             // weight pieces per wave (TERMS == 3: hi | lo planes)
+    auto src_of = [&](int tk) {
+        // (the divisors go through `opaque`: otherwise hipcc hoists three sets of reciprocal constants out of the tile walk
+        // and keeps them in SGPRs for the whole kernel)
+        const int lid = tstart + tk;
+        Src t;
+        const int dq = opaque(nblk_q), dc = opaque(ncb);
+        t.bq = lid % dq;
+        const int rest = lid / dq;
+        t.cb = rest % dc; t.n = rest / dc;
+        const KArgs ka = args();
+        const int nps = opaque(ka->c.n_per_set);
+        const int set = t.n / nps, nn = t.n - set * nps;
+        const long off0 = (long)nn * ka->seg[0].stride_n + ka->seg[0].set_off[set];
+        const long off1 = (long)nn * ka->seg[1].stride_n + ka->seg[1].set_off[set];
+        t.hi0 = ka->seg[0].hi + off0; t.lo0 = ka->seg[0].lo + off0;
+        t.hi1 = ka->seg[1].hi + off1; t.lo1 = ka->seg[1].lo + off1;
+        t.wsrc = ka->w + (long)set * ka->w_set_stride + (long)t.cb * nchunk * (2 * WUNITS);
+        return t;
+    };
+    auto ep_of = [&](const Src& t) {
+        const KArgs ka = args();
+        const int set = t.n / opaque(ka->c.n_per_set);
+        const float* ax = ka->c.aux;
+        return Ep{t.bq, t.cb, t.n, ax ? ax + (long)set * ka->c.aux_set_stride : nullptr};
+    };
+    auto dma = [&](const char* g, int lds_unit) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(smem + lds_unit), 16, 0, 0);
     };
-    // A stage copy = this wave's share of {NIN input pieces of `src` -> in_unit} and {nwp weight pieces of `ws` -> w_unit}:
-    // input pieces wave, wave + 4, ...; weight pieces likewise; every wave issues exactly ceil(NIN / 4) + ceil(nwp / 4) copies
-    // (a surplus repeats the last piece), so one vmcnt value fits all waves.  The per-lane byte offsets are chunk-invariant
-    // and computed once: a copy then costs its wave an M0 write and one global_load_lds with an SGPR base.
-    // The copies of a stage are issued a few at a time BETWEEN the MFMAs of the running chunk (issue_some): an LDS-DMA costs
-    // its wave 60-180 issue cycles, which the matrix pipe hides while MFMAs are queued on it.
-    constexpr int kMaxIn = 4;                                // input pieces per wave: NIN <= 16 (Wp <= 254)
-    constexpr int kMaxW = (2 * WPIECES + 3) / 4;             // weight pieces per wave (TERMS == 3: hi | lo planes)
-    const int cnt_in = (NIN + 3) >> 2;
-    unsigned off_in[kMaxIn];                                 // byte offset of this lane's 16 bytes inside an input plane
-    int unit_in[kMaxIn];
-#pragma unroll
-    for (int k = 0; k < kMaxIn; ++k) {
-        int pid = wave + 4 * k;
-        pid = pid < NIN ? pid : NIN - 1;
-        long q = (long)q0 + 64 * pid + lane;
-        q = q < plane ? q : plane - 1;
-        off_in[k] = (unsigned)(q * 16);
-        unit_in[k] = 64 * pid;
-    }
-    struct Stage { const char* src; const char* ws; int in_unit, w_unit, nwp, cnt, k; };
-    auto stage_of = [&](const uint4* src, int in_unit, const uint4* ws, int w_unit, int nwp) {
-        Stage st{reinterpret_cast<const char*>(src), reinterpret_cast<const char*>(ws), in_unit, w_unit, nwp, cnt_in + ((nwp + 3) >> 2), 0};
-        return st;
-    };
-    auto issue_one = [&](const Stage& st, int k) {           // k < st.cnt, wave-uniform
-        if (k < cnt_in) {
-#pragma unroll
-            for (int i = 0; i < kMaxIn; ++i)
-                if (k == i) dma(reinterpret_cast<const uint4*>(st.src + off_in[i]), st.in_unit + unit_in[i]);
-        } else {
-            int wp = wave + 4 * (k - cnt_in);
-            wp = wp < st.nwp ? wp : st.nwp - 1;
-            dma(reinterpret_cast<const uint4*>(st.ws + (unsigned)((64 * wp + lane) * 16)), st.w_unit + 64 * wp);
-        }
-    };
-    auto issue_some = [&](Stage& st, int npieces) {
-        for (int i = 0; i < npieces && st.k < st.cnt; ++i, ++st.k) issue_one(st, st.k);
-    };
-    auto issue = [&](const uint4* src, int in_unit, const uint4* ws, int w_unit, int nwp) {
-        Stage st = stage_of(src, in_unit, ws, w_unit, nwp);
-        issue_some(st, st.cnt);
-    };
-    auto in_plane = [&](int c, bool lo_plane) -> const uint4* {
+    auto in_plane = [&](const Src& t, int c, bool lo_plane) -> const uint4* {
         const bool first = c < C8_0;
-        const H16Seg& sg = a.seg[first ? 0 : 1];
-        const uint4* base = lo_plane ? sg.lo : sg.hi;
-        return base + (first ? seg_off0 : seg_off1) + (long)(first ? c : c - C8_0) * plane;
+        const uint4* base = first ? (lo_plane ? t.lo0 : t.hi0) : (lo_plane ? t.lo1 : t.hi1);
+        return base + (long)(first ? c : c - C8_0) * plane;
     };
-    // TERMS == 3 issues its copies as straight-line steps at fixed K blocks (the generic "next n pieces" loop above costs a
-    // wave tens of scalar branches per piece, during which it issues no MFMAs: measured 10 % of the fp32 blocked kernel)
-    bool in_ok[kMaxIn];
-#pragma unroll
-    for (int k = 0; k < kMaxIn; ++k) in_ok[k] = wave + 4 * k < NIN;
-    auto issue_in = [&](const uint4* src, int in_unit) {
+    // Copies are issued as straight-line steps at fixed K blocks of the running chunk (a generic "next n pieces" loop costs a
+    // wave tens of scalar branches per piece, during which it issues no MFMAs): this wave's share = input pieces wave,
+    // wave + 4, ... and weight pieces likewise.  Per-lane source position of an input piece p: q0 + 64 * p + lane, clamped
+    // into the plane (positions past the end only feed outputs that the epilogue drops).
+    auto issue_in = [&](const Src& t, const uint4* src, int in_unit) {
         if (!src) return;
         const char* sp = reinterpret_cast<const char*>(src);
+        const int qb = t.bq * kBQ + lane;
+        const int wv = opaque(wave);         // keeps the per-piece predicates / LDS offsets from being hoisted into SGPRs for the whole kernel
 #pragma unroll
-        for (int k = 0; k < kMaxIn; ++k)
-            if (in_ok[k]) dma(reinterpret_cast<const uint4*>(sp + off_in[k]), in_unit + unit_in[k]);
+        for (int k = 0; k < kMaxIn; ++k) {
+            const int pid = wv + 4 * k;
+            if (pid < NIN) {
+                int q = qb + 64 * pid;
+                q = q < plane ? q : plane - 1;
+                dma(sp + (unsigned)q * 16u, in_unit + 64 * pid);
+            }
+        }
     };
     auto issue_w = [&](const uint4* ws, int w_unit, int nwp, int k0, int k1) {      // this wave's weight pieces k0 .. k1 - 1
         if (!ws) return;
         const char* wp8 = reinterpret_cast<const char*>(ws);
+        const int wv = opaque(wave);
 #pragma unroll
         for (int k = 0; k < kMaxW; ++k) {
-            const int wp = wave + 4 * k;
-            if (k >= k0 && k < k1 && wp < nwp) dma(reinterpret_cast<const uint4*>(wp8 + (unsigned)((64 * wp + lane) * 16)), w_unit + 64 * wp);
+            const int wp = wv + 4 * k;
+            if (k >= k0 && k < k1 && wp < nwp) dma(wp8 + (unsigned)((64 * wp + lane) * 16), w_unit + 64 * wp);
         }
     };
 
-    f32x16 acc[NCG][kQG];
-#pragma unroll
-    for (int g = 0; g < NCG; ++g)
-#pragma unroll
-        for (int j = 0; j < kQG; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
-
-    // operand slots (16-byte units), independent of the chunk
-    int bslot[kKB], aslot[kKB];
-#pragma unroll
-    for (int kb = 0; kb < kKB; ++kb) {
-        const int tap = (2 * kb + hi) > 8 ? 8 : (2 * kb + hi);
-        bslot[kb] = wave * (kQG * 32) + lo + (tap / 3) * Wp + (tap % 3);
-        aslot[kb] = tap * BN + lo;
-    }
+    // operand slots (16-byte units) of K block kb: tap = 2 * kb + hi (clamped to 8), B at wave * 128 + lo + (tap / 3) * Wp + tap % 3,
+    // A at tap * BN + lo.  They are formed where they are used from two base registers (ten persistent slot registers were what
+    // pushed the 64-cout kernels over 256 VGPRs once the tile loop kept them alive across the epilogue); `hsel` is re-laundered
+    // per product so that the compiler does not hoist the ten sums back out.
+    const int bbase = wave * (kQG * 32) + lo, abase = lo;
+    auto bslot_of = [&](int kb, int hsel) {
+        const int t0 = 2 * kb, t1 = (2 * kb + 1) > 8 ? 8 : 2 * kb + 1;
+        const int o0 = (t0 / 3) * Wp + (t0 % 3), o1 = (t1 / 3) * Wp + (t1 % 3);
+        return bbase + (hsel ? o1 : o0);
+    };
+    auto aslot_of = [&](int kb, int hsel) {
+        const int t0 = 2 * kb, t1 = (2 * kb + 1) > 8 ? 8 : 2 * kb + 1;
+        return abase + (hsel ? t1 * BN : t0 * BN);
+    };
+    auto vopaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
     const bool zero_half = hi != 0;            // K block 4: the second half-wave has no tap
 
-    // The LDS-DMA path of a CU accepts about one 1-KiB copy per 50 cycles, and a wave stays blocked in its copy until the
-    // copies of the other waves ahead of it are accepted (measured: ~350 cycles per copy when all 8 waves of a CU issue at
-    // once).  Probe switch `stagger`: wave w issues its whole share of the pending stage after the MFMAs of K block w.
-    const bool stagger = (a.desync & 8192) != 0;    // measured: no gain over the even spread (0.477 vs 0.462 ms), off
+    f32x16 acc[NCG][kQG];
     // One product of a chunk: x(in_unit) * w(w_unit) over its 5 K blocks.  Operands of K block kb + 1 are fetched before
-    // the MFMAs of kb issue, so a wave that has its SIMD to itself does not wait for LDS between K blocks.
-    auto load_ab = [&](int kb, int in_unit, int w_unit, v8 (&av)[NCG], v8 (&bv)[kQG]) {
+    // the MFMAs of kb issue; `step(kb)` runs after the MFMAs of K block kb (copy issue).
+    auto load_ab = [&](int kb, int hsel, int in_unit, int w_unit, v8 (&av)[NCG], v8 (&bv)[kQG]) {
+        const int as = w_unit + aslot_of(kb, hsel), bs = in_unit + bslot_of(kb, hsel);
 #pragma unroll
         for (int g = 0; g < NCG; ++g) {
-            av[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
+            av[g] = *reinterpret_cast<const v8*>(smem + as + g * 32);
             if (kb == kKB - 1 && zero_half) av[g] = v8{0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
-        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
+        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + bs + 32 * j);
     };
-    auto mfma_chunk = [&](int in_unit, int w_unit, Stage& pend, int per_kb) {
+    auto mfma_chunk_s = [&](int in_unit, int w_unit, auto&& step) {
         v8 av[2][NCG], bv[2][kQG];
-        load_ab(0, in_unit, w_unit, av[0], bv[0]);
+        const int hsel = vopaque(hi);
+        load_ab(0, hsel, in_unit, w_unit, av[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < kKB; ++kb) {
-            if (kb + 1 < kKB) load_ab(kb + 1, in_unit, w_unit, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            if (kb + 1 < kKB) load_ab(kb + 1, hsel, in_unit, w_unit, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
 #pragma unroll
             for (int g = 0; g < NCG; ++g)
 #pragma unroll
                 for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(av[kb & 1][g], bv[kb & 1][j], acc[g][j]);
-            if (stagger) { if (kb == wave) issue_some(pend, pend.cnt); } else issue_some(pend, per_kb);
+            step(kb);
         }
     };
     // the two products that read the hi tile: x_hi * w_lo + x_hi * w_hi (B operands fetched once)
-    auto load_a2b = [&](int kb, int in_unit, int w_unit, v8 (&ah)[NCG], v8 (&al)[NCG], v8 (&bv)[kQG]) {
+    auto load_a2b = [&](int kb, int hsel, int in_unit, int w_unit, v8 (&ah)[NCG], v8 (&al)[NCG], v8 (&bv)[kQG]) {
+        const int as = w_unit + aslot_of(kb, hsel), bs = in_unit + bslot_of(kb, hsel);
 #pragma unroll
         for (int g = 0; g < NCG; ++g) {
-            ah[g] = *reinterpret_cast<const v8*>(smem + w_unit + aslot[kb] + g * 32);
-            al[g] = *reinterpret_cast<const v8*>(smem + w_unit + WUNITS + aslot[kb] + g * 32);
+            ah[g] = *reinterpret_cast<const v8*>(smem + as + g * 32);
+            al[g] = *reinterpret_cast<const v8*>(smem + as + WUNITS + g * 32);
             if (kb == kKB - 1 && zero_half) { ah[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; al[g] = v8{0, 0, 0, 0, 0, 0, 0, 0}; }
         }
 #pragma unroll
-        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + in_unit + bslot[kb] + 32 * j);
-    };
-    auto mfma_chunk_hi2 = [&](int in_unit, int w_unit, Stage& pend, int per_kb) {
-        v8 ah[2][NCG], al[2][NCG], bv[2][kQG];
-        load_a2b(0, in_unit, w_unit, ah[0], al[0], bv[0]);
-#pragma unroll
-        for (int kb = 0; kb < kKB; ++kb) {
-            if (kb + 1 < kKB) load_a2b(kb + 1, in_unit, w_unit, ah[(kb + 1) & 1], al[(kb + 1) & 1], bv[(kb + 1) & 1]);
-#pragma unroll
-            for (int g = 0; g < NCG; ++g)
-#pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[kb & 1][g], bv[kb & 1][j], acc[g][j]);
-#pragma unroll
-            for (int g = 0; g < NCG; ++g)
-#pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[kb & 1][g], bv[kb & 1][j], acc[g][j]);
-            if (stagger) { if (kb == wave) issue_some(pend, pend.cnt); } else issue_some(pend, per_kb);
-        }
-    };
-
-    // TERMS == 3 variants: `step(kb)` runs after the MFMAs of K block kb (straight-line copy issue, see issue_in / issue_w)
-    // (fetching operands TWO K blocks ahead -- three register stages, 236 VGPRs -- measured no faster: 0.42 vs 0.40-0.41 ms)
-    auto mfma_chunk_s = [&](int in_unit, int w_unit, auto&& step) {
-        v8 av[2][NCG], bv[2][kQG];
-        load_ab(0, in_unit, w_unit, av[0], bv[0]);
-#pragma unroll
-        for (int kb = 0; kb < kKB; ++kb) {
-            if (kb + 1 < kKB) load_ab(kb + 1, in_unit, w_unit, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
-#pragma unroll
-            for (int g = 0; g < NCG; ++g)
-#pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(av[kb & 1][g], bv[kb & 1][j], acc[g][j]);
-            step(kb);
-        }
+        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + bs + 32 * j);
     };
     auto mfma_chunk_hi2_s = [&](int in_unit, int w_unit, auto&& step) {
         v8 ah[2][NCG], al[2][NCG], bv[2][kQG];
-        load_a2b(0, in_unit, w_unit, ah[0], al[0], bv[0]);
+        const int hsel = vopaque(hi);
+        load_a2b(0, hsel, in_unit, w_unit, ah[0], al[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < kKB; ++kb) {
-            if (kb + 1 < kKB) load_a2b(kb + 1, in_unit, w_unit, ah[(kb + 1) & 1], al[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            if (kb + 1 < kKB) load_a2b(kb + 1, hsel, in_unit, w_unit, ah[(kb + 1) & 1], al[(kb + 1) & 1], bv[(kb + 1) & 1]);
 #pragma unroll
             for (int g = 0; g < NCG; ++g)
 #pragma unroll
@@ -413,97 +414,107 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
             step(kb);
         }
     };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int j = 0; j < kQG; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.0f;
+    };
+    auto epilogue = [&](const Ep& t) {
+        H16Args ea;                                          // only the fields the epilogue reads are actually loaded
+        __builtin_memcpy(&ea, args(), sizeof(H16Args));
+        if constexpr (OUT == OUT_B16) h16_epilogue_b16<BF, NCG, EPI>(ea, acc, t.n, t.cb, t.bq, nblk_q, t.aux, tid);
+        else conv_epilogue<NCG, EPI>(ea.c, acc, t.n, t.cb, t.bq, nblk_q, t.aux, tid);
+    };
 
-    const bool up_front = (a.desync & 4096) != 0;           // probe aid: issue a stage's copies in one go, before the MFMAs
-    if (TERMS == 1) {
-        // LDS: 3 stages of [input tile | weight plane hi]
+    if constexpr (TERMS == 1) {
+        // LDS: 3 stages of [input tile | weight plane hi]; per tile, no prefetch across tiles (the opt-in plain-16-bit path)
         const int STU = INU + WUNITS;
-        const int cnt = cnt_in + ((WPIECES + 3) >> 2), per_kb = (cnt + kKB - 1) / kKB;
-        issue(in_plane(0, false), 0, wsrc, INU, WPIECES);
-        if (nchunk > 1) issue(in_plane(1, false), STU, wsrc + 2 * WUNITS, STU + INU, WPIECES);
-        int st = 0;                                     // stage of chunk c
-        for (int c = 0; c < nchunk; ++c) {
-            wait_vm(c + 1 < nchunk ? cnt : 0);          // chunk c has landed (chunk c + 1 may still be in flight)
-            cbarrier();               // ... for every wave; and every wave is done reading chunk c - 1
-            if (a.trace && c == 0) tr1 = __builtin_amdgcn_s_memtime();
-            const int s2 = st == 0 ? 2 : st - 1;        // (c + 2) % 3 == (c - 1) % 3
-            const int cn = c + 2 < nchunk ? c + 2 : c;  // nothing left to prefetch: an empty stage
-            Stage pend = stage_of(in_plane(cn, false), s2 * STU, wsrc + (long)cn * (2 * WUNITS), s2 * STU + INU, WPIECES);
-            if (c + 2 >= nchunk) pend.cnt = 0;
-            if (up_front) issue_some(pend, pend.cnt);
-            if (!(abl & 2)) mfma_chunk(st * STU, st * STU + INU, pend, per_kb);
-            issue_some(pend, pend.cnt);
-            st = st == 2 ? 0 : st + 1;
+        const int cnt_in = (NIN + 3) >> 2;
+        auto issue_stage = [&](const Src& t, int c, int stage) {       // every wave issues exactly `cnt` copies (a surplus repeats the last piece)
+            const char* sp = reinterpret_cast<const char*>(in_plane(t, c, false));
+            const char* wp8 = reinterpret_cast<const char*>(t.wsrc + (long)c * (2 * WUNITS));
+            const int qb = t.bq * kBQ + lane;
+            const int wv = opaque(wave);
+#pragma unroll
+            for (int k = 0; k < kMaxIn; ++k)
+                if (k < cnt_in) {
+                    int pid = wv + 4 * k;
+                    pid = pid < NIN ? pid : NIN - 1;
+                    int q = qb + 64 * pid;
+                    q = q < plane ? q : plane - 1;
+                    dma(sp + (unsigned)q * 16u, stage * STU + 64 * pid);
+                }
+#pragma unroll
+            for (int k = 0; k < (WPIECES + 3) / 4; ++k) {
+                int wp = wv + 4 * k;
+                wp = wp < WPIECES ? wp : WPIECES - 1;
+                dma(wp8 + (unsigned)((64 * wp + lane) * 16), stage * STU + INU + 64 * wp);
+            }
+        };
+        for (int tk = wslot; tk < tcnt; tk += nx) {
+            const Src t = src_of(tk);
+            if (tk != wslot) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); cbarrier(); }   // every wave has left the previous tile's LDS
+            zero_acc();
+            issue_stage(t, 0, 0);
+            if (nchunk > 1) issue_stage(t, 1, 1);
+            int st = 0;                                     // stage of chunk c
+            for (int c = 0; c < nchunk; ++c) {
+                // chunk c has landed.  (Round 2 waited with a COUNTED vmcnt so that chunk c + 1 stayed in flight; inside the tile
+                // walk the compiler may place a scratch access between the copies and the wait, which would shift the count
+                // onto a copy of THIS chunk -- chunk c + 1 was issued a whole chunk ago, so waiting for it costs little.)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                cbarrier();                                 // ... for every wave; and every wave is done reading chunk c - 1
+                const int s2 = st == 0 ? 2 : st - 1;        // (c + 2) % 3 == (c - 1) % 3
+                const bool pre = c + 2 < nchunk;
+                mfma_chunk_s(st * STU, st * STU + INU, [&](int kb) { if (kb == 0 && pre) issue_stage(t, c + 2, s2); });
+                st = st == 2 ? 0 : st + 1;
+            }
+            epilogue(ep_of(t));
         }
     } else {
-        // LDS: HI[0] HI[1] LO W[0] W[1], W = [hi plane | lo plane]
-        // (the same plan staged through VGPRs -- global_load_dwordx4 + ds_write_b128, 36 more registers -- measured 0.425 ms for
-        // the gates launch, identical to the LDS-DMA form: the copy method is not what bounds this loop)
+        // LDS: HI[0] HI[1] LO W[0] W[1], W = [hi plane | lo plane].  The chunk stream runs ACROSS tiles: buffer parity follows the
+        // global chunk counter g, and the stage after the last chunk of a tile is chunk 0 of the workgroup's next tile -- `src`
+        // always describes the tile whose chunks are being STAGED, `ep` the tile being multiplied.
         const int LOU = 2 * INU, WU0 = 3 * INU;
-        const int cntA = cnt_in + ((2 * WPIECES + 3) >> 2), cntB = cnt_in;
-        const int perA = (cntA + kKB - 1) / kKB, perB = (cntB + kKB - 1) / kKB;
-        issue(in_plane(0, false), 0, wsrc, WU0, 2 * WPIECES);
-        issue(in_plane(0, true), LOU, wsrc, 0, 0);
-        for (int c = 0; c < nchunk; ++c) {
-            const int b = c & 1;
-            const bool more = c + 1 < nchunk;
-            const int cn = more ? c + 1 : c;
-            unsigned long long* tq = (a.trace && tid == 0 && c < 7) ? a.trace + (long)blockIdx.x * 64 + 8 + c * 6 : nullptr;
-            if (tq) tq[0] = __builtin_amdgcn_s_memtime();
-            wait_vm(0);                                 // hi, lo and weights of chunk c have landed
-            if (tq) tq[1] = __builtin_amdgcn_s_memtime();
-            cbarrier();               // ... for every wave; every wave is done with chunk c - 1
-            if (tq) tq[2] = __builtin_amdgcn_s_memtime();
-            if (a.trace && c == 0) tr1 = __builtin_amdgcn_s_memtime();
-            const uint4* nhi = more ? in_plane(cn, false) : nullptr;
-            const uint4* nws = more ? wsrc + (long)cn * (2 * WUNITS) : nullptr;
+        Src src = src_of(wslot);
+        Ep ep = ep_of(src);
+        issue_in(src, in_plane(src, 0, false), 0);
+        issue_w(src.wsrc, WU0, 2 * WPIECES, 0, kMaxW);
+        issue_in(src, in_plane(src, 0, true), LOU);
+        // one chunk of the stream: multiply the chunk in buffer parity g & 1 while (cn, any) -- chunk cn of `src`, if any -- is staged
+        auto chunk = [&](int g, int cn, bool any) {
+            const int b = g & 1;
+            const uint4* nhi = any ? in_plane(src, cn, false) : nullptr;
+            const uint4* nlo = any ? in_plane(src, cn, true) : nullptr;
+            const uint4* nws = any ? src.wsrc + (long)cn * (2 * WUNITS) : nullptr;
             const int nwu = WU0 + (b ^ 1) * 2 * WUNITS;
-            auto stepA = [&](int kb) {                   // next hi tile after K block 0, next weights after 1 and 2
-                if (kb == 0) issue_in(nhi, (b ^ 1) * INU);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hi, lo and weights of this chunk have landed (and, after an
+            cbarrier();                                               // epilogue, its stores have retired) ... for every wave; every
+                                                                      // wave is done with the previous chunk
+            mfma_chunk_s(LOU, WU0 + b * 2 * WUNITS, [&](int kb) {      // x_lo * w_hi; next hi tile after K block 0, weights after 1 and 2
+                if (kb == 0) issue_in(src, nhi, (b ^ 1) * INU);
                 else if (kb == 1) issue_w(nws, nwu, 2 * WPIECES, 0, (kMaxW + 1) / 2);
                 else if (kb == 2) issue_w(nws, nwu, 2 * WPIECES, (kMaxW + 1) / 2, kMaxW);
-            };
-            if (prio) __builtin_amdgcn_s_setprio(0);
-            if (!(abl & 2)) mfma_chunk_s(LOU, WU0 + b * 2 * WUNITS, stepA);          // x_lo * w_hi
-            else { stepA(0); stepA(1); stepA(2); }
-            if (prio) __builtin_amdgcn_s_setprio(3);
-            if (tq) tq[3] = __builtin_amdgcn_s_memtime();
-            cbarrier();               // the lo tile is free
-            if (tq) tq[4] = __builtin_amdgcn_s_memtime();
-            const uint4* nlo = more ? in_plane(cn, true) : nullptr;
-            auto stepB = [&](int kb) { if (kb == 0) issue_in(nlo, LOU); };               // next lo tile after K block 0
-            if (prio) __builtin_amdgcn_s_setprio(0);
-            if (!(abl & 2)) mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, stepB);   // x_hi * w_lo + x_hi * w_hi
-            else stepB(0);
-            if (prio) __builtin_amdgcn_s_setprio(3);
-            if (tq) tq[5] = __builtin_amdgcn_s_memtime();
+            });
+            cbarrier();                                               // the lo tile is free
+            mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, [&](int kb) { if (kb == 0) issue_in(src, nlo, LOU); });   // x_hi * (w_lo, w_hi)
+        };
+        int g = 0;
+        for (int tk = wslot;;) {
+            zero_acc();
+            for (int c = 0; c + 1 < nchunk; ++c, ++g) chunk(g, c + 1, true);
+            const bool any = tk + nx < tcnt;                          // last chunk of this tile: stage chunk 0 of the next one
+            if (any) src = src_of(tk + nx);
+            chunk(g, 0, any);
+            ++g;
+            epilogue(ep);                                             // no LDS: the next tile's first chunk is landing meanwhile
+            if (!any) break;
+            tk += nx;
+            ep = ep_of(src);
         }
-    }
-    if (a.trace) tr2 = __builtin_amdgcn_s_memtime();
-    if (abl & 1) {
-        float t = 0.f;
-        for (int g = 0; g < NCG; ++g) for (int j = 0; j < kQG; ++j) for (int r = 0; r < 16; ++r) t += acc[g][j][r];
-        if (t == 1234.5f) a.c.stats[tid] = t + __builtin_bit_cast(float, smem[tid].x);
-    } else if (OUT == OUT_B16) {
-        h16_epilogue_b16<BF, NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
-    } else {
-        if constexpr (EPI <= EPI_SWISH) {
-            conv_epilogue_flat<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid, reinterpret_cast<float*>(smem),
-                                         (a.trace && tid == 0) ? a.trace + (long)blockIdx.x * 64 + 52 : nullptr);
-            goto done;
-        }
-        conv_epilogue<NCG, EPI>(a.c, acc, n, cb, bq, nblk_q, aux, tid);
-    }
-done:
-    if (a.trace && tid == 0) {
-        const unsigned long long tr3 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tr4 = __builtin_amdgcn_s_memtime();
-        unsigned long long* t = a.trace + (long)blockIdx.x * 64;
-        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = tr4;
-        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
-        t[6] = __builtin_amdgcn_s_getreg((3 << 11) | 20);          // HW_REG_XCC_ID
-        t[7] = ((unsigned long long)bq << 32) | (unsigned)n;
     }
 }
 
@@ -513,71 +524,23 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
     constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;
     const int TL = kBQ + 2 * a.c.Wp + 2;
     const int NIN = (TL + 63) >> 6;
-    const size_t lds = std::max(TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)(3 * NIN + 4 * WPIECES) * 1024,
-                                kFlatLdsBytes);
+    const size_t lds = TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)(3 * NIN + 4 * WPIECES) * 1024;
     if (lds > 160 * 1024 || NIN > 16) return hipErrorInvalidValue;
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.c.Hp, a.c.Wp);
-    dim3 grid(nblk_q * pw.ncb * n);
-    static const int dbg = [] { const char* e = getenv("TTC_H16_DEBUG"); return e ? atoi(e) : 0; }();
-    size_t lds_req = lds;
-    if (dbg >= 2) lds_req = 100 * 1024;          // probe: force one workgroup per CU
-    if (dbg) {
-        static int shown = 0;
-        if (shown++ < 12) {
-            int nb = -1;
-            (void)lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds_req);
-            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, kThreads, lds_req);
-            fprintf(stderr, "[h16] terms %d ncg %d epi %d out %d: grid %u lds %zu B -> occupancy API %d blocks/CU (%s)\n", TERMS, NCG, EPI, OUT,
-                    grid.x, lds_req, nb, hipGetErrorString(e));
-        }
-    }
-    if (lds_req != lds) { if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds_req); e != hipSuccess) return e; }
-    static const char* trace_path = getenv("TTC_H16_TRACE");
-    static int trace_left = trace_path ? 1 : 0;
-    static const int trace_epi = [] { const char* e = getenv("TTC_H16_TRACE_EPI"); return e ? atoi(e) : (int)EPI_RAW; }();   // which layer kind to trace
-    if (trace_left > 0 && grid.x > 4000 && EPI == trace_epi && (NCG == 2 || trace_epi != EPI_RAW)) {   // probe aid: per-workgroup timestamps of one big launch
-        trace_left--;
-        unsigned long long* d = nullptr;
-        const size_t bytes = (size_t)grid.x * 64 * sizeof(unsigned long long);
-        (void)hipStreamSynchronize(s);
-        if (hipMalloc(&d, bytes) == hipSuccess) {
-            (void)hipMemset(d, 0, bytes);
-            H16Args b = a; b.trace = d;
-            hipEvent_t e0, e1;
-            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-            float ms = 0.f;
-            for (int rep = 0; rep < 2; ++rep) {          // second pass = warm
-                (void)hipEventRecord(e0, s);
-                hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds_req, s, b, nblk_q, pw.ncb);
-                (void)hipEventRecord(e1, s);
-                (void)hipStreamSynchronize(s);
-                (void)hipEventElapsedTime(&ms, e0, e1);
-            }
-            std::vector<unsigned long long> h((size_t)grid.x * 64);
-            (void)hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
-            (void)hipFree(d);
-            {   // shader clock under this kernel's load: s_memtime span of ONE CU (counters of different CUs are not aligned) / event time
-                const unsigned long long id0 = (h[5] & 0xff00u) | ((h[5] >> 12) & 0xfu) << 16 | (h[6] << 24);
-                unsigned long long lo = ~0ull, hi = 0;
-                for (unsigned w = 0; w < grid.x; ++w) {
-                    const unsigned long long* t = &h[(size_t)w * 64];
-                    const unsigned long long id = (t[5] & 0xff00u) | ((t[5] >> 12) & 0xfu) << 16 | (t[6] << 24);
-                    if (id != id0 || !t[0]) continue;
-                    lo = std::min(lo, t[0]); hi = std::max(hi, t[4]);
-                }
-                fprintf(stderr, "[h16] traced launch: %.3f ms by events, one CU busy for %llu s_memtime ticks -> >= %.2f GHz shader clock\n", ms, hi - lo,
-                        (double)(hi - lo) / (ms * 1e-3) / 1e9);
-            }
-            if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
-            fprintf(stderr, "[h16] trace of terms %d ncg %d epi %d grid %u -> %s\n", TERMS, NCG, EPI, grid.x, trace_path);
-        }
-    }
-    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), grid, dim3(kThreads), lds_req, s, a, nblk_q, pw.ncb);
+    const int ntiles = nblk_q * pw.ncb * n;
+    // persistent grid = the resident set: 2 workgroups per CU (TTC_H16_PERSIST overrides; 0 = one workgroup per tile)
+    static const int resident = [] {
+        if (const char* e = getenv("TTC_H16_PERSIST")) return atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * cus;
+    }();
+    const int grid = resident > 0 ? std::min(ntiles, resident) : ntiles;
+    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles);
     return hipGetLastError();
 }
-
 
 }  // namespace
 
@@ -659,23 +622,18 @@ long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cou
 }
 
 
-hipError_t conv_launch_h16(const H16Args& a_in, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s) {
+hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s) {
     const bool bf = mode == 1;
     const int terms = pw.terms == 1 ? 1 : 3;
-    static const int desync_env = [] { const char* e = getenv("TTC_H16_DESYNC"); return e ? atoi(e) : -1; }();   // probe switches
-    H16Args a = a_in;
-    if (desync_env >= 0) a.desync = desync_env;
-    static const int abl_env = [] { const char* e = getenv("TTC_H16_ABL"); return e ? atoi(e) : 0; }();
-    a.abl = abl_env;
 #define TTC_H16_CASE(BFV, T, ncg, e, o) \
     if ((int)bf == BFV && terms == T && pw.BN == ncg * 32 && epi == e && out_kind == o) return launch_h16<BFV, T, ncg, e, o>(a, pw, n, s);
-#define TTC_H16_LAYERS(BFV, T)                                                                         \
-    TTC_H16_CASE(BFV, T, 2, EPI_RAW, OUT_F32)             /* ConvGRU gates                          */ \
-    TTC_H16_CASE(BFV, T, 1, EPI_SSE, OUT_F32)             /* ConvGRU candidate                      */ \
-    TTC_H16_CASE(BFV, T, 2, EPI_SWISH, OUT_F32)           /* conv_swish_gn blocks                   */ \
-    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_RELU, OUT_B16)       /* DSen2 in / x1 convs -> blocked 16-bit   */ \
-    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_RES, OUT_B16)        /* DSen2 residual convs -> blocked 16-bit  */ \
-    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_TANH_ADD, OUT_F32)   /* DSen2 head                             */
+#define TTC_H16_LAYERS(BFV, T)                                                                                       \
+    TTC_H16_CASE(BFV, T, 2, EPI_RAW, OUT_B16)             /* ConvGRU gates           -> raw fp32, blocked halves  */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_SSE, OUT_B16)             /* ConvGRU candidate       -> raw fp32, blocked halves  */ \
+    TTC_H16_CASE(BFV, T, 2, EPI_SWISH, OUT_B16)           /* conv_swish_gn blocks    -> raw fp32, blocked halves  */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_RELU, OUT_B16)       /* DSen2 in / x1 convs     -> blocked 16-bit pair       */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_RES, OUT_B16)        /* DSen2 residual convs    -> blocked 16-bit pair       */ \
+    TTC_H16_CASE(BFV, T, 1, EPI_BIAS_TANH_ADD, OUT_F32)   /* DSen2 head              -> fp32 planar               */
     TTC_H16_LAYERS(0, 3)
     TTC_H16_LAYERS(0, 1)
     TTC_H16_LAYERS(1, 3)

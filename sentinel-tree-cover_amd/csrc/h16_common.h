@@ -41,6 +41,20 @@ template <> struct Elem<1> {
 };
 
 
+// Raw (pre-GroupNorm) conv outputs of the 16-bit engine are EXACT fp32 values stored channel-blocked as a plane of top and a
+// plane of bottom 16-bit halves ([n][C8][P][8] each, one 16-byte vector per (channel block, position) and plane): the conv
+// epilogue stores them straight from its accumulators, the elementwise consumers read 16-byte vectors.
+__device__ __forceinline__ unsigned raw_top2(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+__device__ __forceinline__ unsigned raw_bot2(float a, float b) { return (__float_as_uint(a) & 0xffffu) | (__float_as_uint(b) << 16); }
+struct Raw16 { const uint4* top; const uint4* bot; };     // [n][C8][P] units each; bot = top + n * C8 * P for a launch over n sequences
+__device__ __forceinline__ void raw_load8(const uint4* top, const uint4* bot, long u, float (&v)[8]) {
+    const uint4 h = top[u], l = bot[u];
+    v[0] = __uint_as_float((h.x << 16) | (l.x & 0xffffu)); v[1] = __uint_as_float((h.x & 0xffff0000u) | (l.x >> 16));
+    v[2] = __uint_as_float((h.y << 16) | (l.y & 0xffffu)); v[3] = __uint_as_float((h.y & 0xffff0000u) | (l.y >> 16));
+    v[4] = __uint_as_float((h.z << 16) | (l.z & 0xffffu)); v[5] = __uint_as_float((h.z & 0xffff0000u) | (l.z >> 16));
+    v[6] = __uint_as_float((h.w << 16) | (l.w & 0xffffu)); v[7] = __uint_as_float((h.w & 0xffff0000u) | (l.w >> 16));
+}
+
 // one channel block (8 channels) of one position: x = hi + lo
 template <int BF>
 __device__ __forceinline__ void b16_store8(uint4* hi, uint4* lo, long u, const float (&v)[8]) {

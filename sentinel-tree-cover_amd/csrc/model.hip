@@ -201,6 +201,9 @@ __global__ void k_block_finalize(FinArgs a) {
 }
 
 // final block tail + 1x1 head (train-model.py:226-231): sigmoid(sum_c hw[c] * z[c] + hb)
+// BLK: the raw conv output is the 16-bit engine's channel-blocked split planes (Raw16, h16_common.h), `yraw` = its top plane
+// and the bottom plane follows after gridDim.y * (C / 8) * PS units
+template <bool BLK>
 __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
                        const float* __restrict__ headp, float* __restrict__ out, int C, int P, int ow, int tr) {
     extern __shared__ float sm[];            // scale shift ssew headw
@@ -215,12 +218,31 @@ __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__
     if (p >= P) return;
     const int oh = P / ow;
     const long PS = (long)oh * (ow + 2);                                   // raw plane with the conv's input pitch
-    const float* y = yraw + (long)n * C * PS + (p / ow) * (ow + 2) + p % ow;
+    const long s0 = (p / ow) * (ow + 2) + p % ow;
     float gate = prm[3 * C];
-    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * PS] * sm[c] + sm[C + c]);
-    gate = sigm(gate);
     float logit = headp[C];
-    for (int c = 0; c < C; ++c) logit += sm[3 * C + c] * ((y[(long)c * PS] * sm[c] + sm[C + c]) * gate);
+    if constexpr (BLK) {
+        const uint4* top = reinterpret_cast<const uint4*>(yraw);
+        const uint4* bot = top + (long)gridDim.y * (C / 8) * PS;
+        float z = 0.f;                                                     // sum_c hw[c] * zn[c]: the gate multiplies it afterwards
+        for (int k = 0; k < C / 8; ++k) {
+            float v[8];
+            raw_load8(top, bot, ((long)n * (C / 8) + k) * PS + s0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * k + j;
+                const float zn = v[j] * sm[c] + sm[C + c];
+                gate += sm[2 * C + c] * zn;
+                z += sm[3 * C + c] * zn;
+            }
+        }
+        logit += z * sigm(gate);
+    } else {
+        const float* y = yraw + (long)n * C * PS + s0;
+        for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * PS] * sm[c] + sm[C + c]);
+        gate = sigm(gate);
+        for (int c = 0; c < C; ++c) logit += sm[3 * C + c] * ((y[(long)c * PS] * sm[c] + sm[C + c]) * gate);
+    }
     out[(long)n * P + (tr ? (p % ow) * oh + p / ow : p)] = sigm(logit);      // tr: the plane is the transposed window
 }
 
@@ -241,6 +263,7 @@ __global__ void k_tap_early(const float* __restrict__ gru_out, int H, int W, int
     out[id] = gru_out[((long)n * 64 + ch) * PP + (long)(y + 1) * Wp + (x + 1)];
 }
 // late = output of the last conv_swish_gn block after its sSE gate (`csse_out_mul/mul:0`), [n, o, o, C] NHWC
+template <bool BLK>
 __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
                            float* __restrict__ out, int C, int P, int ow, int tr) {
     extern __shared__ float sm[];            // scale shift ssew
@@ -255,12 +278,31 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
     if (p >= P) return;
     const int oh = P / ow;
     const long PS = (long)oh * (ow + 2);                                   // raw plane with the conv's input pitch
-    const float* y = yraw + (long)n * C * PS + (p / ow) * (ow + 2) + p % ow;
+    const long s0 = (p / ow) * (ow + 2) + p % ow;
     float gate = prm[3 * C];
-    for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * PS] * sm[c] + sm[C + c]);
-    gate = sigm(gate);
     float* o = out + ((long)n * P + (tr ? (p % ow) * oh + p / ow : p)) * C;
-    for (int c = 0; c < C; ++c) o[c] = (y[(long)c * PS] * sm[c] + sm[C + c]) * gate;
+    if constexpr (BLK) {
+        const uint4* top = reinterpret_cast<const uint4*>(yraw);
+        const uint4* bot = top + (long)gridDim.y * (C / 8) * PS;
+        for (int k = 0; k < C / 8; ++k) {
+            float v[8];
+            raw_load8(top, bot, ((long)n * (C / 8) + k) * PS + s0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gate += sm[2 * C + 8 * k + j] * (v[j] * sm[8 * k + j] + sm[C + 8 * k + j]);
+        }
+        gate = sigm(gate);
+        for (int k = 0; k < C / 8; ++k) {
+            float v[8];
+            raw_load8(top, bot, ((long)n * (C / 8) + k) * PS + s0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[8 * k + j] = (v[j] * sm[8 * k + j] + sm[C + 8 * k + j]) * gate;
+        }
+    } else {
+        const float* y = yraw + (long)n * C * PS + s0;
+        for (int c = 0; c < C; ++c) gate += sm[2 * C + c] * (y[(long)c * PS] * sm[c] + sm[C + c]);
+        gate = sigm(gate);
+        for (int c = 0; c < C; ++c) o[c] = (y[(long)c * PS] * sm[c] + sm[C + c]) * gate;
+    }
 }
 
 // ======================================================================================================================
@@ -268,7 +310,7 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
 // writing the NEXT conv's input channel-blocked as hi + lo 16-bit K vectors ([n][C8][plane][8]).  The ConvGRU state lives
 // only as such a pair (fp16: 22 mantissa bits).
 template <int BF>
-__global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __restrict__ gn, GruParams prm, B16 hcur, B16 rh,
+__global__ void k_gru_apply1_b16(Raw16 yg, const float* __restrict__ gn, GruParams prm, B16 hcur, B16 rh,
                                  int H, int W, int N) {
     const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
@@ -277,17 +319,17 @@ __global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __re
     const int py = p / Wp, px = p - py * Wp;
     const int s = reflect_idx(py - 1, H) * Wp + reflect_idx(px - 1, W);
     const float* pr = prm.base + dir * prm.dir_stride;
-    const float* y = yg + (long)n * 64 * P + s;
     const float* g = gn + (long)n * 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long u = ((long)n * 4 + k) * PP + p;
-        float hv[8], o[8];
+        float hv[8], o[8], y[8];
         b16_load8<BF>(hcur.hi, hcur.lo, u, hv);
+        raw_load8(yg.top, yg.bot, ((long)n * 8 + k) * P + s, y);          // gates channels 0..31 = r
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = 8 * k + j, gi = c >> 2;
-            const float r = sigm((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[c] + pr[32 + c]);
+            const float r = sigm((y[j] - g[2 * gi]) * g[2 * gi + 1] * pr[c] + pr[32 + c]);
             o[j] = r * hv[j];
         }
         b16_store8<BF>(rh.hi, rh.lo, u, o);
@@ -295,8 +337,8 @@ __global__ void k_gru_apply1_b16(const float* __restrict__ yg, const float* __re
 }
 
 template <int BF>
-__global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
-                                 const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
+__global__ void k_gru_apply2_b16(Raw16 yc, const float* __restrict__ gn, GruParams prm,
+                                 Raw16 yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
                                  B16 hcur, B16 hnext, B16 gru_out, int H, int W, int N, float z) {
     const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
@@ -308,21 +350,21 @@ __global__ void k_gru_apply2_b16(const float* __restrict__ yc, const float* __re
     const int s = reflect_idx(sy0, H) * Wp + reflect_idx(sx0, W);
     const int su = reflect_idx(sy0, H) * W + reflect_idx(sx0, W);      // the debug copy of u stays [c][H][W]
     const float* pr = prm.base + dir * prm.dir_stride;
-    const float* y = yc + (long)n * 32 * P + s;
     const float* g = gn + (long)n * 16;
-    const float* yu = yg + ((long)n * 64 + 32) * P + s;
     const float* gu = gn_gates + (long)n * 32 + 16;
     float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * (H * W) + su : nullptr;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long u = ((long)n * 4 + k) * PP + p;
-        float hv[8], o[8];
+        float hv[8], o[8], y[8], yu[8];
         b16_load8<BF>(hcur.hi, hcur.lo, u, hv);
+        raw_load8(yc.top, yc.bot, ((long)n * 4 + k) * P + s, y);
+        raw_load8(yg.top, yg.bot, ((long)n * 8 + 4 + k) * P + s, yu);      // gates channels 32..63 = u
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = 8 * k + j, gi = c >> 2;
-            const float cand = tanh_fast((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
-            const float uv = sigm((yu[(long)c * P] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
+            const float cand = tanh_fast((y[j] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
+            const float uv = sigm((yu[j] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
             if (uk) uk[(long)c * (H * W)] = uv;
             const float hnew = uv * hv[j] + (1.0f - uv) * cand;
             o[j] = hv[j] * z + hnew * (1.0f - z);
@@ -369,27 +411,35 @@ __global__ void k_block_finalize_b16(FinArgs a) {
     if (MODE == G_POOL) {
         src[0] = (2 * iy) * SP + 2 * ix; src[1] = src[0] + 1; src[2] = src[0] + SP; src[3] = src[2] + 1;
     }
-    const float* y = a.y + (long)n * C * PS;
+    // raw conv output: the 16-bit engine's channel-blocked split planes (a.y = top plane, the bottom plane follows)
+    const uint4* ytop = reinterpret_cast<const uint4*>(a.y);
+    const uint4* ybot = ytop + (long)gridDim.y * (C / 8) * PS;
+    const long ub = (long)n * (C / 8) * PS;
     float gate[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) gate[k] = sseb;
-    for (int c = 0; c < C; ++c) {
-        const float sc = sm[c], sh = sm[C + c], w = sm[2 * C + c];
+    for (int cb = 0; cb < C / 8; ++cb) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) gate[k] += w * (y[(long)c * PS + src[k]] * sc + sh);
+        for (int k = 0; k < NS; ++k) {
+            float v[8];
+            raw_load8(ytop, ybot, ub + (long)cb * PS + src[k], v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gate[k] += sm[2 * C + 8 * cb + j] * (v[j] * sm[8 * cb + j] + sm[C + 8 * cb + j]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < NS; ++k) gate[k] = sigm(gate[k]);
     for (int cb = 0; cb < C / 8; ++cb) {
         float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = 8 * cb + j;
-            const float sc = sm[c], sh = sm[C + c];
-            float v = (y[(long)c * PS + src[0]] * sc + sh) * gate[0];
+        for (int k = 0; k < NS; ++k) {
+            float v[8];
+            raw_load8(ytop, ybot, ub + (long)cb * PS + src[k], v);
 #pragma unroll
-            for (int k = 1; k < NS; ++k) v = fmaxf(v, (y[(long)c * PS + src[k]] * sc + sh) * gate[k]);
-            o[j] = v;
+            for (int j = 0; j < 8; ++j) {
+                const float t = (v[j] * sm[8 * cb + j] + sm[C + 8 * cb + j]) * gate[k];
+                o[j] = k == 0 ? t : fmaxf(o[j], t);
+            }
         }
         b16_store8<BF>(a.dhi, a.dlo, u0 + cb * PD, o);
     }
@@ -667,11 +717,21 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
                            Cx, PP, Cx8, c->frames16.hi, c->frames16.lo);
         TTC_HIP(c, hipGetLastError());
     }
-    auto launch = [&](H16Args& a, const PackedConv& pw, int epi, int nseq) -> ttc_status {
+    // raw (pre-GroupNorm) outputs: exact fp32 as channel-blocked top / bottom half planes in the buffer a planar tensor of the same
+    // shape would fill (top plane first, h16_common.h Raw16); `plane` = rows * input pitch
+    auto raw_of = [](float* buf, int nseq, int C, long plane) {
+        uint4* top = reinterpret_cast<uint4*>(buf);
+        return Raw16{top, top + (long)nseq * (C / 8) * plane};
+    };
+    auto launch = [&](H16Args& a, const PackedConv& pw, int epi, int nseq, float* raw) -> ttc_status {
         a.nchunk = a.seg[0].C8 + a.seg[1].C8;
         if (a.nchunk != pw.nchunk_h) return c->fail(TTC_ERR_STATE, "16-bit conv: channel blocks do not match the packed weights");
         a.w = pw.d_wh; a.w_set_stride = pw.nsets > 1 ? pw.set_stride_h : 0;
-        TTC_HIP(c, conv_launch_h16(a, pw, BF, epi, OUT_F32, nseq, s));
+        const long plane = (long)(a.c.Hp - 2) * a.c.Wp;
+        const Raw16 r = raw_of(raw, nseq, a.c.Cout, plane);
+        a.o_hi = const_cast<uint4*>(r.top); a.o_lo = const_cast<uint4*>(r.bot);
+        a.o_stride_n = (long)(a.c.Cout / 8) * plane; a.o_plane = plane;
+        TTC_HIP(c, conv_launch_h16(a, pw, BF, epi, OUT_B16, nseq, s));
         return TTC_OK;
     };
 
@@ -685,25 +745,24 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
         a.seg[0] = {c->frames16.hi, c->frames16.lo, (long)(g.L + 1) * Cx8 * PP, {(long)st * Cx8 * PP, (long)(g.L - 1 - st) * Cx8 * PP}, Cx8};
         a.seg[1] = {c->h16[cur].hi, c->h16[cur].lo, (long)Hd8 * PP, {0, (long)N * Hd8 * PP}, Hd8};
         a.c.Hp = Hp; a.c.Wp = Wp; a.c.Cout = 2 * Hd; a.c.n_per_set = N;
-        a.c.out = c->yg; a.c.out_stride_n = 2L * Hd * Pr; a.c.out_plane = Pr; a.c.out_pitch = Wp;
         a.c.stats = c->stats;
-        { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2)); }
+        { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2, c->yg)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply1", s);
-            hipLaunchKernelGGL((k_gru_apply1_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
+            hipLaunchKernelGGL((k_gru_apply1_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, raw_of(c->yg, N2, 2 * Hd, Pr), gn_slot[8], gp,
                                c->h16[cur], c->rh16, H, W, N);
             TTC_HIP(c, hipGetLastError());
         }
         a.seg[1].hi = c->rh16.hi; a.seg[1].lo = c->rh16.lo;
-        a.c.Cout = Hd; a.c.out = c->yc; a.c.out_stride_n = (long)Hd * Pr;
+        a.c.Cout = Hd;
         a.c.aux = gp.base + 4 * 32; a.c.aux_set_stride = gp.dir_stride;
-        { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2)); }
+        { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2, c->yc)); }
         TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply2", s);
-            hipLaunchKernelGGL((k_gru_apply2_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
-                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h16[cur], c->h16[cur ^ 1],
+            hipLaunchKernelGGL((k_gru_apply2_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, raw_of(c->yc, N2, Hd, Pr), gn_slot[9], gp,
+                               raw_of(c->yg, N2, 2 * Hd, Pr), gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h16[cur], c->h16[cur ^ 1],
                                st == g.L - 1 ? c->gru16 : B16{}, H, W, N, c->cfg.zoneout);
             TTC_HIP(c, hipGetLastError());
         }
@@ -717,10 +776,9 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
         H16Args a{};
         a.seg[0] = s0; a.seg[1] = s1;
         a.c.Hp = in.h; a.c.Wp = in.w; a.c.Cout = kBlockCout[b]; a.c.n_per_set = N;
-        const long Po = (long)(in.h - 2) * (in.w - 2), Pro = (long)(in.h - 2) * in.w;
-        a.c.out = out; a.c.out_stride_n = (long)a.c.Cout * Pro; a.c.out_plane = Pro; a.c.out_pitch = in.w;
+        const long Po = (long)(in.h - 2) * (in.w - 2);
         a.c.stats = c->stats; a.c.same_pad = same;
-        { KTimer kt(c, tname, s); TTC_CHECK(launch(a, c->w_block[b], EPI_SWISH, N)); }
+        { KTimer kt(c, tname, s); TTC_CHECK(launch(a, c->w_block[b], EPI_SWISH, N, out)); }
         return gn_fin(c, gn_slot[b], N, a.c.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.c.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
@@ -771,7 +829,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     {
         KTimer kt(c, "head", s);
         const int Po = (int)o.area();
-        hipLaunchKernelGGL(k_head, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
+        hipLaunchKernelGGL(k_head<true>, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
                            prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0);
         TTC_HIP(c, hipGetLastError());
     }
@@ -884,7 +942,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
     {
         KTimer kt(c, "head", s);
         const int Po = (int)o.area();
-        hipLaunchKernelGGL(k_head, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
+        hipLaunchKernelGGL(k_head<false>, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
                            prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0);
         TTC_HIP(c, hipGetLastError());
     }
@@ -911,8 +969,10 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
     if (d_late) {
         const int Po = g.y.o * g.x.o;
         const float* gn7 = c->gn + (size_t)7 * c->cfg.max_windows * 2 * 32;
-        hipLaunchKernelGGL(k_tap_late, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
-                           c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0);
+        if (c->half()) hipLaunchKernelGGL(k_tap_late<true>, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
+                                          c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0);
+        else hipLaunchKernelGGL(k_tap_late<false>, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
+                                c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0);
     }
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;

@@ -121,11 +121,10 @@ struct H16Args {
     int nchunk;          // seg[0].C8 + seg[1].C8
     const uint4* w;      // packed LDS images: [set][cout_block][chunk][hi|lo][plane_units]
     long w_set_stride;
-    // channel-blocked 16-bit output (OUT_B16 kernels): [n][Cout8][o_plane] hi (+ lo), pixel (y + c.oy) * c.out_pitch + x + c.ox
+    // channel-blocked output (OUT_B16 kernels): [n][Cout8][o_plane] hi (+ lo), pixel (y + c.oy) * c.out_pitch + x + c.ox for the
+    // DSen2 layers (16-bit pair of the next layer's input); GroupNorm layers (EPI <= EPI_SWISH): o_hi / o_lo = the planes of top /
+    // bottom 16-bit halves of the raw fp32 output at the tile's flat positions q, o_plane = (Hp - 2) * Wp
     uint4* o_hi; uint4* o_lo; long o_stride_n; long o_plane;
-    int abl;             // probe aid, see conv3x3_h16.hip (0 in production)
-    unsigned long long* trace;   // probe aid: per-workgroup timestamps (8 x u64 each) or nullptr
-    int desync;          // probe switches (env TTC_H16_DESYNC): 4096 = issue a stage's copies up front, 8192 = staggered issue; 0 in production
     const uint4* r_hi; const uint4* r_lo;   // EPI_BIAS_RES residual in the same blocked layout / indexing as the output
     ConvArgs c;          // geometry (Hp, Wp, Cout, n_per_set) and the fp32 epilogue operands (out, stats, aux, res, ...)
 };

@@ -69,8 +69,16 @@ def test_single_step_intermediates_16bit(precision):
         ok, m = _cmp(name, got, want, rel * scale)
         ok or fails.append(m)
 
-    yg = ctx.debug_fetch("yg", (2 * N, 64, W, W + 2))[..., :W]      # raw conv outputs keep the input pitch (W + 2)
-    yc = ctx.debug_fetch("yc", (2 * N, 32, W, W + 2))[..., :W]
+    def raw(name, n, C, H, Wd):
+        """raw conv outputs of the 16-bit engine: exact fp32, channel-blocked as a plane of top and a plane of bottom 16-bit
+        halves ([n][C/8][H * (Wd + 2)][8] each, input pitch Wd + 2; csrc/h16_common.h Raw16) -> planar [n, C, H, Wd]"""
+        P = H * (Wd + 2)
+        halves = ctx.debug_fetch(name)[:n * C * P].view(np.uint16).reshape(2, n, C // 8, P, 8).astype(np.uint32)
+        val = ((halves[0] << 16) | halves[1]).view(np.float32)                     # [n, C/8, P, 8]
+        return val.transpose(0, 1, 3, 2).reshape(n, C, H, Wd + 2)[..., :Wd]
+
+    yg = raw("yg", 2 * N, 64, W, W)
+    yc = raw("yc", 2 * N, 32, W, W)
     u = ctx.debug_fetch("u", (2 * N, 32, W, W))
     for d, name in enumerate(("fw", "bw")):
         chk("yg_" + name, yg[d * N:(d + 1) * N], tr["yg_" + name])
@@ -80,7 +88,7 @@ def test_single_step_intermediates_16bit(precision):
     for buf, name, C, H in [("y_med", "conv_median", 64, W), ("y_cat", "conv_concat", 64, W), ("y_c1", "conv1", 128, c1),
                             ("y_c2", "conv2", 256, c2), ("y_u2", "up2", 128, u2), ("y_u2o", "up2_out", 128, u2),
                             ("y_u3", "up3", 64, u3), ("y_out", "out", 64, o)]:
-        chk(buf, ctx.debug_fetch(buf, (N, C, H, H + 2))[..., :H], tr["raw_" + name])
+        chk(buf, raw(buf, N, C, H, H), tr["raw_" + name])
     ok, m = _cmp("prob", out, ref[..., 0], 2.5e-4 if precision == "bf16" else 1e-4); ok or fails.append(m)
     assert not fails, "\n".join(fails)
 
