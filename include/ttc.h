@@ -387,6 +387,9 @@ ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t 
  * ttc_debug_timing(ctx, level): 0 = off, 1 = every kernel family, 2 = conv-engine launches only
  * (cheap enough to leave on inside a timed benchmark region). */
 ttc_status ttc_debug_timing(ttc_ctx* ctx, int32_t enable);
+/* process-wide probe knobs of the 16-bit conv engine (tools/probes/h16_knobs.py): which 0 = persistent grid size (-1 default = 2 per
+ * CU, 0 = one workgroup per tile), 1 = start offset of the odd wave slot in s_sleep(127) units (-1 default).  Test / probe aid. */
+ttc_status ttc_debug_knob(int32_t which, int32_t value);
 ttc_status ttc_debug_kernel_ms(ttc_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 
 #ifdef __cplusplus

@@ -24,7 +24,7 @@ EXPORTS = [
     "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
-    "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error",
+    "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error", "ttc_debug_knob",
 ]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
@@ -121,6 +121,7 @@ def load():
     lib.ttc_count_equal.argtypes = [P, VP, I32, I32, C.c_float, I32P, VP]
     lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.ttc_debug_timing.argtypes = [P, I32]
+    lib.ttc_debug_knob.argtypes = [I32, I32]
     lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == missing export

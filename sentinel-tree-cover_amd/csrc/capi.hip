@@ -352,6 +352,9 @@ ttc_status ttc_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, void* st
 }
 #undef TTC_S
 
+void h16_set_knob(int which, int value);
+ttc_status ttc_debug_knob(int32_t which, int32_t value) { h16_set_knob(which, value); return TTC_OK; }
+
 ttc_status ttc_debug_clouds_stage(ttc_ctx* c, int32_t stage) {
     if (!c) return TTC_ERR_ARG;
     c->clouds_debug_stage = stage;

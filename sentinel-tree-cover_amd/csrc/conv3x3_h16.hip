@@ -230,7 +230,7 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
 }
 
 template <int BF, int TERMS, int NCG, int EPI, int OUT>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb, int ntiles) {
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb, int ntiles, int desync) {
     using E = Elem<BF>;
     using v8 = typename E::v8;
     constexpr int BN = NCG * 32;
@@ -263,6 +263,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     const int per = ntiles >> 3, rem = ntiles & 7;
     const int tcnt = per + (xcd < rem ? 1 : 0), tstart = xcd * per + (xcd < rem ? xcd : rem);
     if (wslot >= tcnt) return;
+    // The two workgroups that share a CU start together and their tiles take the same time: left alone they stay in LOCK STEP for
+    // the whole walk -- both inside the chunk loop (sharing the matrix pipe), then both outside it (pipe idle).  Persistent
+    // workgroups keep whatever phase offset they start with, so the one in the odd wave slot starts `desync` x 8128 cycles late:
+    // its chunk loop then runs under the other's epilogue / barriers / copy issue and vice versa.
+    if (desync > 0 && wslot + nx < tcnt && (__builtin_amdgcn_s_getreg((4 << 11) | 4) & 1u))       // HW_REG_HW_ID[3:0] = wave slot
+        for (int i = 0; i < desync; ++i) __builtin_amdgcn_s_sleep(127);
     const int C8_0 = args()->seg[0].C8;
     const int nchunk = args()->nchunk;
 
@@ -518,6 +524,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
     }
 }
 
+// probe knobs (ttc_debug_knob): [0] persistent grid size (-1 = 2 x CUs, 0 = one workgroup per tile), [1] start offset of the odd
+// wave slot in units of s_sleep(127) (-1 = default)
+int g_h16_knob[4] = {-1, -1, -1, -1};
+constexpr int kDesyncDefault = 0;
+
 template <int BF, int TERMS, int NCG, int EPI, int OUT>
 hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t s) {
     constexpr int BN = NCG * 32;
@@ -537,12 +548,16 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return 2 * cus;
     }();
-    const int grid = resident > 0 ? std::min(ntiles, resident) : ntiles;
-    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles);
+    const int res = g_h16_knob[0] >= 0 ? g_h16_knob[0] : resident;
+    const int grid = res > 0 ? std::min(ntiles, res) : ntiles;
+    const int desync = g_h16_knob[1] >= 0 ? g_h16_knob[1] : kDesyncDefault;
+    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles, desync);
     return hipGetLastError();
 }
 
 }  // namespace
+
+void h16_set_knob(int which, int value) { if (which >= 0 && which < 4) g_h16_knob[which] = value; }
 
 // ---- host: 16-bit conversions (round to nearest even), weight packing, dispatch -----------------------------------
 uint16_t h16_from_float(float f, bool bf) {
