@@ -47,6 +47,8 @@ ttc_status prep_count_positive(ttc_ctx* c, const float* d_a, int T, int npix, fl
 ttc_status prep_clip01(ttc_ctx* c, float* d_a, int64_t n, hipStream_t s);
 ttc_status prep_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, hipStream_t s);
 
+void h16_set_knob(int which, int value);      // conv3x3_h16.hip
+
 static void flush_timing(ttc_ctx* c) {
     for (auto& p : c->timing.pending) {
         float ms = 0.f;
@@ -352,7 +354,6 @@ ttc_status ttc_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, void* st
 }
 #undef TTC_S
 
-void h16_set_knob(int which, int value);
 ttc_status ttc_debug_knob(int32_t which, int32_t value) { h16_set_knob(which, value); return TTC_OK; }
 
 ttc_status ttc_debug_clouds_stage(ttc_ctx* c, int32_t stage) {
