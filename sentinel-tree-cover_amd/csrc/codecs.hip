@@ -32,20 +32,80 @@ __global__ void k_f32_to_i16(const float* __restrict__ in, long n, float precisi
     out[i] = (short)x;
 }
 
-// every problem = one image t (both polarisations pooled, as the reference's boolean-mask indexing does)
-struct SrcS1 {
-    const float* s1; int per_image;
-    __device__ int count() const { return per_image; }
-    __device__ bool get(int q, int p, float& v) const { v = s1[(long)(q >> 1) * per_image + p]; return true; }
-};
-
-__global__ void k_s1_finish(float* __restrict__ s1, const SelState* __restrict__ st, int per_image) {
+// Sentinel-1 preparation (job.py:699-708): the per-image median (both polarisations pooled, as the reference's boolean-mask
+// indexing does) replaces saturated samples, then convert_to_db.  The median is selected on the STORED uint16 values --
+// x = u / 65535 is monotone in u, so the order statistics of x are x(order statistics of u) -- with two 8-bit radix passes over
+// 2 bytes per sample; both middle order statistics come out of the same two histograms.  (Round 2 decoded to float32 first
+// and ran the generic 4-pass float select twice per image: 8 passes over 4-byte samples + a read-modify-write finish.)
+struct S1Sel { unsigned prefix[2]; long long k[2]; };     // [lower, upper] middle order statistic of one image
+// LDS histogram update aggregated per wave: backscatter values cluster, so most lanes of a wave hit the same few bins and plain
+// LDS atomics would serialise; one atomic per DISTINCT bin of the wave instead (few iterations exactly when contention is high)
+__device__ __forceinline__ void wave_hist_add(unsigned* h, unsigned bin, bool pred) {
+    unsigned long long todo = __ballot(pred);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(pred && bin == b0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[b0], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+}
+__global__ void k_s1_hist(const uint16_t* __restrict__ u16, int per_image, const S1Sel* __restrict__ sel, int pass,
+                          unsigned* __restrict__ hist /*[T][2][256]*/) {
+    __shared__ unsigned h[2][256];
+    const int t = blockIdx.y;
+    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const uint16_t* src = u16 + (long)t * per_image;
+    const unsigned p0 = pass ? sel[t].prefix[0] : 0u, p1 = pass ? sel[t].prefix[1] : 0u;
+    for (int base = blockIdx.x * blockDim.x; base < per_image; base += gridDim.x * blockDim.x) {       // whole waves stay in the loop
+        const int p = base + threadIdx.x;
+        const bool live = p < per_image;
+        const unsigned u = live ? src[p] : 0u;
+        if (!pass) wave_hist_add(h[0], u >> 8, live);                  // pass 0: one histogram serves both ranks
+        else {
+            wave_hist_add(h[0], u & 255u, live && (u >> 8) == p0);
+            wave_hist_add(h[1], u & 255u, live && (u >> 8) == p1);
+        }
+    }
+    __syncthreads();
+    if (h[0][threadIdx.x]) atomicAdd(&hist[(t * 2 + 0) * 256 + threadIdx.x], h[0][threadIdx.x]);
+    if (pass && h[1][threadIdx.x]) atomicAdd(&hist[(t * 2 + 1) * 256 + threadIdx.x], h[1][threadIdx.x]);
+}
+// one wave per (image, rank): walk the 256 bins to the one holding the rank; clears the histogram for the next pass
+__global__ void k_s1_pick(S1Sel* __restrict__ sel, int per_image, int pass, unsigned* __restrict__ hist) {
+    const int t = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
+    const unsigned* h = hist + (t * 2 + (pass ? which : 0)) * 256;
+    unsigned c[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c[j] = h[4 * lane + j]; mine += c[j]; }
+    unsigned incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const long long excl = (long long)incl - mine;
+    const long long k = pass ? sel[t].k[which] : (which ? (long long)per_image / 2 : ((long long)per_image - 1) / 2);
+    const bool here = k >= excl && k < (long long)incl;
+    const unsigned long long m = __ballot(here);
+    const int owner = m ? __ffsll((long long)m) - 1 : 63;
+    if (lane == owner) {
+        long long r = k - excl;
+        int b = 0;
+        for (; b < 3; ++b) { if (r < (long long)c[b]) break; r -= c[b]; }
+        const unsigned digit = (unsigned)(4 * lane + b);
+        sel[t].prefix[which] = pass ? ((sel[t].prefix[which] << 8) | digit) : digit;
+        sel[t].k[which] = m ? r : 0;
+    }
+}
+__global__ void k_s1_clear(unsigned* __restrict__ hist, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hist[i] = 0;
+}
+__global__ void k_s1_finish(const uint16_t* __restrict__ u16, const S1Sel* __restrict__ sel, int per_image, float* __restrict__ s1) {
 #pragma clang fp contract(off)
     const int t = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= per_image) return;
-    const float med = (fkey_inv(st[2 * t].prefix) + fkey_inv(st[2 * t + 1].prefix)) * 0.5f;
-    float x = s1[(long)t * per_image + p];
+    const float med = ((float)sel[t].prefix[0] / 65535.0f + (float)sel[t].prefix[1] / 65535.0f) * 0.5f;   // np.median of the float32 image
+    float x = (float)u16[(long)t * per_image + p] / 65535.0f;   // to_float32, tof_downloading.py:64-72
     if (x == 1.0f) x = med;                                  // job.py:703
     x = 10.0f * log10f(x + (float)(1.0 / 65535.0));          // convert_to_db, job.py:86-89 (min_db = 22)
     if (x < -22.0f) x = -22.0f;
@@ -84,15 +144,15 @@ ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y
     const int per = X * Y * 2;
     char* ctl = static_cast<char*>(c->scratch_buf("s1_ctl", 4096 + 128 * 256 * 4));
     if (!ctl) return c->fail(TTC_ERR_NOMEM, "s1 scratch");
-    SelState* st = reinterpret_cast<SelState*>(ctl);
-    unsigned* hist = reinterpret_cast<unsigned*>(ctl + 4096);
-    int* nptr = reinterpret_cast<int*>(ctl + 3072);
-    TTC_CHECK(codec_u16_to_f32(c, d_u16, (int64_t)T * per, d_out, s));
-    TTC_HIP(c, hipMemsetAsync(hist, 0, 128 * 256 * 4, s));
-    TTC_HIP(c, hipMemsetAsync(nptr, 0, sizeof(int), s));      // n = per - 0 (ranks are formed on the device)
-    hipLaunchKernelGGL(k_sel_init, dim3((2 * T + 63) / 64), dim3(64), 0, s, st, 2 * T, nptr, per, 1, 0, PctList{});
-    TTC_HIP(c, radix_select(SrcS1{d_out, per}, st, hist, 2 * T, s));
-    hipLaunchKernelGGL(k_s1_finish, dim3((per + 255) / 256, T), dim3(256), 0, s, d_out, st, per);
+    S1Sel* sel = reinterpret_cast<S1Sel*>(ctl);                 // 64 x 24 B
+    unsigned* hist = reinterpret_cast<unsigned*>(ctl + 4096);   // [T][2][256]
+    const int nh = T * 2 * 256;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_s1_clear, dim3((nh + 255) / 256), dim3(256), 0, s, hist, nh);
+        hipLaunchKernelGGL(k_s1_hist, dim3(48, T), dim3(256), 0, s, d_u16, per, sel, pass, hist);
+        hipLaunchKernelGGL(k_s1_pick, dim3(T, 2), dim3(64), 0, s, sel, per, pass, hist);
+    }
+    hipLaunchKernelGGL(k_s1_finish, dim3((per + 255) / 256, T), dim3(256), 0, s, d_u16, sel, per, d_out);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }

@@ -536,7 +536,7 @@ __global__ void k_gram_reduce(const double* __restrict__ partial, int nblk, doub
 // tile = tile * (1 - w) + pred * w
 struct Beta { double b[10][11]; int fitted; };
 __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restrict__ w, const float* __restrict__ mosaic,
-                                const float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date,
+                                float* __restrict__ snow, const Beta* __restrict__ bep, int npix, int date,
                                 float* __restrict__ snowp, int T = 0, int clip01 = 0) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -545,13 +545,9 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
     if (!(wd > 0.f)) return;                                   // tile * 1 + 0 * 0: unchanged
     float* tv = tiles + ((long)date * npix + p) * 10;
     const float* mv = mosaic + (long)p * 10;
-    float snf;
-    if (snow) snf = snow[p];
-    else {                                                       // mean of the cached per-date probabilities (CR.py:372)
-        snf = 0.f;
-        for (int t = 0; t < T; ++t) snf += snowp[(long)t * npix + p];
-        snf = snf / (float)T;
-    }
+    // the mean snow probability as it stands before this date is blended (CR.py:372): `snow` holds it in both forms of the date
+    // loop -- the batched form (T > 0) keeps it current below, the replayed-sampler form refreshes it with k_snow_mean_cached
+    const float snf = snow[p];
     const double sn = (double)snf;
     const Beta& be = *bep;
     float bl[10];
@@ -567,6 +563,11 @@ __global__ void k_predict_blend(float* __restrict__ tiles, const float* __restri
         bl[c] = tv[c] * (1.0f - wd) + pred * wd;
     }
     snowp[(long)date * npix + p] = snow_prob_px(bl);           // keep the cache of this date current (unclipped values)
+    if (T > 0) {                                                // ... and the mean: same float sum in date order as k_snow_mean_cached
+        float sm = 0.f;
+        for (int t = 0; t < T; ++t) sm += snowp[(long)t * npix + p];
+        snow[p] = sm / (float)T;
+    }
     // clip01 (single-call tile path): process_tile's final np.clip(sentinel2, 0, 1) (job.py:993) applied at the only place a
     // value can leave [0, 1] -- decoded uint16 / 65535 and their bilinear means cannot, an NNLS prediction can.  Nothing in
     // the rest of the gap-fill reads a blended pixel (training rows have w == 0), so clipping here equals clipping at the end.
@@ -804,52 +805,43 @@ __global__ void k_gram_reduce_all(const double* __restrict__ partial, int nblk, 
         out[i] = t;
     }
 }
-// snow products of ONE date over its rows: sv[i] = sum_rows w * z_i * snow (z_10 = z_21 = snow), snow = the mean of the
-// cached per-date probabilities as they stand now (same float sum, same order as k_snow_mean_cached)
-constexpr int kSnowBlocks = 512;
+// snow products of ONE date over its rows: sv[i] = sum_rows w * z_i * snow (z_10 = z_21 = snow), snow = the CURRENT mean of
+// the per-date probabilities (`snowm`, kept exact by k_predict_blend: the same float sum in date order as k_snow_mean_cached).
+// Lane = COLUMN: the 32 lanes of a half-wave own the 32 columns of Z and walk the row list together, two rows per wave and
+// step -- a lane loads ONE float per row (its own x / y element; row index, weight and snow mean are half-wave broadcasts)
+// and accumulates its column in double, so there is no cross-lane reduction per row.  (Round 2: a thread per row with 32
+// double accumulators and a 32 x 6-step shuffle tree for 2-3 rows each -- 65 us per date, 0.78 ms of a tile's 5.2 ms.)
+constexpr int kSnowBlocks = 1024;
 __global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ tiles, const float* __restrict__ mosaic,
-                                                    const float* __restrict__ snowp, const int* __restrict__ rows,
-                                                    const float* __restrict__ weight, const DatePlan* __restrict__ plan, int T,
+                                                    const float* __restrict__ snowm, const int* __restrict__ rows,
+                                                    const float* __restrict__ weight, const DatePlan* __restrict__ plan,
                                                     int npix, double* __restrict__ partial /*[kSnowBlocks][32]*/,
                                                     double* __restrict__ sv_out /*[32]*/, unsigned* __restrict__ ticket) {
 #pragma clang fp contract(off)
     __shared__ double red[8][32];
     __shared__ unsigned last;
     const int nsample = plan->nrows, t0 = plan->t0;
-    double acc[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = 0.0;
-    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < nsample; s += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
+    // column -> source: 0..9 clip(x_c), 10 snow, 11..20 x_c, 21 snow, 22..31 y_c
+    const bool is_y = col >= 22, is_sn = col == 10 || col == 21, do_clip = col < 10;
+    const int ch = is_y ? col - 22 : (col >= 11 ? col - 11 : col);
+    const int stream = (blockIdx.x * 4 + wv) * 2 + half, nstream = gridDim.x * 8;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int s = stream; s < nsample; s += nstream) {
         const int rr = rows[s];
         const int t = t0 + rr / npix, p = rr % npix;
-        float sn = 0.f;
-        for (int k = 0; k < T; ++k) sn += snowp[(long)k * npix + p];
-        sn = sn / (float)T;
-        const float* x = mosaic + (long)p * 10;
-        const float* y = tiles + ((long)t * npix + p) * 10;
-        const double ws = (double)weight[s] * (double)sn;
-#pragma unroll
-        for (int c = 0; c < 10; ++c) {
-            const float xv = x[c];
-            acc[c] += (double)fminf(fmaxf(xv, 0.005f), 1.0f) * ws;
-            acc[11 + c] += (double)xv * ws;
-            acc[22 + c] += (double)y[c] * ws;
-        }
-        acc[10] += (double)sn * ws;
+        const float sn = snowm[p];
+        const float w = weight[s];
+        float z = is_y ? tiles[((long)t * npix + p) * 10 + ch] : mosaic[(long)p * 10 + (is_sn ? 0 : ch)];
+        if (do_clip) z = fminf(fmaxf(z, 0.005f), 1.0f);
+        if (is_sn) z = sn;
+        acc += (double)z * ((double)w * (double)sn);
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        double v = acc[c];
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wv][c] = v;
-    }
+    acc += __shfl_xor(acc, 32);
+    if (lane < 32) red[wv][lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 32) {
-        const int c = threadIdx.x;
-        partial[blockIdx.x * 32 + c] = c == 21 ? ((red[0][10] + red[1][10]) + red[2][10]) + red[3][10]
-                                               : ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-    }
+    if (threadIdx.x < 32) partial[blockIdx.x * 32 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     // the workgroup that finishes last sums the partials in a fixed order (bit-reproducible) and re-arms the ticket
     __threadfence();
     __syncthreads();
@@ -1457,15 +1449,16 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
         hipLaunchKernelGGL(k_strata_thresholds_all, dim3(1), dim3(64), 0, s, st_all, plans, T, pl6, sd_all);
         hipLaunchKernelGGL(k_strata_count_all, dim3(64, T), b256, 0, s, evi_all, plans, npix, sd_all);
         hipLaunchKernelGGL(k_row_weights_all, dim3(128, T), b256, 0, s, evi_all, plans, npix, sd_all, weight_all);
+        hipLaunchKernelGGL(k_snow_mean_cached, grid, b256, 0, s, snowp, T, npix, snow);       // CR.py:372; k_predict_blend keeps it current
         hipLaunchKernelGGL(k_gram_all, dim3(kGramBlocks, T), b256, 0, s, d_tiles, mosaic, rows_all, weight_all, plans, npix, gpart_all);
         hipLaunchKernelGGL(k_gram_reduce_all, dim3(64, T), b256, 0, s, gpart_all, kGramBlocks, Z0);
         TTC_HIP(c, hipGetLastError());
         for (int date = 0; date < T; ++date) {
             DatePlan* plan = plans + date;
-            hipLaunchKernelGGL(k_gram_snow, dim3(kSnowBlocks), b256, 0, s, d_tiles, mosaic, snowp, rows_all + (size_t)date * 3 * npix,
-                               weight_all + (size_t)date * 3 * npix, plan, T, npix, spart, spart + 32 * kSnowBlocks, ticket);
+            hipLaunchKernelGGL(k_gram_snow, dim3(kSnowBlocks), b256, 0, s, d_tiles, mosaic, snow, rows_all + (size_t)date * 3 * npix,
+                               weight_all + (size_t)date * 3 * npix, plan, npix, spart, spart + 32 * kSnowBlocks, ticket);
             hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Z0 + 1024L * date, plan, d_beta, spart + 32 * kSnowBlocks, 1);
-            hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, (const float*)nullptr, d_beta, npix, date, snowp, T,
+            hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, d_beta, npix, date, snowp, T,
                                spec ? 1 : 0);
         }
         TTC_HIP(c, hipGetLastError());
