@@ -38,18 +38,6 @@ __global__ void k_f32_to_i16(const float* __restrict__ in, long n, float precisi
 // 2 bytes per sample; both middle order statistics come out of the same two histograms.  (Round 2 decoded to float32 first
 // and ran the generic 4-pass float select twice per image: 8 passes over 4-byte samples + a read-modify-write finish.)
 struct S1Sel { unsigned prefix[2]; long long k[2]; };     // [lower, upper] middle order statistic of one image
-// LDS histogram update aggregated per wave: backscatter values cluster, so most lanes of a wave hit the same few bins and plain
-// LDS atomics would serialise; one atomic per DISTINCT bin of the wave instead (few iterations exactly when contention is high)
-__device__ __forceinline__ void wave_hist_add(unsigned* h, unsigned bin, bool pred) {
-    unsigned long long todo = __ballot(pred);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const unsigned b0 = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-        const unsigned long long same = __ballot(pred && bin == b0);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&h[b0], (unsigned)__popcll(same));
-        todo &= ~same;
-    }
-}
 __global__ void k_s1_hist(const uint16_t* __restrict__ u16, int per_image, const S1Sel* __restrict__ sel, int pass,
                           unsigned* __restrict__ hist /*[T][2][256]*/) {
     __shared__ unsigned h[2][256];
@@ -58,14 +46,12 @@ __global__ void k_s1_hist(const uint16_t* __restrict__ u16, int per_image, const
     __syncthreads();
     const uint16_t* src = u16 + (long)t * per_image;
     const unsigned p0 = pass ? sel[t].prefix[0] : 0u, p1 = pass ? sel[t].prefix[1] : 0u;
-    for (int base = blockIdx.x * blockDim.x; base < per_image; base += gridDim.x * blockDim.x) {       // whole waves stay in the loop
-        const int p = base + threadIdx.x;
-        const bool live = p < per_image;
-        const unsigned u = live ? src[p] : 0u;
-        if (!pass) wave_hist_add(h[0], u >> 8, live);                  // pass 0: one histogram serves both ranks
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < per_image; p += gridDim.x * blockDim.x) {
+        const unsigned u = src[p];
+        if (!pass) atomicAdd(&h[0][u >> 8], 1u);                       // pass 0: one histogram serves both ranks
         else {
-            wave_hist_add(h[0], u & 255u, live && (u >> 8) == p0);
-            wave_hist_add(h[1], u & 255u, live && (u >> 8) == p1);
+            if ((u >> 8) == p0) atomicAdd(&h[0][u & 255u], 1u);
+            if ((u >> 8) == p1) atomicAdd(&h[1][u & 255u], 1u);
         }
     }
     __syncthreads();
@@ -149,7 +135,7 @@ ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y
     const int nh = T * 2 * 256;
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(k_s1_clear, dim3((nh + 255) / 256), dim3(256), 0, s, hist, nh);
-        hipLaunchKernelGGL(k_s1_hist, dim3(48, T), dim3(256), 0, s, d_u16, per, sel, pass, hist);
+        hipLaunchKernelGGL(k_s1_hist, dim3(96, T), dim3(256), 0, s, d_u16, per, sel, pass, hist);
         hipLaunchKernelGGL(k_s1_pick, dim3(T, 2), dim3(64), 0, s, sel, per, pass, hist);
     }
     hipLaunchKernelGGL(k_s1_finish, dim3((per + 255) / 256, T), dim3(256), 0, s, d_u16, sel, per, d_out);

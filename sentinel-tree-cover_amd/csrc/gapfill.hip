@@ -827,16 +827,25 @@ __global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ til
     const int ch = is_y ? col - 22 : (col >= 11 ? col - 11 : col);
     const int stream = (blockIdx.x * 4 + wv) * 2 + half, nstream = gridDim.x * 8;
     double acc = 0.0;
-#pragma unroll 4
-    for (int s = stream; s < nsample; s += nstream) {
-        const int rr = rows[s];
-        const int t = t0 + rr / npix, p = rr % npix;
-        const float sn = snowm[p];
-        const float w = weight[s];
-        float z = is_y ? tiles[((long)t * npix + p) * 10 + ch] : mosaic[(long)p * 10 + (is_sn ? 0 : ch)];
-        if (do_clip) z = fminf(fmaxf(z, 0.005f), 1.0f);
-        if (is_sn) z = sn;
-        acc += (double)z * ((double)w * (double)sn);
+    // a half-wave takes 32 CONSECUTIVE rows per step: row indices and weights arrive as one coalesced load each and are handed
+    // round by shuffles, so the per-row loads (snow mean, this lane's element) of all 32 rows are independent and in flight together
+    for (int base = stream * 32; base < nsample; base += nstream * 32) {
+        const int mine = base + col;
+        const int rr_l = mine < nsample ? rows[mine] : 0;
+        const float w_l = mine < nsample ? weight[mine] : 0.f;
+        const int cnt = min(32, nsample - base);
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int rr = __shfl(rr_l, i, 32);
+            const float w = __shfl(w_l, i, 32);
+            const int dt = (rr >= npix) + (rr >= 2 * npix);          // a fit trains on at most 3 dates (CR.py:394-402)
+            const int p = rr - dt * npix;
+            const float sn = snowm[p];
+            float z = is_y ? tiles[((long)(t0 + dt) * npix + p) * 10 + ch] : mosaic[(long)p * 10 + (is_sn ? 0 : ch)];
+            if (do_clip) z = fminf(fmaxf(z, 0.005f), 1.0f);
+            if (is_sn) z = sn;
+            if (i < cnt) acc += (double)z * ((double)w * (double)sn);
+        }
     }
     acc += __shfl_xor(acc, 32);
     if (lane < 32) red[wv][lane] = acc;
