@@ -811,7 +811,7 @@ __global__ void k_gram_reduce_all(const double* __restrict__ partial, int nblk, 
 // step -- a lane loads ONE float per row (its own x / y element; row index, weight and snow mean are half-wave broadcasts)
 // and accumulates its column in double, so there is no cross-lane reduction per row.  (Round 2: a thread per row with 32
 // double accumulators and a 32 x 6-step shuffle tree for 2-3 rows each -- 65 us per date, 0.78 ms of a tile's 5.2 ms.)
-constexpr int kSnowBlocks = 1024;
+constexpr int kSnowBlocks = 512;
 __global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ tiles, const float* __restrict__ mosaic,
                                                     const float* __restrict__ snowm, const int* __restrict__ rows,
                                                     const float* __restrict__ weight, const DatePlan* __restrict__ plan,
@@ -858,11 +858,19 @@ __global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ til
     __syncthreads();
     if (!last) return;
     __threadfence();
-    {
+    {   // 8 threads per column, each with FOUR independent partial sums and the loop unrolled: 16 loads in flight per thread (a
+        // single running sum made this tail a chain of serialised memory round trips -- most of the kernel's 65 us in round 2)
         const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
-        double t = 0.0;
-        for (int b = part; b < (int)gridDim.x; b += 8) t += __builtin_nontemporal_load(&partial[b * 32 + c]);
-        red[part][c] = t;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        const int G = (int)gridDim.x;
+#pragma unroll 4
+        for (int b = part; b < G; b += 32) {
+            t0 += __builtin_nontemporal_load(&partial[b * 32 + c]);
+            if (b + 8 < G) t1 += __builtin_nontemporal_load(&partial[(b + 8) * 32 + c]);
+            if (b + 16 < G) t2 += __builtin_nontemporal_load(&partial[(b + 16) * 32 + c]);
+            if (b + 24 < G) t3 += __builtin_nontemporal_load(&partial[(b + 24) * 32 + c]);
+        }
+        red[part][c] = (t0 + t1) + (t2 + t3);
     }
     __syncthreads();
     if (threadIdx.x < 32) {
