@@ -29,8 +29,13 @@ constexpr int kMaxT = 32;
 __device__ __forceinline__ int reflect_edge(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }  // scipy 'reflect'
 
 // ------------------------------------------------------------------------------------------------ a6
-// pass 1: along Y (contiguous): squared distance to the nearest masked pixel in the row, capped (13^2)
-__global__ void k_edt_rows(const float* __restrict__ mask, int X, int Y, int clip, unsigned short* __restrict__ g2) {
+// The feather weight is b = f(d2) with d2 the squared distance to the nearest masked pixel capped at 169 and
+//     f(d2) = 1 - min(sqrt(d2), 12) / 12, values below 0.2 -> 0                                  (CR.py:915-918, float64 like scipy),
+// a NON-INCREASING function of the integer d2.  A flat max filter therefore commutes with f as a min filter on d2 (and min
+// as max), ties included, so the whole chain -- exact EDT, grey dilation, grey erosion -- runs on ONE BYTE per pixel and f is
+// applied once when the weight is stored: bit-identical to filtering float64 planes (round 2: 8 bytes per pixel and pass).
+// pass 1: along Y (contiguous): distance to the nearest masked pixel in the row, 13 = none within 12
+__global__ void k_edt_rows(const float* __restrict__ mask, int X, int Y, int clip, unsigned char* __restrict__ g) {
     const int t = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= X * Y) return;
@@ -43,52 +48,54 @@ __global__ void k_edt_rows(const float* __restrict__ mask, int X, int Y, int cli
         if (y + d < Y) { float v = row[y + d]; if (clip) v = fminf(fmaxf(v, 0.f), 1.f); hit |= (1.0f - v) == 0.0f; }
         if (hit) { best = d; break; }
     }
-    g2[(long)t * X * Y + p] = (unsigned short)(best * best);
+    g[(long)t * X * Y + p] = (unsigned char)best;
 }
-// pass 2: along X: d2 = min_dx g2(x+dx)^2 + dx^2; b = 1 - min(sqrt(d2), 12)/12, < 0.2 -> 0 (float64 like scipy)
-__global__ void k_edt_cols(const unsigned short* __restrict__ g2, int X, int Y, double* __restrict__ b) {
+// pass 2: along X: d2 = min_dx g(x+dx)^2 + dx^2, capped at 169 (= "further than 12")
+__global__ void k_edt_cols(const unsigned char* __restrict__ g, int X, int Y, unsigned char* __restrict__ d2) {
     const int t = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= X * Y) return;
     const int x = p / Y, y = p % Y;
-    const unsigned short* pl = g2 + (long)t * X * Y;
+    const unsigned char* pl = g + (long)t * X * Y;
     int best = 169;
     for (int dx = -12; dx <= 12; ++dx) {
         const int xx = x + dx;
         if (xx < 0 || xx >= X) continue;
-        const int v = (int)pl[xx * Y + y] + dx * dx;
+        const int gv = pl[xx * Y + y];
+        const int v = gv * gv + dx * dx;
         best = v < best ? v : best;
     }
-    double d = sqrt((double)best);
-    if (d > 12.0) d = 12.0;
-    double v = 1.0 - d / 12.0;
-    if (v < 0.2) v = 0.0;
-    b[(long)t * X * Y + p] = v;
+    d2[(long)t * X * Y + p] = (unsigned char)best;
 }
-// separable flat max / min filter with window [lo, hi] and scipy 'reflect' borders
+// separable flat filter on the d2 planes with window [lo, hi] and scipy 'reflect' borders.  MAXF refers to the WEIGHT
+// (grey dilation of b = min of d2, grey erosion of b = max of d2)
 template <bool MAXF, bool ALONG_Y>
-__global__ void k_minmax(const double* __restrict__ in, int X, int Y, int lo, int hi, double* __restrict__ out) {
+__global__ void k_minmax(const unsigned char* __restrict__ in, int X, int Y, int lo, int hi, unsigned char* __restrict__ out) {
     const int t = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= X * Y) return;
     const int x = p / Y, y = p % Y;
-    const double* pl = in + (long)t * X * Y;
-    double acc = MAXF ? -1e300 : 1e300;
+    const unsigned char* pl = in + (long)t * X * Y;
+    int acc = MAXF ? 255 : 0;
     for (int k = lo; k <= hi; ++k) {
-        const double v = ALONG_Y ? pl[x * Y + reflect_edge(y + k, Y)] : pl[reflect_edge(x + k, X) * Y + y];
-        acc = MAXF ? fmax(acc, v) : fmin(acc, v);
+        const int v = ALONG_Y ? pl[x * Y + reflect_edge(y + k, Y)] : pl[reflect_edge(x + k, X) * Y + y];
+        acc = MAXF ? min(acc, v) : max(acc, v);
     }
-    out[(long)t * X * Y + p] = acc;
+    out[(long)t * X * Y + p] = (unsigned char)acc;
 }
 // dates whose mask is empty keep the (clipped) mask itself (CR.py:786 / :914 `if np.sum(...) > 0`)
-__global__ void k_feather_store(const double* __restrict__ closed, const float* __restrict__ mask, const int* __restrict__ nz,
+__global__ void k_feather_store(const unsigned char* __restrict__ closed, const float* __restrict__ mask, const int* __restrict__ nz,
                                 int npix, int clip, float* __restrict__ w) {
     const int t = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
     float m = mask[(long)t * npix + p];
     if (clip) m = fminf(fmaxf(m, 0.f), 1.f);
-    w[(long)t * npix + p] = nz[t] > 0 ? (float)closed[(long)t * npix + p] : m;
+    double d = sqrt((double)closed[(long)t * npix + p]);
+    if (d > 12.0) d = 12.0;
+    double v = 1.0 - d / 12.0;
+    if (v < 0.2) v = 0.0;
+    w[(long)t * npix + p] = nz[t] > 0 ? (float)v : m;
 }
 __global__ void k_mask_positive(const float* __restrict__ mask, int npix, int clip, int* __restrict__ nz) {
     const int t = blockIdx.y;
@@ -811,21 +818,19 @@ __global__ void k_gram_reduce_all(const double* __restrict__ partial, int nblk, 
 // step -- a lane loads ONE float per row (its own x / y element; row index, weight and snow mean are half-wave broadcasts)
 // and accumulates its column in double, so there is no cross-lane reduction per row.  (Round 2: a thread per row with 32
 // double accumulators and a 32 x 6-step shuffle tree for 2-3 rows each -- 65 us per date, 0.78 ms of a tile's 5.2 ms.)
-constexpr int kSnowBlocks = 512;
-__global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ tiles, const float* __restrict__ mosaic,
-                                                    const float* __restrict__ snowm, const int* __restrict__ rows,
-                                                    const float* __restrict__ weight, const DatePlan* __restrict__ plan,
-                                                    int npix, double* __restrict__ partial /*[kSnowBlocks][32]*/,
-                                                    double* __restrict__ sv_out /*[32]*/, unsigned* __restrict__ ticket) {
+constexpr int kSnowBlocks = 128;       // x 1024 threads; k_nnls sums the per-block partials in a fixed order (bit-reproducible)
+__global__ __launch_bounds__(1024) void k_gram_snow(const float* __restrict__ tiles, const float* __restrict__ mosaic,
+                                                     const float* __restrict__ snowm, const int* __restrict__ rows,
+                                                     const float* __restrict__ weight, const DatePlan* __restrict__ plan,
+                                                     int npix, double* __restrict__ partial /*[kSnowBlocks][32]*/) {
 #pragma clang fp contract(off)
-    __shared__ double red[8][32];
-    __shared__ unsigned last;
+    __shared__ double red[16][32];
     const int nsample = plan->nrows, t0 = plan->t0;
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, wv = threadIdx.x >> 6;
     // column -> source: 0..9 clip(x_c), 10 snow, 11..20 x_c, 21 snow, 22..31 y_c
     const bool is_y = col >= 22, is_sn = col == 10 || col == 21, do_clip = col < 10;
     const int ch = is_y ? col - 22 : (col >= 11 ? col - 11 : col);
-    const int stream = (blockIdx.x * 4 + wv) * 2 + half, nstream = gridDim.x * 8;
+    const int stream = (blockIdx.x * 16 + wv) * 2 + half, nstream = gridDim.x * 32;
     double acc = 0.0;
     // a half-wave takes 32 CONSECUTIVE rows per step: row indices and weights arrive as one coalesced load each and are handed
     // round by shuffles, so the per-row loads (snow mean, this lane's element) of all 32 rows are independent and in flight together
@@ -850,35 +855,13 @@ __global__ __launch_bounds__(256) void k_gram_snow(const float* __restrict__ til
     acc += __shfl_xor(acc, 32);
     if (lane < 32) red[wv][lane] = acc;
     __syncthreads();
-    if (threadIdx.x < 32) partial[blockIdx.x * 32 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    // the workgroup that finishes last sums the partials in a fixed order (bit-reproducible) and re-arms the ticket
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    {   // 8 threads per column, each with FOUR independent partial sums and the loop unrolled: 16 loads in flight per thread (a
-        // single running sum made this tail a chain of serialised memory round trips -- most of the kernel's 65 us in round 2)
-        const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        const int G = (int)gridDim.x;
-#pragma unroll 4
-        for (int b = part; b < G; b += 32) {
-            t0 += __builtin_nontemporal_load(&partial[b * 32 + c]);
-            if (b + 8 < G) t1 += __builtin_nontemporal_load(&partial[(b + 8) * 32 + c]);
-            if (b + 16 < G) t2 += __builtin_nontemporal_load(&partial[(b + 16) * 32 + c]);
-            if (b + 24 < G) t3 += __builtin_nontemporal_load(&partial[(b + 24) * 32 + c]);
-        }
-        red[part][c] = (t0 + t1) + (t2 + t3);
-    }
-    __syncthreads();
+    // (no grid-wide "last block" reduction here: its agent-scope release / acquire pair cost more than the products -- the
+    // kernel stayed at 47-78 us whatever the main loop did; the consumer sums kSnowBlocks partials instead)
     if (threadIdx.x < 32) {
         double t = 0.0;
-        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-        sv_out[threadIdx.x] = t;
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        partial[blockIdx.x * 32 + threadIdx.x] = t;
     }
-    if (threadIdx.x == 0) *ticket = 0u;
 }
 // Lawson-Hanson NNLS on the normal equations, ONE WAVE per band: lane r owns row r of the active system.  The
 // arithmetic per matrix element is the same as a serial active-set solver's (row operations of the Gauss-Jordan elimination
@@ -903,11 +886,19 @@ __global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan
         return;
     }
     if (snow_partial) {                                  // date-batched form: Z holds everything but the snow products
-        if (lane < 32) {
-            double t = 0.0;
-            for (int b = 0; b < snow_blocks; ++b) t += snow_partial[b * 32 + lane];       // fixed order: deterministic
-            sv[lane] = t;
+        // per-block partials of k_gram_snow, summed in a fixed order (deterministic): two lanes per column, four independent
+        // running sums each so that the loads overlap
+        const int c = lane & 31, part = lane >> 5;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (int b = part; b < snow_blocks; b += 8) {
+            t0 += snow_partial[b * 32 + c];
+            if (b + 2 < snow_blocks) t1 += snow_partial[(b + 2) * 32 + c];
+            if (b + 4 < snow_blocks) t2 += snow_partial[(b + 4) * 32 + c];
+            if (b + 6 < snow_blocks) t3 += snow_partial[(b + 6) * 32 + c];
         }
+        double t = (t0 + t1) + (t2 + t3);
+        t += __shfl_xor(t, 32);
+        if (lane < 32) sv[lane] = t;
         __syncthreads();
     }
     if (lane < n) {
@@ -1011,17 +1002,16 @@ ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y,
     if (!d_mask || !d_w || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "feather: bad argument (T in [1,32])");
     if (closing != 15 && closing != 20) return c->fail(TTC_ERR_ARG, "feather: closing must be 15 or 20");
     const long npix = (long)X * Y;
-    unsigned short* g2 = static_cast<unsigned short*>(c->scratch_buf("gf_g2", sizeof(unsigned short) * T * npix));
-    double* b0 = static_cast<double*>(c->scratch_buf("gf_b0", sizeof(double) * T * npix));
-    double* b1 = static_cast<double*>(c->scratch_buf("gf_b1", sizeof(double) * T * npix));
+    unsigned char* b0 = static_cast<unsigned char*>(c->scratch_buf("gf_g2", 2 * (size_t)T * npix));      // two byte planes per date
+    unsigned char* b1 = b0 ? b0 + (size_t)T * npix : nullptr;
     int* nz = static_cast<int*>(c->scratch_buf("gf_nz", sizeof(int) * kMaxT));
-    if (!g2 || !b0 || !b1 || !nz) return c->fail(TTC_ERR_NOMEM, "feather scratch");
+    if (!b0 || !nz) return c->fail(TTC_ERR_NOMEM, "feather scratch");
     KTimer kt(c, "feather", s);
     const dim3 grid((unsigned)((npix + 255) / 256), T), blk(256);
     TTC_HIP(c, hipMemsetAsync(nz, 0, sizeof(int) * kMaxT, s));
     hipLaunchKernelGGL(k_mask_positive, dim3(64, T), blk, 0, s, d_mask, (int)npix, clip, nz);
-    hipLaunchKernelGGL(k_edt_rows, grid, blk, 0, s, d_mask, X, Y, clip, g2);
-    hipLaunchKernelGGL(k_edt_cols, grid, blk, 0, s, g2, X, Y, b0);
+    hipLaunchKernelGGL(k_edt_rows, grid, blk, 0, s, d_mask, X, Y, clip, b1);
+    hipLaunchKernelGGL(k_edt_cols, grid, blk, 0, s, b1, X, Y, b0);
     // scipy grey_closing(size): dilation window [-(size/2 - 1), size/2] for even sizes, then erosion [-size/2, size/2 - 1]
     const int dlo = closing == 20 ? -9 : -7, dhi = closing == 20 ? 10 : 7, elo = closing == 20 ? -10 : -7, ehi = closing == 20 ? 9 : 7;
     hipLaunchKernelGGL((k_minmax<true, true>), grid, blk, 0, s, b0, X, Y, dlo, dhi, b1);
@@ -1455,7 +1445,6 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
         SelState* st_all = reinterpret_cast<SelState*>(ctl2);
         StrataDev* sd_all = reinterpret_cast<StrataDev*>(st_all + 12 * kMaxT);
         unsigned* hist_all = reinterpret_cast<unsigned*>(sd_all + kMaxT);
-        unsigned* ticket = hist_all + 12 * 256 * kMaxT;
         TTC_HIP(c, hipMemsetAsync(hist_all, 0, sizeof(unsigned) * (12 * 256 * kMaxT + 16), s));
         hipLaunchKernelGGL(k_rows_fill, dim3(nb3, T), b256, 0, s, d_interp, water2, d_tiles, npix, 0, 0, plans, blk, rows_all, evi_all);
         hipLaunchKernelGGL(k_sel_init_evi, dim3((T * 12 + 63) / 64), dim3(64), 0, s, st_all, plans, T, pl6);
@@ -1472,9 +1461,9 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
         TTC_HIP(c, hipGetLastError());
         for (int date = 0; date < T; ++date) {
             DatePlan* plan = plans + date;
-            hipLaunchKernelGGL(k_gram_snow, dim3(kSnowBlocks), b256, 0, s, d_tiles, mosaic, snow, rows_all + (size_t)date * 3 * npix,
-                               weight_all + (size_t)date * 3 * npix, plan, npix, spart, spart + 32 * kSnowBlocks, ticket);
-            hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Z0 + 1024L * date, plan, d_beta, spart + 32 * kSnowBlocks, 1);
+            hipLaunchKernelGGL(k_gram_snow, dim3(kSnowBlocks), dim3(1024), 0, s, d_tiles, mosaic, snow, rows_all + (size_t)date * 3 * npix,
+                               weight_all + (size_t)date * 3 * npix, plan, npix, spart);
+            hipLaunchKernelGGL(k_nnls, dim3(10), dim3(64), 0, s, Z0 + 1024L * date, plan, d_beta, spart, kSnowBlocks);
             hipLaunchKernelGGL(k_predict_blend, grid, b256, 0, s, d_tiles, d_interp, mosaic, snow, d_beta, npix, date, snowp, T,
                                spec ? 1 : 0);
         }
