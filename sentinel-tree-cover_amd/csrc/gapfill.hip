@@ -752,50 +752,72 @@ __global__ void k_row_weights_all(const float* __restrict__ evi_all, const DateP
         weight[i] = w;
     }
 }
-// Z'Z without the snow regressor for date blockIdx.y (columns 10 and 21 are left zero; k_gram_snow supplies them)
+// Z'Z without the snow regressor for date blockIdx.y (columns 10 and 21 are left zero; k_gram_snow supplies them), on the
+// fp64 matrix cores: G[i][j] += sum_k (w_k z_k[i]) * z_k[j] is a 32 x 32 x rows GEMM, four rows per v_mfma_f64_16x16x4_f64 and
+// three 16 x 16 blocks (G00, G01, G11; G10 = G01').  Same products in double as the LDS-tiled vector form it replaces
+// ((double)z_i * (double)w, times (double)z_j, FMA-accumulated), 3 matrix instructions per 4 rows instead of 1024 DFMA lanes
+// with two LDS operand reads each (round 2: 305 us per tile).  A lane (c = lane & 15, k = lane >> 4) supplies row k of the
+// step, columns c (block 0) and 16 + c (block 1): two gathered floats.  Row indices / weights of 64 consecutive rows arrive
+// as one coalesced load each per wave and are handed round with ds_bpermute.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_gram_all(const float* __restrict__ tiles, const float* __restrict__ mosaic,
                                                    const int* __restrict__ rows_all, const float* __restrict__ weight_all,
                                                    const DatePlan* __restrict__ plans, int npix, double* __restrict__ partial) {
-    constexpr int R = 256;
-    __shared__ float zs[R][33];
-    __shared__ float ws[R];
+#pragma clang fp contract(off)
+    __shared__ double red[4][3][16][16];
     const int d = blockIdx.y;
     const int nsample = plans[d].nrows, t0 = plans[d].t0;
     const int* rows = rows_all + (long)d * 3 * npix;
     const float* weight = weight_all + (long)d * 3 * npix;
-    double acc[4] = {0, 0, 0, 0};
-    const int tid = threadIdx.x;
-    const int r0 = tid >> 3, c0 = (tid & 7) * 4;
-    for (int base = blockIdx.x * R; base < nsample; base += gridDim.x * R) {
-        __syncthreads();
-        {
-            const int s = base + tid;
-            float wgt = 0.f;
-            if (s < nsample) {
-                const int rr = rows[s];
-                const int t = t0 + rr / npix, p = rr % npix;
-                const float* x = mosaic + (long)p * 10;
-                const float* y = tiles + ((long)t * npix + p) * 10;
-#pragma unroll
-                for (int c = 0; c < 10; ++c) { const float xv = x[c]; zs[tid][c] = fminf(fmaxf(xv, 0.005f), 1.0f); zs[tid][11 + c] = xv; zs[tid][22 + c] = y[c]; }
-                zs[tid][10] = 0.f; zs[tid][21] = 0.f;
-                wgt = weight[s];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 32; ++c) zs[tid][c] = 0.f;
-            }
-            ws[tid] = wgt;
-        }
-        __syncthreads();
-        const int n = min(R, nsample - base);
-        for (int s = 0; s < n; ++s) {
-            const double zr = (double)zs[s][r0] * (double)ws[s];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] += zr * (double)zs[s][c0 + k];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, k = lane >> 4;
+    // block 0 column c: 0..9 clip(x_c), 10 zero (snow), 11..15 x_{c-11};  block 1 column 16 + c: 16..20 x_{c+5}, 21 zero, 22..31 y_{c-6}
+    const bool a_zero = c == 10, a_clip = c < 10;
+    const int a_ch = c < 10 ? c : (c > 10 ? c - 11 : 0);
+    const bool b_zero = c == 5, b_y = c >= 6;
+    const int b_ch = c < 5 ? c + 5 : (c >= 6 ? c - 6 : 0);
+    f64x4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
+    const int chunk0 = blockIdx.x * 4 + wv, nchunks = gridDim.x * 4;
+    for (int base = chunk0 * 64; base < nsample; base += nchunks * 64) {
+        const int mine = base + lane;
+        const int rr_l = mine < nsample ? rows[mine] : 0;
+        const float w_l = mine < nsample ? weight[mine] : 0.f;          // rows past the end: weight 0 -> contribute nothing
+#pragma unroll 4
+        for (int st = 0; st < 16; ++st) {
+            const int src = 4 * st + k;
+            const int rr = __shfl(rr_l, src);
+            const float w = __shfl(w_l, src);
+            const int dt = (rr >= npix) + (rr >= 2 * npix);
+            const int p = rr - dt * npix;
+            const float* x = mosaic + (long)p * 10;
+            const float* y = tiles + ((long)(t0 + dt) * npix + p) * 10;
+            float za = x[a_ch];
+            if (a_clip) za = fminf(fmaxf(za, 0.005f), 1.0f);
+            if (a_zero) za = 0.f;
+            float zb = b_y ? y[b_ch] : x[b_ch];
+            if (b_zero) zb = 0.f;
+            const double wa = (double)za * (double)w, wb = (double)zb * (double)w;
+            g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, (double)za, g00, 0, 0, 0);
+            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, (double)zb, g01, 0, 0, 0);
+            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(wb, (double)zb, g11, 0, 0, 0);
         }
     }
+    // C / D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int k = 0; k < 4; ++k) partial[((long)d * gridDim.x + blockIdx.x) * 1024 + r0 * 32 + c0 + k] = acc[k];
+    for (int r = 0; r < 4; ++r) {
+        red[wv][0][k + 4 * r][c] = g00[r];
+        red[wv][1][k + 4 * r][c] = g01[r];
+        red[wv][2][k + 4 * r][c] = g11[r];
+    }
+    __syncthreads();
+    // the four waves' partials in a fixed order -> this block's 32 x 32 partial (symmetric fill)
+    double* out = partial + ((long)d * gridDim.x + blockIdx.x) * 1024;
+    for (int e = threadIdx.x; e < 768; e += 256) {
+        const int blk = e >> 8, i = (e >> 4) & 15, j2 = e & 15;
+        const double v = ((red[0][blk][i][j2] + red[1][blk][i][j2]) + red[2][blk][i][j2]) + red[3][blk][i][j2];
+        if (blk == 0) out[i * 32 + j2] = v;
+        else if (blk == 2) out[(16 + i) * 32 + 16 + j2] = v;
+        else { out[i * 32 + 16 + j2] = v; out[(16 + j2) * 32 + i] = v; }
+    }
 }
 __global__ void k_gram_reduce_all(const double* __restrict__ partial, int nblk, double* __restrict__ out) {
     __shared__ double red[16][17];
@@ -818,7 +840,7 @@ __global__ void k_gram_reduce_all(const double* __restrict__ partial, int nblk, 
 // step -- a lane loads ONE float per row (its own x / y element; row index, weight and snow mean are half-wave broadcasts)
 // and accumulates its column in double, so there is no cross-lane reduction per row.  (Round 2: a thread per row with 32
 // double accumulators and a 32 x 6-step shuffle tree for 2-3 rows each -- 65 us per date, 0.78 ms of a tile's 5.2 ms.)
-constexpr int kSnowBlocks = 128;       // x 1024 threads; k_nnls sums the per-block partials in a fixed order (bit-reproducible)
+constexpr int kSnowBlocks = 256;       // x 1024 threads; k_nnls sums the per-block partials in a fixed order (bit-reproducible)
 __global__ __launch_bounds__(1024) void k_gram_snow(const float* __restrict__ tiles, const float* __restrict__ mosaic,
                                                      const float* __restrict__ snowm, const int* __restrict__ rows,
                                                      const float* __restrict__ weight, const DatePlan* __restrict__ plan,
@@ -839,7 +861,7 @@ __global__ __launch_bounds__(1024) void k_gram_snow(const float* __restrict__ ti
         const int rr_l = mine < nsample ? rows[mine] : 0;
         const float w_l = mine < nsample ? weight[mine] : 0.f;
         const int cnt = min(32, nsample - base);
-#pragma unroll 8
+#pragma unroll 16
         for (int i = 0; i < 32; ++i) {
             const int rr = __shfl(rr_l, i, 32);
             const float w = __shfl(w_l, i, 32);
@@ -889,14 +911,14 @@ __global__ void k_nnls(const double* __restrict__ Z, DatePlan* __restrict__ plan
         // per-block partials of k_gram_snow, summed in a fixed order (deterministic): two lanes per column, four independent
         // running sums each so that the loads overlap
         const int c = lane & 31, part = lane >> 5;
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        for (int b = part; b < snow_blocks; b += 8) {
-            t0 += snow_partial[b * 32 + c];
-            if (b + 2 < snow_blocks) t1 += snow_partial[(b + 2) * 32 + c];
-            if (b + 4 < snow_blocks) t2 += snow_partial[(b + 4) * 32 + c];
-            if (b + 6 < snow_blocks) t3 += snow_partial[(b + 6) * 32 + c];
+        double t = 0.0;
+        for (int b0 = part; b0 < snow_blocks; b0 += 32) {            // 16 loads in flight, then a fixed-order sum
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (b0 + 2 * u < snow_blocks) ? snow_partial[(b0 + 2 * u) * 32 + c] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += v[u];
         }
-        double t = (t0 + t1) + (t2 + t3);
         t += __shfl_xor(t, 32);
         if (lane < 32) sv[lane] = t;
         __syncthreads();
