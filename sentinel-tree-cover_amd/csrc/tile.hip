@@ -155,25 +155,30 @@ __device__ __forceinline__ void smooth_store(const float (&v)[TM], const WMat& w
     }
 }
 
-// One wave per 64 pixels.  The [T, X, Y, 10] stack is pixel-major (40-byte records): a thread-per-pixel load touches 20
-// cache lines per instruction for 512 useful bytes, and the kernel sat at 0.76 TB/s.  The wave therefore copies its
-// 64 x 10 floats per date into LDS with coalesced float4 loads (all T x 3 loads of a lane in flight at once) and every
-// lane then picks its pixel's series out of LDS (40-byte lane stride: conflict-free for ds_read_b64).
+// TWO waves per 64 pixels.  The [T, X, Y, 10] stack is pixel-major (40-byte records): a thread-per-pixel load touches 20
+// cache lines per instruction for 512 useful bytes, and the kernel sat at 0.76 TB/s.  The block therefore copies its
+// 64 x 10 floats per date into LDS with coalesced 16-byte DMA copies and every lane then picks its pixel's series out of LDS
+// (40-byte lane stride: conflict-free for ds_read_b64).  The staged tile (480 B per pixel at T = 12) caps a CU at ~5 blocks, and
+// with one wave per block that was ONE wave per SIMD running ~9 k dependent VALU operations per pixel (14 sorting networks,
+// 14 12 x T products, the spectral indices twice): 27 % of the VALU rate.  The two waves of a block now split that work over
+// the same staged pixels -- wave 0: the medians over all dates (bands, raw indices); wave 1: 0 / 1 repair, the temporal
+// operator on bands and on the indices of the repaired bands -- so a SIMD holds two independent instruction streams.
 template <int TM>
-__global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ s2, const WMat* __restrict__ wmp, int npix, int L,
-                                                      float* __restrict__ sm, float* __restrict__ med) {
+__global__ __launch_bounds__(128) void k_tile_temporal(const float* __restrict__ s2, const WMat* __restrict__ wmp, int npix, int L,
+                                                       float* __restrict__ sm, float* __restrict__ med) {
     const WMat& wm = *wmp;              // device memory (built by the host mirror or by k_build_wmat); uniform indices -> scalar loads
     extern __shared__ __attribute__((aligned(16))) float stage[];      // [T][64 px][10]
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int p0 = blockIdx.x * 64;
     const int T = wm.T;
     {
         const int nfl = min(64, npix - p0) * 10;                      // floats of this block per date
         if (nfl == 640 && (npix & 1) == 0) {     // (odd pixel counts break the 16-byte alignment of odd dates)
-            // global -> LDS DMA (wave-uniform LDS base + lane * 16 = exactly this linear copy); no staging registers
+            // global -> LDS DMA (wave-uniform LDS base + lane * 16 = exactly this linear copy); no staging registers; the two
+            // waves take alternate dates
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                if (t < T) {
+                if (t < T && (t & 1) == role) {
                     const float* src = s2 + ((long)t * npix + p0) * 10;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ 
             }
         } else {                                                       // ragged last block / unaligned: element-wise
             for (int t = 0; t < T; ++t)
-                for (int i = lane; i < nfl; i += 64) stage[t * 640 + i] = s2[((long)t * npix + p0) * 10 + i];
+                for (int i = threadIdx.x; i < nfl; i += 128) stage[t * 640 + i] = s2[((long)t * npix + p0) * 10 + i];
         }
     }
     __syncthreads();
@@ -205,14 +210,14 @@ __global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ 
             b0[t] = q0.x; b1[t] = q0.y; b2[t] = q1.x; b3[t] = q1.y; b8[t] = q4.x; b9[t] = q4.y;
         } else { b0[t] = b1[t] = b2[t] = b3[t] = b8[t] = b9[t] = 0.f; }
     }
-    // medians over ALL dates of the raw bands and of the raw per-date indices (job.py:1152-1160)
-    med[0L * npix + p] = median_masked<TM>(b0, all, T);
-    med[1L * npix + p] = median_masked<TM>(b1, all, T);
-    med[2L * npix + p] = median_masked<TM>(b2, all, T);
-    med[3L * npix + p] = median_masked<TM>(b3, all, T);
-    med[8L * npix + p] = median_masked<TM>(b8, all, T);
-    med[9L * npix + p] = median_masked<TM>(b9, all, T);
-    {
+    if (role == 0) {
+        // medians over ALL dates of the raw bands and of the raw per-date indices (job.py:1152-1160)
+        med[0L * npix + p] = median_masked<TM>(b0, all, T);
+        med[1L * npix + p] = median_masked<TM>(b1, all, T);
+        med[2L * npix + p] = median_masked<TM>(b2, all, T);
+        med[3L * npix + p] = median_masked<TM>(b3, all, T);
+        med[8L * npix + p] = median_masked<TM>(b8, all, T);
+        med[9L * npix + p] = median_masked<TM>(b9, all, T);
         float ix[TM];
 #pragma unroll
         for (int t = 0; t < TM; ++t) ix[t] = idx_evi(b0[t], b2[t], b3[t]);
@@ -226,17 +231,16 @@ __global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ 
 #pragma unroll
         for (int t = 0; t < TM; ++t) ix[t] = idx_grndvi(b1[t], b2[t], b3[t]);
         med[13L * npix + p] = median_masked<TM>(ix, all, T);
-    }
-    // repair, then smooth bands and the indices of the REPAIRED bands (job.py:1067-1082)
-    fix_zero_one<TM>(b0, wm.keep, wm.Tk); fix_zero_one<TM>(b1, wm.keep, wm.Tk); fix_zero_one<TM>(b2, wm.keep, wm.Tk);
-    fix_zero_one<TM>(b3, wm.keep, wm.Tk); fix_zero_one<TM>(b8, wm.keep, wm.Tk); fix_zero_one<TM>(b9, wm.keep, wm.Tk);
-    smooth_store<TM>(b0, wm, L, sm + 0L * npix + p, fstride);
-    smooth_store<TM>(b1, wm, L, sm + 1L * npix + p, fstride);
-    smooth_store<TM>(b2, wm, L, sm + 2L * npix + p, fstride);
-    smooth_store<TM>(b3, wm, L, sm + 3L * npix + p, fstride);
-    smooth_store<TM>(b8, wm, L, sm + 8L * npix + p, fstride);
-    smooth_store<TM>(b9, wm, L, sm + 9L * npix + p, fstride);
-    {
+    } else {
+        // repair, then smooth bands and the indices of the REPAIRED bands (job.py:1067-1082)
+        fix_zero_one<TM>(b0, wm.keep, wm.Tk); fix_zero_one<TM>(b1, wm.keep, wm.Tk); fix_zero_one<TM>(b2, wm.keep, wm.Tk);
+        fix_zero_one<TM>(b3, wm.keep, wm.Tk); fix_zero_one<TM>(b8, wm.keep, wm.Tk); fix_zero_one<TM>(b9, wm.keep, wm.Tk);
+        smooth_store<TM>(b0, wm, L, sm + 0L * npix + p, fstride);
+        smooth_store<TM>(b1, wm, L, sm + 1L * npix + p, fstride);
+        smooth_store<TM>(b2, wm, L, sm + 2L * npix + p, fstride);
+        smooth_store<TM>(b3, wm, L, sm + 3L * npix + p, fstride);
+        smooth_store<TM>(b8, wm, L, sm + 8L * npix + p, fstride);
+        smooth_store<TM>(b9, wm, L, sm + 9L * npix + p, fstride);
         float ix[TM];
 #pragma unroll
         for (int t = 0; t < TM; ++t) ix[t] = idx_evi(b0[t], b2[t], b3[t]);
@@ -261,16 +265,19 @@ __global__ __launch_bounds__(64) void k_tile_temporal(const float* __restrict__ 
                 c4[t] = q2.x; c5[t] = q2.y; c6[t] = q3.x; c7[t] = q3.y;
             } else { c4[t] = c5[t] = c6[t] = c7[t] = 0.f; }
         }
-        med[4L * npix + p] = median_masked<TM>(c4, all, T);
-        med[5L * npix + p] = median_masked<TM>(c5, all, T);
-        med[6L * npix + p] = median_masked<TM>(c6, all, T);
-        med[7L * npix + p] = median_masked<TM>(c7, all, T);
-        fix_zero_one<TM>(c4, wm.keep, wm.Tk); fix_zero_one<TM>(c5, wm.keep, wm.Tk);
-        fix_zero_one<TM>(c6, wm.keep, wm.Tk); fix_zero_one<TM>(c7, wm.keep, wm.Tk);
-        smooth_store<TM>(c4, wm, L, sm + 4L * npix + p, fstride);
-        smooth_store<TM>(c5, wm, L, sm + 5L * npix + p, fstride);
-        smooth_store<TM>(c6, wm, L, sm + 6L * npix + p, fstride);
-        smooth_store<TM>(c7, wm, L, sm + 7L * npix + p, fstride);
+        if (role == 0) {
+            med[4L * npix + p] = median_masked<TM>(c4, all, T);
+            med[5L * npix + p] = median_masked<TM>(c5, all, T);
+            med[6L * npix + p] = median_masked<TM>(c6, all, T);
+            med[7L * npix + p] = median_masked<TM>(c7, all, T);
+        } else {
+            fix_zero_one<TM>(c4, wm.keep, wm.Tk); fix_zero_one<TM>(c5, wm.keep, wm.Tk);
+            fix_zero_one<TM>(c6, wm.keep, wm.Tk); fix_zero_one<TM>(c7, wm.keep, wm.Tk);
+            smooth_store<TM>(c4, wm, L, sm + 4L * npix + p, fstride);
+            smooth_store<TM>(c5, wm, L, sm + 5L * npix + p, fstride);
+            smooth_store<TM>(c6, wm, L, sm + 6L * npix + p, fstride);
+            smooth_store<TM>(c7, wm, L, sm + 7L * npix + p, fstride);
+        }
     }
 }
 
@@ -808,7 +815,7 @@ static ttc_status tile_core(ttc_ctx* c, const float* d_s2, int T, int X, int Y, 
           static LdsConfig cfg32;
           TTC_HIP(c, cfg32.ensure(&k_tile_temporal<32>, (size_t)32 * 640 * 4));
       }
-      LAUNCH_T(k_tile_temporal, T, dim3((unsigned)((npix + 63) / 64)), dim3(64), (size_t)TM * 640 * sizeof(float), s, d_s2, d_wm, (int)npix, L, sm, med);
+      LAUNCH_T(k_tile_temporal, T, dim3((unsigned)((npix + 63) / 64)), dim3(128), (size_t)std::min(T, TM) * 640 * sizeof(float), s, d_s2, d_wm, (int)npix, L, sm, med);
       TTC_HIP(c, hipGetLastError()); }
     { KTimer kt(c, "tile_s1", s);
       hipLaunchKernelGGL(k_tile_s1, dim3(gp), dim3(256), 0, s, d_s1, (int)npix, L, s1q, s1med);
