@@ -200,6 +200,43 @@ __global__ void k_block_finalize(FinArgs a) {
     }
 }
 
+// The same for the single-source gathers (COPY / UP) of the C = 64 and C = 128 blocks: the thread keeps its C normalised values
+// in registers between the gate sum and the output pass, so the raw conv output is read from HBM ONCE (the two-pass form above
+// read it twice: these passes are pure HBM streams, and the raw tensors do not fit the L2).
+template <int MODE, int C>
+__global__ __launch_bounds__(256) void k_block_finalize_1p(FinArgs a) {
+    static_assert(MODE != G_POOL, "the pooled gather has four sources per destination");
+    __shared__ float sm[3 * C];              // scale[C] shift[C] ssew[C]
+    const int n = blockIdx.y;
+    constexpr int cpg = C / 8;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mean = a.gn[((long)n * 8 + c / cpg) * 2], rstd = a.gn[((long)n * 8 + c / cpg) * 2 + 1];
+        const float sc = rstd * a.prm[c];
+        sm[c] = sc; sm[C + c] = a.prm[C + c] - mean * sc; sm[2 * C + c] = a.prm[2 * C + c];
+    }
+    __syncthreads();
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.Hd * a.Wd) return;
+    const int dy = d / a.Wd, dx = d - dy * a.Wd;
+    const int SP = a.Ws + 2;
+    const long PS = (long)a.Hs * SP, PD = (long)a.Hd * a.Wd;
+    float* dst = a.dst + (long)n * a.dst_stride_n + (long)a.dst_coff * PD + d;
+    const int iy = dy - a.pad, ix = dx - a.pad;
+    if (iy < 0 || ix < 0 || iy >= a.Hd - 2 * a.pad || ix >= a.Wd - 2 * a.pad) {
+        for (int c = 0; c < C; ++c) dst[(long)c * PD] = 0.0f;
+        return;
+    }
+    const int src = MODE == G_COPY ? (iy + a.crop) * SP + ix + a.crop : (iy >> 1) * SP + (ix >> 1);
+    const float* y = a.y + (long)n * C * PS + src;
+    float zn[C];
+    float gate = a.prm[3 * C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { zn[c] = y[(long)c * PS] * sm[c] + sm[C + c]; gate += sm[2 * C + c] * zn[c]; }
+    gate = sigm(gate);
+#pragma unroll
+    for (int c = 0; c < C; ++c) dst[(long)c * PD] = zn[c] * gate;
+}
+
 // final block tail + 1x1 head (train-model.py:226-231): sigmoid(sum_c hw[c] * z[c] + hb)
 // BLK: the raw conv output is the 16-bit engine's channel-blocked split planes (Raw16, h16_common.h), `yraw` = its top plane
 // and the bottom plane follows after gridDim.y * (C / 8) * PS units
@@ -441,6 +478,54 @@ __global__ void k_block_finalize_b16(FinArgs a) {
                 o[j] = k == 0 ? t : fmaxf(o[j], t);
             }
         }
+        b16_store8<BF>(a.dhi, a.dlo, u0 + cb * PD, o);
+    }
+}
+
+// one-pass form for the single-source gathers of the C = 64 / 128 blocks (see k_block_finalize_1p)
+template <int BF, int MODE, int C>
+__global__ __launch_bounds__(256) void k_block_finalize_b16_1p(FinArgs a) {
+    static_assert(MODE != G_POOL, "the pooled gather has four sources per destination");
+    __shared__ float sm[3 * C];
+    const int n = blockIdx.y;
+    constexpr int cpg = C / 8;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float mean = a.gn[((long)n * 8 + c / cpg) * 2], rstd = a.gn[((long)n * 8 + c / cpg) * 2 + 1];
+        const float sc = rstd * a.prm[c];
+        sm[c] = sc; sm[C + c] = a.prm[C + c] - mean * sc; sm[2 * C + c] = a.prm[2 * C + c];
+    }
+    __syncthreads();
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.Hd * a.Wd) return;
+    const int dy = d / a.Wd, dx = d - dy * a.Wd;
+    const int SP = a.Ws + 2;
+    const long PS = (long)a.Hs * SP, PD = (long)a.Hd * a.Wd;
+    const long u0 = (long)n * a.dst_stride_n + (long)a.dst_coff * PD + d;
+    const int iy = dy - a.pad, ix = dx - a.pad;
+    if (iy < 0 || ix < 0 || iy >= a.Hd - 2 * a.pad || ix >= a.Wd - 2 * a.pad) {
+        const uint4 zv = make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < C / 8; ++k) { a.dhi[u0 + k * PD] = zv; a.dlo[u0 + k * PD] = zv; }
+        return;
+    }
+    const int src = MODE == G_COPY ? (iy + a.crop) * SP + ix + a.crop : (iy >> 1) * SP + (ix >> 1);
+    const uint4* ytop = reinterpret_cast<const uint4*>(a.y);
+    const uint4* ybot = ytop + (long)gridDim.y * (C / 8) * PS;
+    const long ub = (long)n * (C / 8) * PS + src;
+    float zn[C];
+    float gate = a.prm[3 * C];
+#pragma unroll
+    for (int cb = 0; cb < C / 8; ++cb) {
+        float v[8];
+        raw_load8(ytop, ybot, ub + (long)cb * PS, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { zn[8 * cb + j] = v[j] * sm[8 * cb + j] + sm[C + 8 * cb + j]; gate += sm[2 * C + 8 * cb + j] * zn[8 * cb + j]; }
+    }
+    gate = sigm(gate);
+#pragma unroll
+    for (int cb = 0; cb < C / 8; ++cb) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = zn[8 * cb + j] * gate;
         b16_store8<BF>(a.dhi, a.dlo, u0 + cb * PD, o);
     }
 }
@@ -689,7 +774,10 @@ static ttc_status finalize(ttc_ctx* c, int mode, const FinArgs& a, int n, hipStr
     KTimer kt(c, "block_finalize", s);
     dim3 grid((a.Hd * a.Wd + 255) / 256, n);
     const size_t lds = 3 * a.C * sizeof(float);
-    if (mode == G_COPY) hipLaunchKernelGGL(k_block_finalize<G_COPY>, grid, dim3(256), lds, s, a);
+    if (mode == G_COPY && a.C == 64) hipLaunchKernelGGL((k_block_finalize_1p<G_COPY, 64>), grid, dim3(256), 0, s, a);
+    else if (mode == G_COPY && a.C == 128) hipLaunchKernelGGL((k_block_finalize_1p<G_COPY, 128>), grid, dim3(256), 0, s, a);
+    else if (mode == G_UP && a.C == 128) hipLaunchKernelGGL((k_block_finalize_1p<G_UP, 128>), grid, dim3(256), 0, s, a);
+    else if (mode == G_COPY) hipLaunchKernelGGL(k_block_finalize<G_COPY>, grid, dim3(256), lds, s, a);
     else if (mode == G_POOL) hipLaunchKernelGGL(k_block_finalize<G_POOL>, grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL(k_block_finalize<G_UP>, grid, dim3(256), lds, s, a);
     TTC_HIP(c, hipGetLastError());
@@ -789,7 +877,10 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
         KTimer kt(c, "block_finalize", s);
         dim3 grid((f.Hd * f.Wd + 255) / 256, N);
         const size_t lds = 3 * f.C * sizeof(float);
-        if (mode == G_COPY) hipLaunchKernelGGL((k_block_finalize_b16<BF, G_COPY>), grid, dim3(256), lds, s, f);
+        if (mode == G_COPY && f.C == 64) hipLaunchKernelGGL((k_block_finalize_b16_1p<BF, G_COPY, 64>), grid, dim3(256), 0, s, f);
+        else if (mode == G_COPY && f.C == 128) hipLaunchKernelGGL((k_block_finalize_b16_1p<BF, G_COPY, 128>), grid, dim3(256), 0, s, f);
+        else if (mode == G_UP && f.C == 128) hipLaunchKernelGGL((k_block_finalize_b16_1p<BF, G_UP, 128>), grid, dim3(256), 0, s, f);
+        else if (mode == G_COPY) hipLaunchKernelGGL((k_block_finalize_b16<BF, G_COPY>), grid, dim3(256), lds, s, f);
         else if (mode == G_POOL) hipLaunchKernelGGL((k_block_finalize_b16<BF, G_POOL>), grid, dim3(256), lds, s, f);
         else hipLaunchKernelGGL((k_block_finalize_b16<BF, G_UP>), grid, dim3(256), lds, s, f);
         TTC_HIP(c, hipGetLastError());
