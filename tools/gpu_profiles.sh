@@ -1,6 +1,8 @@
 #!/bin/bash
-# usage (GPU box, repo root): bash tools/gpu_profiles.sh <tag>   -> gpurun_out/<tag>_*: bench lines, rocprofv3 kernel stats, PMC passes
-TAG=${1:-r02_c}
+# usage (GPU box, repo root): bash tools/gpu_profiles.sh <tag>   -> gpurun_out/<tag>_*: bench lines, rocprofv3 kernel stats, PMC passes.
+# Kernel-stats runs use --inflight 1 --no-dprob --no-alt --no-cpu-baseline so that a kernel's average is not a mix of live
+# (two tiles in flight), isolated, warm-up and 3-window parity launches.  PMC passes are their own runs (--kernel-trace --pmc only).
+TAG=${1:-r03_f}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -11,31 +13,34 @@ prof() {  # name, bench args...
     (cd $R && python tools/rocpd_stats.py $f > $O/${TAG}_${name}_kernel_stats.md)
     rm -rf $O/prof_${TAG}_$name
 }
-prof bench                                   # the default command, as the driver runs it
-prof fp16 --precision fp16 --no-alt --no-cpu-baseline
-prof preprocess --preprocess-only --tiles 64 --no-cpu-baseline
+prof fp32 --inflight 1 --no-dprob --no-alt --no-cpu-baseline --steps 10
+prof fp16 --precision fp16 --inflight 1 --no-dprob --no-alt --no-cpu-baseline --steps 10
+prof preprocess --preprocess-only --tiles 64 --inflight 1 --no-cpu-baseline
 cd $R
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
-    t=${TAG}_pmc_$(echo $c | cut -d' ' -f1)
-    bash tools/gpu_pmc.sh $t "$c" -- $R/tools/gpu_probe.py 172 4 36 fp16 > /dev/null 2>&1
+pmc() {  # out-file, kernel substring(s) separated by |, counters, command...
+    local out=$1 subs=$2 cnt=$3; shift 3
+    local t=${TAG}_pmc_$(echo $cnt | cut -d' ' -f1)_$(basename $out .txt)
+    bash tools/gpu_pmc.sh $t "$cnt" -- "$@" > /dev/null 2>&1
     f=$(find gpurun_out/pmc_$t -name "*results.db" | head -1)
-    echo "== $c"; python tools/rocpd_pmc.py $f "conv3x3_h16<0, 3, 2, 0, 0>"
+    echo "== $cnt" >> $out
+    IFS='|' read -ra SS <<< "$subs"
+    for sname in "${SS[@]}"; do python tools/rocpd_pmc.py $f "$sname" >> $out; done
     rm -rf gpurun_out/pmc_$t
-done > $O/${TAG}_pmc_h16_gates.txt 2>&1
+}
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    pmc $O/${TAG}_pmc_f32_gates.txt "conv3x3_f32<10, 2, 0" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
+    pmc $O/${TAG}_pmc_h16_gates.txt "conv3x3_h16<0, 3, 2, 0, 1>|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+    pmc $O/${TAG}_pmc_preprocess.txt "k_hist_all|k_tile_temporal|k_stat_all|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
+done
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python bench.py --precision fp16 --no-cpu-baseline > $O/${TAG}_bench_fp16.json 2>> $O/${TAG}_bench.err
-python bench.py --precision bf16 --no-alt --no-cpu-baseline > $O/${TAG}_bench_bf16.json 2>> $O/${TAG}_bench.err
+python bench.py --precision fp16 --no-cpu-baseline --no-alt > $O/${TAG}_bench_fp16.json 2>> $O/${TAG}_bench.err
 python bench.py --preprocess-only --tiles 256 --no-cpu-baseline > $O/${TAG}_bench_preprocess_only.json 2>> $O/${TAG}_bench.err
-python - <<'PY'
-import json, glob, os
-for f in sorted(glob.glob(os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/%s_bench*.json" % os.environ.get("TAGX", ""))):
-    pass
-PY
-for f in $O/${TAG}_bench.json $O/${TAG}_bench_fp16.json $O/${TAG}_bench_bf16.json $O/${TAG}_bench_preprocess_only.json $O/${TAG}_bench_profiled.json; do
+for f in $O/${TAG}_bench.json $O/${TAG}_bench_fp16.json $O/${TAG}_bench_preprocess_only.json $O/${TAG}_fp32_profiled.json $O/${TAG}_fp16_profiled.json; do
     python -c "
 import json,sys
 d=json.load(open('$f')); r=d['roofline']
-print('$f'.split('/')[-1], round(d['value']/1e6,2),'Mpx/s', round(d['ms_per_step'],2),'ms/step dprob',d.get('max_dprob'),'| roofline', r.get('launch_ms'), r.get('frac'), r.get('isolated_launch_ms'), '| alt', (d.get('alt_precision') or {}).get('value'))
+print('$f'.split('/')[-1], round(d['value']/1e6,2),'Mpx/s', round(d['ms_per_step'],2),'ms/step dprob',d.get('max_dprob'),'| roofline', r.get('launch_ms'), r.get('frac'), r.get('isolated_launch_ms'))
 "
 done
-cat $O/${TAG}_pmc_h16_gates.txt
