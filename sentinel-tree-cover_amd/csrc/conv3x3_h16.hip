@@ -229,8 +229,9 @@ __device__ __forceinline__ void h16_epilogue_b16(const H16Args& a, f32x16 (&acc)
     }
 }
 
-template <int BF, int TERMS, int NCG, int EPI, int OUT>
-__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb, int ntiles, int desync) {
+template <int BF, int TERMS, int NCG, int EPI, int OUT, bool TRACE = false>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q, int ncb, int ntiles, int desync,
+                                                            unsigned long long* __restrict__ trace) {
     using E = Elem<BF>;
     using v8 = typename E::v8;
     constexpr int BN = NCG * 32;
@@ -509,14 +510,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
             mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, [&](int kb) { if (kb == 0) issue_in(src, nlo, LOU); });   // x_hi * (w_lo, w_hi)
         };
         int g = 0;
-        for (int tk = wslot;;) {
+        // probe aid (ttc_debug_knob 2 / 3, tools/probes/h16_trace.py): thread 0 stamps s_memtime at the phase boundaries of the
+        // workgroup's first 12 tiles -- [tile][0] start, [1] before the last chunk, [2] after it, [3] after the epilogue; slot 63 = HW ids
+        unsigned long long* tr = (TRACE && trace && tid == 0) ? trace + (long)blockIdx.x * 64 : nullptr;
+        if (TRACE && tr) tr[63] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        int ti = 0;
+        for (int tk = wslot;; ++ti) {
+            if (TRACE && tr && ti < 12) tr[4 * ti] = __builtin_amdgcn_s_memtime();
             zero_acc();
             for (int c = 0; c + 1 < nchunk; ++c, ++g) chunk(g, c + 1, true);
             const bool any = tk + nx < tcnt;                          // last chunk of this tile: stage chunk 0 of the next one
             if (any) src = src_of(tk + nx);
+            if (TRACE && tr && ti < 12) tr[4 * ti + 1] = __builtin_amdgcn_s_memtime();
             chunk(g, 0, any);
             ++g;
+            if (TRACE && tr && ti < 12) tr[4 * ti + 2] = __builtin_amdgcn_s_memtime();
             epilogue(ep);                                             // no LDS: the next tile's first chunk is landing meanwhile
+            if (TRACE && tr && ti < 12) tr[4 * ti + 3] = __builtin_amdgcn_s_memtime();
             if (!any) break;
             tk += nx;
             ep = ep_of(src);
@@ -525,8 +535,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
 }
 
 // probe knobs (ttc_debug_knob): [0] persistent grid size (-1 = 2 x CUs, 0 = one workgroup per tile), [1] start offset of the odd
-// wave slot in units of s_sleep(127) (-1 = default)
-int g_h16_knob[4] = {-1, -1, -1, -1};
+// wave slot in units of s_sleep(127) (-1 = default), [2] | [3] low / high half of a device pointer to a trace buffer, [4] the
+// epilogue kind to trace
+int g_h16_knob[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
 constexpr int kDesyncDefault = 0;
 
 template <int BF, int TERMS, int NCG, int EPI, int OUT>
@@ -551,13 +562,28 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
     const int res = g_h16_knob[0] >= 0 ? g_h16_knob[0] : resident;
     const int grid = res > 0 ? std::min(ntiles, res) : ntiles;
     const int desync = g_h16_knob[1] >= 0 ? g_h16_knob[1] : kDesyncDefault;
-    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles, desync);
+    // trace buffer (device pointer in knobs 2 | 3, 64 x u64 per workgroup) for the layer kind in knob 4 (default: the ConvGRU gates)
+    unsigned long long* trace = nullptr;
+    if (g_h16_knob[2] != -1 || g_h16_knob[3] != -1) {
+        const int want_epi = g_h16_knob[4] >= 0 ? g_h16_knob[4] : (int)EPI_RAW;
+        if (EPI == want_epi && TERMS == 3)
+            trace = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)g_h16_knob[3] << 32) | (unsigned)g_h16_knob[2]);
+    }
+    if constexpr (TERMS == 3 && EPI <= EPI_SWISH && BF == 0) {        // the traced instantiations exist for the fp16 GroupNorm layers only
+        if (trace) {
+            static LdsConfig lds_tr;
+            if (hipError_t e = lds_tr.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT, true>, lds); e != hipSuccess) return e;
+            hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT, true>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles, desync, trace);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_h16<BF, TERMS, NCG, EPI, OUT>), dim3(grid), dim3(kThreads), lds, s, a, nblk_q, pw.ncb, ntiles, desync, nullptr);
     return hipGetLastError();
 }
 
 }  // namespace
 
-void h16_set_knob(int which, int value) { if (which >= 0 && which < 4) g_h16_knob[which] = value; }
+void h16_set_knob(int which, int value) { if (which >= 0 && which < 8) g_h16_knob[which] = value; }
 
 // ---- host: 16-bit conversions (round to nearest even), weight packing, dispatch -----------------------------------
 uint16_t h16_from_float(float f, bool bf) {
