@@ -513,7 +513,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
         // probe aid (ttc_debug_knob 2 / 3, tools/probes/h16_trace.py): thread 0 stamps s_memtime at the phase boundaries of the
         // workgroup's first 12 tiles -- [tile][0] start, [1] before the last chunk, [2] after it, [3] after the epilogue; slot 63 = HW ids
         unsigned long long* tr = (TRACE && trace && tid == 0) ? trace + (long)blockIdx.x * 64 : nullptr;
-        if (TRACE && tr) tr[63] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        if (TRACE && tr) {
+            tr[63] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            tr[60] = __builtin_amdgcn_s_memrealtime();     // constant 100 MHz reference clock: with [62] / the end stamps = the shader clock
+            tr[62] = __builtin_amdgcn_s_memtime();
+        }
         int ti = 0;
         for (int tk = wslot;; ++ti) {
             if (TRACE && tr && ti < 12) tr[4 * ti] = __builtin_amdgcn_s_memtime();
@@ -527,6 +531,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
             if (TRACE && tr && ti < 12) tr[4 * ti + 2] = __builtin_amdgcn_s_memtime();
             epilogue(ep);                                             // no LDS: the next tile's first chunk is landing meanwhile
             if (TRACE && tr && ti < 12) tr[4 * ti + 3] = __builtin_amdgcn_s_memtime();
+            if (TRACE && tr && !any) { tr[61] = __builtin_amdgcn_s_memrealtime(); tr[59] = __builtin_amdgcn_s_memtime(); }
             if (!any) break;
             tk += nx;
             ep = ep_of(src);

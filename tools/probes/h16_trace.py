@@ -41,13 +41,23 @@ ids = t[:, 63]
 hw, xcc = (ids >> np.uint64(32)).astype(np.int64), (ids & np.uint64(0xffffffff)).astype(np.int64)
 cu = (xcc & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xf)
 print(f"conv_gates event time {ms:.3f} ms x {n}; traced workgroups {int(ok[:, 0].sum())}, tiles stamped {int(ok.sum())}")
-full = ok[:, :8].all(axis=1)
+# shader clock under this launch: s_memtime ticks per 100 MHz reference tick over each workgroup's whole walk
+rt = (t[:, 61].astype(np.float64) - t[:, 60].astype(np.float64))
+mt = (t[:, 59].astype(np.float64) - t[:, 62].astype(np.float64))
+good = (rt > 0) & (mt > 0)
+if good.any():
+    ghz = mt[good] / rt[good] * 0.1
+    print(f"  shader clock during the walk (s_memtime / s_memrealtime): mean {ghz.mean():.3f} GHz, p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}; "
+          f"walk length mean {rt[good].mean() / 100:.1f} us of the launch's {ms * 1e3:.0f} us")
+nt = int(ok.sum(axis=1).min())
+nt = max(2, min(8, nt))
+full = ok[:, :nt].all(axis=1)
 s = st[full]
-tile = s[:, 1:8, 0] - s[:, 0:7, 0]                    # start -> next start
-body = s[:, :8, 1] - s[:, :8, 0]                      # all chunks but the last
-lastc = s[:, :8, 2] - s[:, :8, 1]
-epi = s[:, :8, 3] - s[:, :8, 2]
-gap = s[:, 1:8, 0] - s[:, 0:7, 3]
+tile = s[:, 1:nt, 0] - s[:, 0:nt - 1, 0]                    # start -> next start
+body = s[:, :nt, 1] - s[:, :nt, 0]                      # all chunks but the last
+lastc = s[:, :nt, 2] - s[:, :nt, 1]
+epi = s[:, :nt, 3] - s[:, :nt, 2]
+gap = s[:, 1:nt, 0] - s[:, 0:nt - 1, 3]
 for name, a in (("tile period", tile), ("chunks 0..n-2", body), ("last chunk", lastc), ("epilogue", epi), ("epilogue end -> next tile start", gap)):
     print(f"  {name:34s} mean {a.mean():9.0f}  p10 {np.percentile(a, 10):9.0f}  p50 {np.percentile(a, 50):9.0f}  p90 {np.percentile(a, 90):9.0f} ticks")
 # phase offset between the two workgroups of a CU, relative to the tile period
@@ -55,10 +65,8 @@ offs = []
 for c in np.unique(cu[full]):
     m = np.flatnonzero((cu == c) & full)
     if len(m) == 2:
-        d = abs(st[m[0], 3, 0] - st[m[1], 3, 0])
+        d = abs(st[m[0], 1, 0] - st[m[1], 1, 0])
         per = np.mean(tile)
         offs.append((d % per) / per)
 if offs:
     print(f"  co-resident pairs found: {len(offs)}; start offset of tile 3 as a fraction of the period: mean {np.mean(offs):.2f}, p10 {np.percentile(offs, 10):.2f}, p90 {np.percentile(offs, 90):.2f}")
-span = (st[full][:, 7, 3].max() - st[full][:, 0, 0].min())
-print(f"  first 8 tiles of all workgroups span {span:.0f} ticks; kernel {ms * 1e3:.0f} us -> ticks per us (if they covered the whole launch): {st[ok].max() - st[:, 0, 0][ok[:, 0]].min():.0f} / {ms * 1e3:.0f}")
