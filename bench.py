@@ -41,7 +41,9 @@ DTYPES = {
     "fp16": "fp16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
     "bf16": "bf16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
 }
-E2E_WINDOWS = (0, 14, 35)        # windows of tile 0 the oracle's model leg is run on (corner, interior, opposite corner)
+E2E_WINDOWS = tuple(range(36))   # windows of tile 0 the oracle's model leg is run on: all of them
+ORACLE_THREADS = 16              # torch threads of the CPU oracle: its best setting on the GPU box's 256 cpus (128, torch's default
+                                 # there, is ~9x slower: profiles/r03_cpu_threads.txt); the numpy stages are single-threaded
 
 
 def conv_gates_flops(W, n_windows):
@@ -93,9 +95,10 @@ def roofline(precision, win, n_windows, gates_ms, gates_n):
 def oracle_pass(args, host_tile, weights):
     """ONE pass of the chained CPU oracle (oracle/restate_e2e.single_call_chain: the CPU restatement of the reference, kind =
     "port") over tile 0 of the bench, on the host cores.  It serves two purposes: the `cpu_baseline` (every stage timed on
-    the WHOLE tile except the ConvGRU / U-Net model, which runs on len(E2E_WINDOWS) of the 36 windows and is scaled) and the
-    reference values of `max_dprob_e2e`."""
+    the WHOLE tile; were E2E_WINDOWS a subset, the model's share would be scaled to 36 windows) and the reference values of
+    `max_dprob_e2e`."""
     import torch
+    torch.set_num_threads(min(ORACLE_THREADS, os.cpu_count() or 1))
     from oracle import restate_e2e as E, restate_model as M
     from ttc import weights as Wt
     s2_10, s2_20, probs, dates, s1, dem = host_tile
@@ -111,7 +114,8 @@ def oracle_pass(args, host_tile, weights):
             "sample": "oracle/restate_e2e.single_call_chain on one whole 618x618 T=%d tile: codecs, bilinear, gap-fill (expected-"
                       "multiplicity sampler), DSen2 on all 31 windows x T dates, NaN repair / temporal operator / indices / medians / "
                       "window assembly / post-masks and the Gaussian mosaic run in full; the ConvGRU / U-Net model on %d of 36 windows, "
-                      "x%.0f; seconds per tile: %s" % (args.dates, n_model, 36.0 / n_model, json.dumps({k: round(v, 2) for k, v in tm.items()}))}
+                      "x%.0f; torch stages (DSen2, model) on %d threads, numpy stages on 1; seconds per tile: %s"
+                      % (args.dates, n_model, 36.0 / n_model, torch.get_num_threads(), json.dumps({k: round(v, 2) for k, v in tm.items()}))}
     return ref, base
 
 
@@ -415,7 +419,7 @@ def main():
             "max_dprob": dprob,
             "max_dprob_e2e": {"value": e2e.get(args.precision), "by_precision": by_prec,
                               "what": "raw uint16 tile 0 -> ONE ttc_predict_tile call -> pre-rounding window probabilities vs the chained CPU oracle "
-                                      "(oracle/restate_e2e.py, expected-multiplicity sampler restated), windows %s; contract 1e-3" % (list(E2E_WINDOWS),),
+                                      "(oracle/restate_e2e.py, expected-multiplicity sampler restated), %d of the 36 windows; contract 1e-3" % (len(E2E_WINDOWS),),
                               "sampler_effect": sampler_effect},
             "config": {
                 "workload": f"{args.inflight} x 618x618 tile per GPU per step, T={args.dates} dates, 36 overlapping {args.win}x{args.win} "
@@ -434,7 +438,7 @@ def main():
                 "tiles_per_step_per_gpu": args.inflight, "streams_per_gpu": args.inflight, "distinct_tiles_per_gpu": len(pool),
                 "tile_ids": "k * world + rank", "gather_batch": B if world > 1 else None, "gathers_timed": state["gathers"] if world > 1 else None,
                 "tiles_flagged_for_staged_path": bad, "tiles_failed": state["failed"],
-                "max_dprob_sample": "model only: HIP vs fp32 oracle on windows %s of tile 0 (model inputs as the tile path assembled them)" % (list(E2E_WINDOWS),),
+                "max_dprob_sample": "model only: HIP vs fp32 oracle on %d of the 36 windows of tile 0 (model inputs as the tile path assembled them)" % (len(E2E_WINDOWS),),
                 "win_in": args.win, "length": args.length, "dates": args.dates,
                 "model_tflop_per_tile": 36 * model_flops(args.win, args.length) / 1e12,
             },

@@ -136,7 +136,8 @@ def test_dsen2_16bit(precision, tol):
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("precision,size,length", [("fp32", 158, 4), ("fp16", 158, 4), ("bf16", 158, 4), ("fp16", 154, 12)])
+# 158 / L = 4 in all three precisions is covered from the raw uint16 tile by tests/test_gpu_e2e.py
+@pytest.mark.parametrize("precision,size,length", [("fp16", 158, 4), ("fp16", 154, 12)])
 def test_tile_16bit_vs_oracle(precision, size, length):
     """Whole 618^2 tile (36 windows of size + 14, L steps) on the 16-bit engine against the fp32 oracle: window probabilities
     BEFORE the reference's 3-decimal rounding within the 1e-3 contract, identical no-data, uint8 raster within one count.

@@ -40,6 +40,8 @@ ok = st[:, :, 3] > 0
 ids = t[:, 63]
 hw, xcc = (ids >> np.uint64(32)).astype(np.int64), (ids & np.uint64(0xffffffff)).astype(np.int64)
 cu = (xcc & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xf)
+if not ok.any():
+    sys.exit(f"no workgroup was traced: the traced instantiations exist for the fp16 GroupNorm layers only (precision {PREC}, epilogue {EPI})")
 print(f"conv_gates event time {ms:.3f} ms x {n}; traced workgroups {int(ok[:, 0].sum())}, tiles stamped {int(ok.sum())}")
 # shader clock under this launch: s_memtime ticks per 100 MHz reference tick over each workgroup's whole walk
 rt = (t[:, 61].astype(np.float64) - t[:, 60].astype(np.float64))
