@@ -403,23 +403,52 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
 #pragma unroll
         for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + bs + 32 * j);
     };
-    auto mfma_chunk_hi2_s = [&](int in_unit, int w_unit, auto&& step) {
+    // nkb = 5: all tap pairs (the last one half empty); nkb = 4: taps 0..7 only -- tap 8 of this chunk shares a K block with
+    // tap 8 of its pair chunk (`straddle`)
+    auto mfma_chunk_hi2_s = [&](int in_unit, int w_unit, int nkb, auto&& step) {
         v8 ah[2][NCG], al[2][NCG], bv[2][kQG];
         const int hsel = vopaque(hi);
         load_a2b(0, hsel, in_unit, w_unit, ah[0], al[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < kKB; ++kb) {
-            if (kb + 1 < kKB) load_a2b(kb + 1, hsel, in_unit, w_unit, ah[(kb + 1) & 1], al[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            if (kb + 1 < kKB - 1 || (kb + 1 == kKB - 1 && nkb == kKB))
+                load_a2b(kb + 1, hsel, in_unit, w_unit, ah[(kb + 1) & 1], al[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            if (kb < kKB - 1 || nkb == kKB) {
 #pragma unroll
-            for (int g = 0; g < NCG; ++g)
+                for (int g = 0; g < NCG; ++g)
 #pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[kb & 1][g], bv[kb & 1][j], acc[g][j]);
+                    for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[kb & 1][g], bv[kb & 1][j], acc[g][j]);
 #pragma unroll
-            for (int g = 0; g < NCG; ++g)
+                for (int g = 0; g < NCG; ++g)
 #pragma unroll
-                for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[kb & 1][g], bv[kb & 1][j], acc[g][j]);
+                    for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[kb & 1][g], bv[kb & 1][j], acc[g][j]);
+            }
             step(kb);
         }
+    };
+    // The K block that removes the tenth tap half from the two hi-tile products of a PAIR of chunks: half-wave 0 multiplies tap 8
+    // of the chunk in buffer parity b, half-wave 1 tap 8 of the chunk in parity b ^ 1 (both hi tiles and both weight images are
+    // resident: they are double-buffered).  x_hi * (w_lo, w_hi).
+    auto straddle = [&](int b, int inu, int wu0, int wstride) {
+        const int hsel = vopaque(hi);
+        const int bb = hsel ? (b ^ 1) : b;
+        const int as = wu0 + bb * wstride + abase + 8 * BN, bs = bb * inu + bbase + 2 * Wp + 2;
+        v8 ah[NCG], al[NCG], bv[kQG];
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) {
+            ah[g] = *reinterpret_cast<const v8*>(smem + as + g * 32);
+            al[g] = *reinterpret_cast<const v8*>(smem + as + WUNITS + g * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < kQG; ++j) bv[j] = *reinterpret_cast<const v8*>(smem + bs + 32 * j);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(al[g], bv[j], acc[g][j]);
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+#pragma unroll
+            for (int j = 0; j < kQG; ++j) acc[g][j] = E::mfma(ah[g], bv[j], acc[g][j]);
     };
     auto zero_acc = [&]() {
 #pragma unroll
@@ -491,8 +520,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
         issue_in(src, in_plane(src, 0, false), 0);
         issue_w(src.wsrc, WU0, 2 * WPIECES, 0, kMaxW);
         issue_in(src, in_plane(src, 0, true), LOU);
-        // one chunk of the stream: multiply the chunk in buffer parity g & 1 while (cn, any) -- chunk cn of `src`, if any -- is staged
-        auto chunk = [&](int g, int cn, bool any) {
+        // one chunk of the stream: multiply the chunk in buffer parity g & 1 while (cn, any) -- chunk cn of `src`, if any -- is staged.
+        // mode 0: a chunk on its own (5 + 5 K blocks).  Chunks 2i and 2i + 1 of a tile form a PAIR whose hi-tile products skip the
+        // half-empty fifth K block: mode 1 (first of the pair) ends with the straddle block over both chunks' tap 8 -- by then the
+        // second chunk's hi tile and weights have landed, which is exactly the wait the second chunk would start with -- and mode 2
+        // (second) runs taps 0..7 only: 28 K-block products per pair instead of 30.
+        auto chunk = [&](int g, int cn, bool any, int mode) {
             const int b = g & 1;
             const uint4* nhi = any ? in_plane(src, cn, false) : nullptr;
             const uint4* nlo = any ? in_plane(src, cn, true) : nullptr;
@@ -507,8 +540,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
                 else if (kb == 2) issue_w(nws, nwu, 2 * WPIECES, (kMaxW + 1) / 2, kMaxW);
             });
             cbarrier();                                               // the lo tile is free
-            mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, [&](int kb) { if (kb == 0) issue_in(src, nlo, LOU); });   // x_hi * (w_lo, w_hi)
+            mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, mode == 0 ? kKB : kKB - 1,
+                             [&](int kb) { if (kb == 0) issue_in(src, nlo, LOU); });   // x_hi * (w_lo, w_hi)
+            if (mode == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pair chunk's tiles (issued during this chunk) have landed
+                cbarrier();
+                straddle(b, INU, WU0, 2 * WUNITS);
+            }
         };
+        auto mode_of = [&](int c) { return (c & 1) ? 2 : (c + 1 < nchunk ? 1 : 0); };
         int g = 0;
         // probe aid (ttc_debug_knob 2 / 3, tools/probes/h16_trace.py): thread 0 stamps s_memtime at the phase boundaries of the
         // workgroup's first 12 tiles -- [tile][0] start, [1] before the last chunk, [2] after it, [3] after the epilogue; slot 63 = HW ids
@@ -522,11 +562,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
         for (int tk = wslot;; ++ti) {
             if (TRACE && tr && ti < 12) tr[4 * ti] = __builtin_amdgcn_s_memtime();
             zero_acc();
-            for (int c = 0; c + 1 < nchunk; ++c, ++g) chunk(g, c + 1, true);
+            for (int c = 0; c + 1 < nchunk; ++c, ++g) chunk(g, c + 1, true, mode_of(c));
             const bool any = tk + nx < tcnt;                          // last chunk of this tile: stage chunk 0 of the next one
             if (any) src = src_of(tk + nx);
             if (TRACE && tr && ti < 12) tr[4 * ti + 1] = __builtin_amdgcn_s_memtime();
-            chunk(g, 0, any);
+            chunk(g, 0, any, (nchunk & 1) ? 0 : 2);
             ++g;
             if (TRACE && tr && ti < 12) tr[4 * ti + 2] = __builtin_amdgcn_s_memtime();
             epilogue(ep);                                             // no LDS: the next tile's first chunk is landing meanwhile
