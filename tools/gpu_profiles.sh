@@ -2,7 +2,9 @@
 # usage (GPU box, repo root): bash tools/gpu_profiles.sh <tag>   -> gpurun_out/<tag>_*: bench lines, rocprofv3 kernel stats, PMC passes.
 # Kernel-stats runs use --inflight 1 --no-dprob --no-alt --no-cpu-baseline so that a kernel's average is not a mix of live
 # (two tiles in flight), isolated, warm-up and 3-window parity launches.  PMC passes are their own runs (--kernel-trace --pmc only).
-TAG=${1:-r03_f}
+# ONLY=<section>[,<section>] restricts the run to stats | pmc_f32 | pmc_h16 | pmc_pre | bench.
+TAG=${1:-r03_g}
+want() { [ -z "$ONLY" ] || [[ ",$ONLY," == *",$1,"* ]]; }
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -13,9 +15,11 @@ prof() {  # name, bench args...
     (cd $R && python tools/rocpd_stats.py $f > $O/${TAG}_${name}_kernel_stats.md)
     rm -rf $O/prof_${TAG}_$name
 }
+if want stats; then
 prof fp32 --inflight 1 --no-dprob --no-alt --no-cpu-baseline --steps 10
 prof fp16 --precision fp16 --inflight 1 --no-dprob --no-alt --no-cpu-baseline --steps 10
 prof preprocess --preprocess-only --tiles 64 --inflight 1 --no-cpu-baseline
+fi
 cd $R
 pmc() {  # out-file, kernel substring(s) separated by |, counters, command...
     local out=$1 subs=$2 cnt=$3; shift 3
@@ -28,12 +32,13 @@ pmc() {  # out-file, kernel substring(s) separated by |, counters, command...
     rm -rf gpurun_out/pmc_$t
 }
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
-    pmc $O/${TAG}_pmc_f32_gates.txt "conv3x3_f32<10, 2, 0" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
-    pmc $O/${TAG}_pmc_h16_gates.txt "conv3x3_h16<0, 3, 2, 0, 1>|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
+    want pmc_f32 && pmc $O/${TAG}_pmc_f32_gates.txt "conv3x3_f32<10, 2, 0" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
+    want pmc_h16 && pmc $O/${TAG}_pmc_h16_gates.txt "conv3x3_h16<0, 3, 2, 0, 1|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-    pmc $O/${TAG}_pmc_preprocess.txt "k_hist_all|k_tile_temporal|k_stat_all|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
+    want pmc_pre && pmc $O/${TAG}_pmc_preprocess.txt "k_hist_all|k_tile_temporal|k_stat_all|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
 done
+want bench || exit 0
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --precision fp16 --no-cpu-baseline --no-alt > $O/${TAG}_bench_fp16.json 2>> $O/${TAG}_bench.err
 python bench.py --preprocess-only --tiles 256 --no-cpu-baseline > $O/${TAG}_bench_preprocess_only.json 2>> $O/${TAG}_bench.err
