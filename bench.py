@@ -84,7 +84,9 @@ def roofline(precision, win, n_windows, gates_ms, gates_n):
     # 16-bit engines: ALGORITHMIC flops against the dense 16-bit MFMA peak; the three split products and the K padding
     # (49 -> 56 channels, 9 -> 10 tap halves) that the kernel actually issues are reported beside it
     nbytes = 2.0 * n_windows * (56 * (win + 2) ** 2 * 4 + 64 * win * (win + 2) * 4)          # hi+lo blocked input planes + fp32 raw output
-    issued = 3.0 * flops * (56.0 / 49) * (10.0 / 9)
+    # 7 chunks = 3 chunk pairs (28 K-block products each: tap 8 of the two hi-tile products shares a K block) + 1 single (15),
+    # against 3 x 9 / 2 = 13.5 per chunk without any padding
+    issued = 3.0 * flops * (56.0 / 49) * (10.0 / 9) * (99.0 / 105)
     return {"kernel": "conv3x3_h16<TERMS=3,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)", "bound": "mfma", "achieved": ach,
             "peak": H16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / H16_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": src,
             "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops,
