@@ -464,6 +464,60 @@ def predict_tile_raw_checked(raw, mask, sess, size=SIZE, to_host=True, sampler="
     return (f32, u8, st, staged) if want_status else (f32, u8)
 
 
+def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, want_status=False, depth=None):
+    """The job's TILE LOOP (job.py:1869-2091 processes one tile after the other) over a sequence of tiles, pipelined on one GPU:
+    `sessions` = 1 .. K TTCSession of the same device; tile k is enqueued on session k % K, each session on its own HIP stream,
+    with ONE ttc_predict_tile call and no host wait, so K tiles are in flight (bench.py: two saturate an MI355X -- one tile's
+    latency-bound preprocessing runs under the other's convolutions).  A tile's status words are read only when the pipeline
+    is `depth` (default 2 K) tiles ahead; a tile they flag is re-run through the staged mirror exactly like
+    predict_tile_raw_checked does, on its own session, before its result is returned.
+
+    tiles: iterable of (raw, mask) as predict_tile_raw_checked takes them (may be a generator that loads files lazily:
+    at most `depth` tiles are resident).  -> list of (float32 percent raster, uint8 product[, status int32[4], staged]) in
+    input order, numpy with to_host else cuda tensors."""
+    from collections import deque
+    sessions = list(sessions)
+    if not sessions:
+        raise ValueError("predict_tiles needs at least one session")
+    t = sessions[0].ctx.torch
+    dev = sessions[0].ctx.device
+    if any(sx.ctx.device != dev for sx in sessions):
+        raise ValueError("predict_tiles: every session must live on the same device (shard tiles across ranks with shard.py)")
+    streams = [t.cuda.Stream(device=dev) for _ in sessions]
+    depth = int(depth) if depth else 2 * len(sessions)
+    pending, results = deque(), []
+
+    def finish():
+        k, raw, mask, u8, f32, status = pending.popleft()
+        sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
+        with t.cuda.stream(st):
+            words = status.cpu().numpy()                                      # waits for this tile's stream only
+            staged = bool(words[0] or words[2] or words[3])
+            if staged:
+                s2, dates, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None, clm=None), sess, sampler=sampler, cloudshad=mask)
+                sess.ctx.superresolve_tile(s2, quirks=True)
+                f32, u8 = predict_tile(s2, dates, interp, s1, dem, sess, size=size, to_host=False)
+            if to_host:
+                f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
+            else:
+                st.synchronize()
+        results.append((f32, u8, words, staged) if want_status else (f32, u8))
+
+    for k, (raw, mask) in enumerate(tiles):
+        sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
+        ctx = sess.ctx
+        with t.cuda.stream(st):
+            dem90 = ctx.divide(ctx.median5(np.ascontiguousarray(raw["dem"], dtype=np.float32)), 90.0)      # job.py:713, :993
+            u8, f32, _, status = ctx.predict_tile_raw(raw["s2_10"], raw["s2_20"], raw["s1"], dem90, mask, raw["dates"], min_all, max_all,
+                                                      size, want_float=True)
+        pending.append((k, raw, mask, u8, f32, status))
+        if len(pending) > depth:
+            finish()
+    while pending:
+        finish()
+    return results
+
+
 def write_tif(arr, point, x, y, out_folder, suffix="_FINAL"):
     """src/downloading/io.py:229-263 without rasterio: arr [X, Y] (any dtype castable to uint8) is transposed like there and
     written as `{out_folder}{x}X{y}Y{suffix}.tif` -- LZW GeoTIFF, EPSG:4326, bounds point = [west, south, east, north]."""

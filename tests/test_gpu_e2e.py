@@ -185,3 +185,31 @@ def test_status_words_and_checked_wrapper(case, word, bit):
     d8 = np.abs(u8.astype(int) - ref["u8"].astype(int))
     print(f"[parity] status words, {case}: percent raster max|d| = {d.max():.3f}, uint8 > 1 count: {(d8 > 1).mean():.2e}")
     assert d.max() <= 0.15 and (d8 > 1).mean() < 1e-4
+
+
+def test_predict_tiles_pipeline_matches_per_tile_calls():
+    """job.predict_tiles (the tile loop of job.py:1869-2091, K tiles in flight on K sessions / HIP streams, status words read
+    late, flagged tiles re-run through the staged mirror) returns, in input order, what predict_tile_raw_checked returns for
+    each tile on its own -- for clean AND flagged tiles, with the pipeline deeper than the number of sessions."""
+    from ttc import job, weights as Wt
+    w = Wt.synth_weights(0)
+    cases = ["clean", "unalignable_date", "clean", "fully_interpolated_date", "half_missing_date", "clean", "clean"]
+    tiles = []
+    for k, case in enumerate(cases):
+        raw, mask = small_raw(60 + k)
+        tiles.append(force(case, raw, mask))
+    sessions = [job.TTCSession(w, win_in=44, length=4, max_windows=36) for _ in range(2)]
+    got = job.predict_tiles(((dict(r), m.copy()) for r, m in tiles), sessions, size=30, want_status=True)
+    assert len(got) == len(tiles)
+    solo = job.TTCSession(w, win_in=44, length=4, max_windows=36)
+    n_staged = 0
+    for k, ((raw, mask), (f32, u8, st, staged)) in enumerate(zip(tiles, got)):
+        rf, ru, rst, rstaged = job.predict_tile_raw_checked(dict(raw), mask.copy(), solo, size=30, want_status=True)
+        assert staged == rstaged == (cases[k] != "clean") and np.array_equal(st, rst), (k, cases[k], st, rst)
+        assert np.array_equal(np.isnan(f32), np.isnan(rf))
+        d8 = np.abs(u8.astype(int) - ru.astype(int))
+        assert d8.max() <= 1 and (d8 > 0).mean() < 1e-3, (k, cases[k], d8.max(), (d8 > 0).mean())
+        n_staged += staged
+    print(f"[parity] predict_tiles: {len(tiles)} tiles on 2 sessions, {n_staged} re-run through the staged path, order and rasters match")
+    for sx in sessions + [solo]:
+        sx.close()
