@@ -4,7 +4,7 @@
     python bench.py --preprocess-only --tiles 256          # BASELINE configs[2] as its own headline line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" = `--inflight` (default 2) synthetic 618x618 tiles per GPU, each resident in HBM as the job stores it (uint16 bands,
+A "step" = `--inflight` (default 3) synthetic 618x618 tiles per GPU, each resident in HBM as the job stores it (uint16 bands,
 cloud / shadow mask, DEM) and each pushed through the WHOLE built hot path by ONE C-ABI call (ttc_predict_tile, no host round
 trip) on its own HIP stream and context:
 
@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--precision", choices=list(DTYPES), default="fp32",
                     help="conv engines: exact fp32 MFMA chains (BASELINE configs[1], default) or fp16 / bf16 hi+lo operand pairs on the "
                          "16-bit engine (configs[4] / [3])")
-    ap.add_argument("--inflight", type=int, default=2, help="tiles in flight per GPU per step, each on its own HIP stream + context")
+    ap.add_argument("--inflight", type=int, default=3, help="tiles in flight per GPU per step, each on its own HIP stream + context")
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic tiles per rank, visited round-robin")
     ap.add_argument("--gather-batch", type=int, default=64, help="finished rasters per RCCL gather (N > 1)")
     ap.add_argument("--detect", action="store_true",
