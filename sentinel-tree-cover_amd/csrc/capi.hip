@@ -262,6 +262,7 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
         TTC_CHECK(clouds_identify(c, s2, T, X, Y, d_dem_m, nullptr, nullptr, nullptr, clouds, fcps, 0, s));
         mask = clouds; pf = fcps;
     }
+    c->want_planar_frames = d_model_in != nullptr;
     c->spec_status = d_status;                     // the speculative stages report into it instead of waiting for the host
     // cloud_removal.py:888-973; with spec_status set the blend also applies process_tile's final np.clip(sentinel2, 0, 1) (job.py:993)
     ttc_status st = gapfill_remove_clouds(c, s2, mask, pf, T, X, Y, nullptr, nullptr, interp, nullptr, nullptr, nullptr, s);
@@ -269,6 +270,7 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
     if (st == TTC_OK) st = tile_process_subtiles_dev(c, s2, T, X, Y, d_dates, interp, s1db, d_dem, h_min, h_max, size, windows, windows_raw,
                                                      inputs_only, s);                                                         // job.py:1125-1483
     c->spec_status = nullptr;
+    c->want_planar_frames = false;
     TTC_CHECK(st);
     if (d_model_in) {
         const size_t nfl = (size_t)n_win * (c->cfg.length + 1) * c->cfg.n_bands * (c->cfg.win_in + 2) * (c->cfg.win_in + 2);

@@ -756,6 +756,7 @@ ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStrea
     const Geo g(c->cfg);
     KTimer kt(c, "frames_from_nhwc", s);
     dim3 grid((g.y.np * g.x.np + 255) / 256, g.L + 1, n);
+    c->frames16_ready = false;                   // fp32 planar frames: forward_h16 converts them
     hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.y.n, g.x.n, c->cfg.n_bands, g.tr ? 1 : 0);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
@@ -798,8 +799,11 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
     const int nblk_full = conv_stat_slots(Hp, Wp);
 
-    // frames (written fp32 planar by the window assembly) -> channel-blocked hi / lo
-    {
+    // frames (fp32 planar from the NHWC entry points / the border assembly) -> channel-blocked hi / lo; the tile path's window
+    // assembly writes the blocked form itself (tile.hip k_assemble)
+    const bool have16 = c->frames16_ready;
+    c->frames16_ready = false;
+    if (!have16) {
         KTimer kt(c, "frames_to_b16", s);
         hipLaunchKernelGGL((k_planar_to_b16<BF>), dim3((unsigned)((PP + 255) / 256), N * (g.L + 1)), dim3(256), 0, s, c->frames,
                            Cx, PP, Cx8, c->frames16.hi, c->frames16.lo);

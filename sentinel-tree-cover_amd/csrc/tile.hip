@@ -17,6 +17,7 @@
 // Tile arrays arrive in the reference's layout ([T, X, Y, C] float32); intermediates are planar
 // [C][X][Y] so that every later access is coalesced along Y.
 #include "ttc_internal.h"
+#include "h16_common.h"
 
 namespace {
 
@@ -308,11 +309,14 @@ __global__ void k_tile_s1(const float* __restrict__ s1, int npix, int L, float* 
     }
 }
 
-// window assembly straight into the padded planar frame buffer of the model
+// window assembly straight into the model's padded frame buffer: fp32 planar [win][L+1][17][PP] (BF < 0), or -- for the 16-bit
+// conv engine -- its channel-blocked hi / lo pairs [win][L+1][3][PP][8] (BF = 0 fp16, 1 bf16; channels 17..23 zero), which saves
+// the planar round trip and the conversion pass
+template <int BF>
 __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ sm, const float* __restrict__ med,
                                                   const float* __restrict__ s1q, const float* __restrict__ s1med,
                                                   const float* __restrict__ dem, WinTable wt, Norm nm, int X, int Y,
-                                                  int W, int L, float* __restrict__ frames) {
+                                                  int W, int L, float* __restrict__ frames, uint4* __restrict__ fhi, uint4* __restrict__ flo) {
 #pragma clang fp contract(off)
     const int Wp = W + 2, PP = Wp * Wp;
     const int f = blockIdx.y, wi = blockIdx.z;
@@ -322,25 +326,40 @@ __global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ sm, 
     int lx = py - 1, ly = pxx - 1;
     const bool border = lx < 0 || lx >= W || ly < 0 || ly >= W;
     const bool last = (f == L);
-    float* dst = frames + (((long)wi * (L + 1) + f) * 17) * PP + p;
-    if (last && border) {
-        for (int c = 0; c < 17; ++c) dst[(long)c * PP] = 0.0f;
-        return;
-    }
-    lx = reflect_idx(lx, W); ly = reflect_idx(ly, W);        // ConvGRU reflect pad (model.py:250)
-    const WinDesc& w = wt.w[wi];
-    const int tx = win_to_tile(lx, w.sx, w.lx, w.fx), ty = win_to_tile(ly, w.sy, w.ly, w.fy);
-    const long npix = (long)X * Y, tp = (long)tx * Y + ty;
-    for (int c = 0; c < 17; ++c) {
-        float v;
-        if (c == 10) v = dem[tp];
-        else if (c == 11 || c == 12) v = last ? s1med[(c - 11) * npix + tp] : s1q[(2L * f + (c - 11)) * npix + tp];
-        else {
-            const int ch = c < 10 ? c : c - 3;               // 13..16 -> smoothed / median index 10..13
-            v = last ? med[ch * npix + tp] : sm[((long)f * 14 + ch) * npix + tp];
+    const long img = (long)wi * (L + 1) + f;
+    float* dst = BF < 0 ? frames + (img * 17) * PP + p : nullptr;
+    float o[24];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) o[c] = 0.0f;
+    if (!(last && border)) {
+        lx = reflect_idx(lx, W); ly = reflect_idx(ly, W);        // ConvGRU reflect pad (model.py:250)
+        const WinDesc& w = wt.w[wi];
+        const int tx = win_to_tile(lx, w.sx, w.lx, w.fx), ty = win_to_tile(ly, w.sy, w.ly, w.fy);
+        const long npix = (long)X * Y, tp = (long)tx * Y + ty;
+#pragma unroll
+        for (int c = 0; c < 17; ++c) {
+            float v;
+            if (c == 10) v = dem[tp];
+            else if (c == 11 || c == 12) v = last ? s1med[(c - 11) * npix + tp] : s1q[(2L * f + (c - 11)) * npix + tp];
+            else {
+                const int ch = c < 10 ? c : c - 3;               // 13..16 -> smoothed / median index 10..13
+                v = last ? med[ch * npix + tp] : sm[((long)f * 14 + ch) * npix + tp];
+            }
+            v = fminf(fmaxf(v, nm.lo[c]), nm.hi[c]);             // normalize_subtile, job.py:316-325 (float32)
+            o[c] = (v - nm.mid[c]) / nm.half[c];
         }
-        v = fminf(fmaxf(v, nm.lo[c]), nm.hi[c]);             // normalize_subtile, job.py:316-325 (float32)
-        dst[(long)c * PP] = (v - nm.mid[c]) / nm.half[c];
+    }
+    if constexpr (BF < 0) {
+#pragma unroll
+        for (int c = 0; c < 17; ++c) dst[(long)c * PP] = o[c];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] = o[8 * k + j];
+            b16_store8<BF>(fhi, flo, (img * 3 + k) * PP + p, v8);
+        }
     }
 }
 
@@ -822,8 +841,14 @@ static ttc_status tile_core(ttc_ctx* c, const float* d_s2, int T, int X, int Y, 
       TTC_HIP(c, hipGetLastError()); }
     const int PP = (W + 2) * (W + 2);
     { KTimer kt(c, "assemble", s);
-      hipLaunchKernelGGL(k_assemble, dim3((PP + 255) / 256, L + 1, wt.n), dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm,
-                         X, Y, W, L, c->frames);
+      const dim3 ag((PP + 255) / 256, L + 1, wt.n);
+      // 16-bit engine: the blocked pairs directly, unless somebody wants to see the fp32 frames (model feed output, debug keep)
+      const bool blocked = c->half() && !c->want_planar_frames && !c->keep_debug && (c->cfg.win_rows == 0 || c->cfg.win_rows == c->cfg.win_in) && c->cfg.n_bands == 17;
+      if (!blocked) hipLaunchKernelGGL(k_assemble<-1>, ag, dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm, X, Y, W, L, c->frames, nullptr, nullptr);
+      else if (c->blk_mode() == 1) hipLaunchKernelGGL(k_assemble<1>, ag, dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm, X, Y, W, L, nullptr,
+                                                      c->frames16.hi, c->frames16.lo);
+      else hipLaunchKernelGGL(k_assemble<0>, ag, dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm, X, Y, W, L, nullptr, c->frames16.hi, c->frames16.lo);
+      c->frames16_ready = blocked;
       TTC_HIP(c, hipGetLastError()); }
     if (stop_after_inputs) return TTC_OK;
     { KTimer kt(c, "bright", s);

@@ -192,6 +192,8 @@ struct ttc_ctx {
     int* spec_status = nullptr;   // single-call tile path: device int32[4] the speculative stages report into (see ttc_predict_tile)
     unsigned wmat_slot = 0;       // ring index of the host-built temporal operator (tile.hip)
     std::vector<hipEvent_t> wmat_events;   // per ring slot: the H2D copy that last read it
+    bool want_planar_frames = false;   // the caller asked for the model feed (ttc_predict_tile d_model_in): keep the fp32 planar frames
+    bool frames16_ready = false;       // the window assembly wrote the 16-bit engine's blocked hi / lo frames itself (tile.hip)
     bool minv_ready = false;      // the constant Whittaker matrix has been uploaded (tile.hip)
 
     Timing timing;

@@ -378,7 +378,7 @@ def test_bench_two_ranks_on_one_gpu():
     from tests.helpers import ROOT
     env = dict(os.environ, TTC_BENCH_BACKEND="gloo", TTC_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pool", "2",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--inflight", "2", "--steps", "2", "--warmup", "1", "--pool", "2",
            "--gather-batch", "2", "--no-cpu-baseline", "--no-dprob", "--no-alt"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
