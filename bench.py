@@ -365,7 +365,7 @@ def main():
     dt, gates_ms, gates_n, bad = measure(sessions, args.steps, args.warmup)
     iso_ms = isolated_gates(sessions[0]) if (args.inflight > 1 and rank == 0) else None
     ref, cpu = None, None
-    if rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:           # the CPU oracle pass (cpu_baseline + the e2e reference): N = 1 only
         ref, cpu = oracle_pass(args, host_tile, weights)
     dprob = max_dprob(sessions[0]) if (rank == 0 and not args.no_dprob) else None
     e2e = {args.precision: dprob_e2e(sessions[0], ref)} if (rank == 0 and not args.no_dprob) else {}
