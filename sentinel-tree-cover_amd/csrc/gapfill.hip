@@ -1369,7 +1369,8 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
         GF_T(k_ref_all, T, dim3(2048), blk, 0, s, d_tiles, d_w, water, T, npix, ref_all, vmask, count);
         hipLaunchKernelGGL(k_sel_init_dates, dim3((T * 20 + 63) / 64), dim3(64), 0, s, st, count, T);
         for (int shift = 24; shift >= 0; shift -= 8) {
-            hipLaunchKernelGGL(k_hist_all, dim3(64, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, shift, hist);
+            // 128 x T workgroups: measured 64 / 128 / 256 / 512 -> 3.58 / 3.47 / 3.51 / 3.66 ms per tile for the whole preprocessing chain
+            hipLaunchKernelGGL(k_hist_all, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, shift, hist);
             hipLaunchKernelGGL(k_sel_pick, dim3(T * 20), dim3(64), 0, s, st, shift, hist);
         }
         hipLaunchKernelGGL(k_stat_init, dim3(1), dim3(kMaxT * 20), 0, s, cs);
