@@ -355,12 +355,14 @@ ttc_status ttc_s1_to_db(ttc_ctx* ctx, const uint16_t* d_u16, int32_t T, int32_t 
 
 /* ---- on-disk formats (host code, no GPU) ----------------------------------------------------------------------------------
  * hkl.load(path) for the numeric arrays of temp/raw (src/download_and_predict_job.py:684-714; written at :462-463, :592-633
- * with hkl.dump(..., compression='gzip')): reads dataset `name` of the HDF5 file's root group (NULL = hickle's "data", then
- * "data_0", then the first dataset) into h_out (raw little-endian elements, C order).  Supported: the layout h5py's default
- * format produces -- superblock v0/v1, old-style groups, object headers v1, contiguous or chunked (B-tree v1) storage,
- * deflate and shuffle filters.  h_out may be NULL to query shape[<= 8] / ndim / elem_size / type_class (0 integer, 1 float) /
- * is_signed only.  ttc_read_hkl_error() returns the message of the last failure.  Parity with files written by real hickle is
- * unpinned in this repository (no sample, no HDF5 library in the build image): see DESIGN.md. */
+ * with hkl.dump(..., compression='gzip')): reads the dataset at `name`, a '/'-separated path from the root ("data",
+ * "data/data_1"); NULL = what hkl.load returns first: hickle 4/5's "data", then hickle 3's "data_0", then the first dataset,
+ * descending into container groups (a dumped list of arrays is a group of data_i datasets) -- into h_out (raw little-endian
+ * elements, C order).  Supported: the layout h5py's default format produces -- superblock v0/v1, old-style groups, object
+ * headers v1 (attributes skipped), contiguous or chunked (B-tree v1) storage, deflate and shuffle filters.  h_out may be NULL to
+ * query shape[<= 8] / ndim / elem_size / type_class (0 integer, 1 float) / is_signed only.  ttc_read_hkl_error() returns the
+ * message of the last failure.  Pinned against files written by h5py 3.3.0 / HDF5 1.10.6 in hickle's layouts
+ * (tests/golden/hkl, tools/gen_golden_hkl.py); hickle itself is not installed in the build image. */
 ttc_status ttc_read_hkl(const char* path, const char* name, void* h_out, size_t cap_bytes, int64_t* shape, int32_t* ndim,
                         int32_t* elem_size, int32_t* type_class, int32_t* is_signed);
 const char* ttc_read_hkl_error(void);

@@ -552,9 +552,23 @@ def mosaic_features(windows: dict, size, depth):
 
 
 def resize_bilinear(img, shape):
-    """skimage.transform.resize(img, shape, order=1) as skimage >= 0.19 evaluates it for
-    upsampling: scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) in float64.
-    (job.py:741-743, :759-781.)  PARITY UNPINNED vs skimage itself (absent here)."""
+    """skimage.transform.resize(img, shape, order=1) with scikit-image's defaults (mode='reflect',
+    anti_aliasing=True), as the reference calls it (job.py:741-743, :759-781; resegment_tiles_wide.py:1190-1236,
+    :1354-1355):
+      1. anti-aliasing: along every axis that SHRINKS (factor f = n_in / n_out > 1) the image is first smoothed with a
+         Gaussian of sigma = (f - 1) / 2 (scipy.ndimage.gaussian_filter, truncate 4, numpy-pad 'reflect' == ndimage
+         'mirror' borders), in the dtype of the input; axes that grow or keep their size get sigma 0 (no filter);
+      2. bilinear sampling at pixel-centre aligned coordinates f * (i + 0.5) - 0.5 with mirrored edge samples
+         == scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) in float64.
+    PINNED (round 4) against the real scikit-image 0.18.3 on the reference's own shapes: tests/golden/resize.npz
+    (tools/gen_golden_resize.py, run with /opt/conda/bin/python3.9)."""
+    img = np.asarray(img)
+    if img.dtype.kind != 'f':
+        img = img.astype(np.float64)
+    factors = [i / o for o, i in zip(shape, img.shape)]
+    sigma = [max(0.0, (f - 1.0) / 2.0) for f in factors]
+    if any(s > 0 for s in sigma):
+        img = ndi.gaussian_filter(img, sigma, mode='mirror')
     zoom = [o / i for o, i in zip(shape, img.shape)]
     return ndi.zoom(img.astype(np.float64), zoom, order=1, mode='mirror', grid_mode=True)
 

@@ -7,9 +7,10 @@
 //     chunk B-tree v1, type 1), filter pipeline v1 (deflate = 1, shuffle = 2)
 // This file parses exactly that subset of the HDF5 file format (HDF5 File Format Specification 2.0/3.0: III.A superblock,
 // III.A.1 B-trees v1, III.C symbol-table nodes, III.D local heaps, IV.A.1.a object header v1, IV.A.2 messages) on the host,
-// inflating chunks with zlib.  No HDF5 / hickle / h5py exists in the build image and the checkout holds no .hkl sample, so the
-// parser is exercised against files that tools/write_hdf5_fixture.py lays out byte by byte from the same specification:
-// PARITY WITH REAL hickle FILES IS UNPINNED until a sample exists.
+// inflating chunks with zlib.  PINNED (round 4): tests/golden/hkl/*.hkl are written by the real h5py 3.3.0 / libhdf5 1.10.6
+// in the layouts hickle 3.4, 4 and 5 produce (tools/gen_golden_hkl.py, run with /opt/conda/bin/python3.9: root arrays, container
+// groups, attributes, gzip with and without shuffle, contiguous int64 date lists).  hickle itself is not installed anywhere in the
+// image; tools/write_hdf5_fixture.py (a byte-level writer from the same specification) is kept for the malformed-file tests.
 #include <zlib.h>
 
 #include <cstdio>
@@ -218,6 +219,44 @@ bool read_chunks(const File& f, const Dataset& d, uint8_t* out, std::string& err
     return true;
 }
 
+// links of the group whose object header is at `oh` (is_group = false and no error when the object is not an old-style group)
+bool group_links(const File& f, uint64_t oh, std::vector<std::pair<std::string, uint64_t>>& links, bool& is_group, std::string& err) {
+    std::vector<Msg> msgs;
+    is_group = false;
+    if (!read_header(f, oh, msgs, err)) return false;
+    for (const Msg& m : msgs)
+        if (m.type == 0x11) {
+            is_group = true;
+            return list_group(f, f.u(m.off, 8), f.u(m.off + 8, 8), links, err);
+        }
+    return true;
+}
+
+// What hkl.load hands back first for the object at `oh`: the object itself when it is a dataset; for a group (the file root, or
+// the container group hickle writes for a list / tuple / dict: `data` in hickle 4 / 5, `data_0` in hickle 3, children `data_i`)
+// the member "data", else "data_0", else the first member that resolves, descended the same way.
+bool default_dataset(const File& f, uint64_t oh, int depth, uint64_t& out, std::string& err) {
+    if (depth > 8) { err = "groups nested deeper than 8 levels"; return false; }
+    std::vector<std::pair<std::string, uint64_t>> links;
+    bool is_group = false;
+    if (!group_links(f, oh, links, is_group, err)) return false;
+    if (!is_group) {
+        Dataset t;
+        if (!parse_dataset(f, oh, t, err)) return false;
+        out = oh;
+        return true;
+    }
+    for (const char* w : {"data", "data_0"})
+        for (auto& l : links)
+            if (l.first == w) return default_dataset(f, l.second, depth + 1, out, err);
+    for (auto& l : links) {
+        std::string e2;
+        if (default_dataset(f, l.second, depth + 1, out, e2)) return true;
+    }
+    err = "group without a dataset";
+    return false;
+}
+
 thread_local std::string g_hkl_err;     // per thread: loaders may read files concurrently
 
 }  // namespace
@@ -226,7 +265,8 @@ extern "C" {
 
 const char* ttc_read_hkl_error(void) { return g_hkl_err.c_str(); }
 
-// name: dataset in the root group; NULL = hickle's ("data", then "data_0", then the first dataset found).
+// name: '/'-separated path from the root ("data", "data/data_1"); NULL = what hkl.load returns first: "data", then "data_0", then
+// the first dataset found, descending into container groups (hickle writes a list of arrays as a group of data_i datasets).
 // h_out may be NULL (query shape / type only); cap_bytes = its capacity.
 ttc_status ttc_read_hkl(const char* path, const char* name, void* h_out, size_t cap_bytes, int64_t* shape, int32_t* ndim,
                         int32_t* elem_size, int32_t* type_class, int32_t* is_signed) {
@@ -252,24 +292,32 @@ ttc_status ttc_read_hkl(const char* path, const char* name, void* h_out, size_t 
     const uint64_t root_entry = 24 + (sver == 1 ? 4 : 0) + 32;      // after base / free-space / EOF / driver addresses
     const uint64_t root_oh = f.u(root_entry + 8, 8);
     std::string err;
-    std::vector<Msg> msgs;
-    if (!read_header(f, root_oh, msgs, err)) return fail(TTC_ERR_ARG, "read_hkl: root group: " + err);
-    uint64_t btree = kUndef, heap = kUndef;
-    for (const Msg& m : msgs) if (m.type == 0x11) { btree = f.u(m.off, 8); heap = f.u(m.off + 8, 8); }
-    if (btree == kUndef) return fail(TTC_ERR_ARG, "read_hkl: the root group has no symbol table (new-style group?)");
-    std::vector<std::pair<std::string, uint64_t>> links;
-    if (!list_group(f, btree, heap, links, err)) return fail(TTC_ERR_ARG, "read_hkl: " + err);
     uint64_t oh = kUndef;
-    const char* wanted[3] = {name, name ? nullptr : "data", name ? nullptr : "data_0"};
-    for (const char* w : wanted) {
-        if (!w || oh != kUndef) continue;
-        for (auto& l : links) if (l.first == w) oh = l.second;
+    if (name && *name) {                                             // explicit path from the root: "data", "data/data_1", ...
+        oh = root_oh;
+        std::string rest(name);
+        while (!rest.empty() && oh != kUndef) {
+            const size_t cut = rest.find('/');
+            const std::string part = rest.substr(0, cut);
+            rest = cut == std::string::npos ? std::string() : rest.substr(cut + 1);
+            if (part.empty()) continue;
+            std::vector<std::pair<std::string, uint64_t>> links;
+            bool is_group = false;
+            if (!group_links(f, oh, links, is_group, err)) return fail(TTC_ERR_ARG, "read_hkl: " + err);
+            uint64_t next = kUndef;
+            if (is_group) for (auto& l : links) if (l.first == part) next = l.second;
+            oh = next;
+        }
+        if (oh != kUndef && !default_dataset(f, oh, 0, oh, err)) oh = kUndef;   // a path that names a container: its first array
+    } else {
+        bool is_group = false;
+        std::vector<std::pair<std::string, uint64_t>> links;
+        if (!group_links(f, root_oh, links, is_group, err)) return fail(TTC_ERR_ARG, "read_hkl: root group: " + err);
+        if (!is_group) return fail(TTC_ERR_ARG, "read_hkl: the root group has no symbol table (new-style group?)");
+        if (!default_dataset(f, root_oh, 0, oh, err)) oh = kUndef;
     }
     Dataset d;
-    if (oh == kUndef && !name) {                                     // first link that is a dataset
-        for (auto& l : links) { Dataset t; std::string e2; if (parse_dataset(f, l.second, t, e2)) { oh = l.second; break; } }
-    }
-    if (oh == kUndef) return fail(TTC_ERR_ARG, std::string("read_hkl: dataset not found: ") + (name ? name : "data / data_0"));
+    if (oh == kUndef) return fail(TTC_ERR_ARG, std::string("read_hkl: dataset not found: ") + (name && *name ? name : "data / data_0") + (err.empty() ? "" : " (" + err + ")"));
     if (!parse_dataset(f, oh, d, err)) return fail(TTC_ERR_ARG, "read_hkl: " + err);
     *ndim = d.rank; *elem_size = d.esize; *type_class = d.tclass; *is_signed = d.is_signed;
     uint64_t total = (uint64_t)d.esize;

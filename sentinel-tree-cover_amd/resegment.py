@@ -158,11 +158,16 @@ _KINDS = {"n": 0, "l": 1, "r": 2, "u": 3, "d": 4}
 
 
 def _resize(img, shape):
-    """What the reference asks of skimage.transform.resize(img, shape, order=1): bilinear, pixel-centre aligned, edge
-    samples mirrored (skimage >= 0.19 hands this to scipy.ndimage.zoom(grid_mode=True, mode='mirror')).  Host-side table
-    preparation only -- the tables are uploaded once per tile shape."""
+    """What the reference asks of skimage.transform.resize(img, shape, order=1) with scikit-image's defaults: along every
+    axis that shrinks by f = n_in / n_out > 1 a Gaussian anti-aliasing prefilter of sigma = (f - 1) / 2 (mirrored borders),
+    then bilinear, pixel-centre aligned sampling with mirrored edge samples.  Checked against scikit-image 0.18.3 on the
+    reference's table shapes (tests/golden/resize.npz).  Host-side table preparation only -- the tables are uploaded once
+    per tile shape."""
     from scipy import ndimage
     img = np.asarray(img, dtype=np.float64)
+    sigma = [max(0.0, (i / o - 1.0) / 2.0) for o, i in zip(shape, img.shape)]
+    if any(s > 0 for s in sigma):
+        img = ndimage.gaussian_filter(img, sigma, mode="mirror")
     return ndimage.zoom(img, [o / i for o, i in zip(shape, img.shape)], order=1, mode="mirror", grid_mode=True)
 
 

@@ -135,3 +135,31 @@ def test_feature_mosaic_matches_reference():
     assert got.shape == g["mosaic"].shape and got.dtype == np.int16
     d = np.abs(got.astype(int) - g["mosaic"].astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 1e-2, (d.max(), (d > 0).mean())     # float32 summation follows os.listdir order
+
+
+def test_resize_matches_real_skimage():
+    """oracle.resize_bilinear and the package's table builder (resegment._resize) against skimage.transform.resize(order=1) of the REAL
+    scikit-image 0.18.3 on the shapes of job.py:741-781 (20 m -> 10 m, float32) and resegment_tiles_wide.py:1190-1236, :1354-1355
+    (border-mosaic weight tables, float64, incl. the anti-aliased downsampling).  Float64 tables: 1e-12 (measured <= 1.3e-13).
+    Float32 bands: skimage 0.18's warp evaluates coordinates and weights in float32 -- 1 ulp on the x2 grids (measured 6e-8) and
+    1.4e-5 on the odd-grid 154 -> 617 branch (x4.006: a float32 coordinate near 150 carries 1.5e-5); scikit-image >= 0.19
+    (what the reference's python3.11 Dockerfile installs) evaluates in float64 like the oracle."""
+    import importlib
+    RS = importlib.import_module("sentinel-tree-cover_amd.resegment")
+    g = golden("resize.npz")
+    assert str(g["skimage_version"]) == "0.18.3"
+    worst32, worst64 = 0.0, 0.0
+    for k in range(int(g["n"])):
+        a, shape, want = g[f"in_{k}"], tuple(int(v) for v in g[f"shape_{k}"]), g[f"out_{k}"]
+        got = O.resize_bilinear(a, shape)
+        assert got.shape == want.shape
+        e = float(np.abs(got - want).max())
+        if a.dtype == np.float32:
+            x2 = shape[0] == 2 * a.shape[0]
+            assert e < (1.5e-7 if x2 else 2e-5), (k, e)
+            worst32 = max(worst32, e)
+        else:
+            assert e < 1e-12, (k, e)
+            assert float(np.abs(RS._resize(a, shape) - want).max()) < 1e-12, k
+            worst64 = max(worst64, e)
+    print(f"resize vs scikit-image 0.18.3: float32 bands {worst32:.2e}, float64 tables {worst64:.2e}")

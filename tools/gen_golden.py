@@ -25,7 +25,7 @@ import ref_harness  # noqa: E402
 
 synth = importlib.import_module("sentinel-tree-cover_amd.synth")
 from tests.helpers import fake_model, fake_dsen2  # noqa: E402
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("TTC_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
 
 
 class FakeSess:

@@ -18,7 +18,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
 import ref_harness  # noqa: E402
 from tests.helpers import fake_model, fake_dsen2, synth_border_strip, synth_reseg_windows  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("TTC_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
 
 
 def set_geometry(RS, size, size_y):

@@ -82,7 +82,8 @@ class Writer:
 
         def node(level, ents):
             body = b"".join(k + struct.pack("<Q", a) for k, a in ents) + last_key
-            return self.alloc(b"TREE" + struct.pack("<BBHQQ", 1, level, len(ents), UNDEF, UNDEF) + body)
+            full = 64 * 8 + 65 * len(last_key)      # libhdf5 reads whole nodes: 2K children + 2K + 1 keys, K = 32 for chunk trees
+            return self.alloc(b"TREE" + struct.pack("<BBHQQ", 1, level, len(ents), UNDEF, UNDEF) + body + b"\0" * (full - len(body)))
         if len(entries) <= leaf_fanout:
             root = node(0, entries)
         else:                                       # two levels: leaves of `leaf_fanout` chunks under one internal node
@@ -123,12 +124,16 @@ class Writer:
             heap_data += pad8(nme.encode() + b"\0")
         heap_data += b"\0" * 64
         hdata = self.alloc(bytes(heap_data))
-        heap = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, hdata))
+        # free-list head: libhdf5 writes 1 (H5HL_FREE_NULL) for "no free block" and rejects anything else that is not an
+        # offset inside the data segment (round-3 files carried the undefined address here and h5ls refused them)
+        heap = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, hdata))
         snod = b"SNOD" + struct.pack("<BxH", 1, len(names))
         for nme in names:
             snod += struct.pack("<QQII16x", offs[nme], links[nme], 0, 0)
-        snod_addr = self.alloc(snod)
-        btree = self.alloc(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_addr, offs[names[-1]]))
+        assert len(names) <= 8                      # one symbol-table node: 2 x leaf K (4) entries of 40 bytes, stored at full size
+        snod_addr = self.alloc(snod + b"\0" * (8 + 8 * 40 - len(snod)))
+        btree = self.alloc(b"TREE" + struct.pack("<BBHQQ", 0, 0, 1, UNDEF, UNDEF) + struct.pack("<QQQ", 0, snod_addr, offs[names[-1]])
+                           + b"\0" * (32 * 8 + 33 * 8 - 24))          # full node for internal K = 16
         root = self.alloc(object_header([msg(0x11, struct.pack("<QQ", btree, heap))]))
         sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBxBBBx", 0, 0, 0, 0, 8, 8) + struct.pack("<HHI", 4, 16, 0)
         sb += struct.pack("<QQQQ", 0, UNDEF, len(self.buf), UNDEF)
