@@ -94,7 +94,7 @@ def roofline(precision, win, n_windows, gates_ms, gates_n):
             "hbm_frac": nbytes / (gates_ms * 1e-3) / (HBM_PEAK_GBS * 1e9) if gates_ms > 0 else 0.0, "bytes_per_launch": nbytes}
 
 
-def oracle_pass(args, host_tile, weights):
+def oracle_pass(args, host_tile, weights, size=None, length=None, cache=None):
     """ONE pass of the chained CPU oracle (oracle/restate_e2e.single_call_chain: the CPU restatement of the reference, kind =
     "port") over tile 0 of the bench, on the host cores.  It serves two purposes: the `cpu_baseline` (every stage timed on
     the WHOLE tile; were E2E_WINDOWS a subset, the model's share would be scaled to 36 windows) and the reference values of
@@ -107,8 +107,10 @@ def oracle_pass(args, host_tile, weights):
     net = M.TreeCoverNet(weights, dtype=torch.float32)
     ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
     tm = {}
-    ref = E.single_call_chain(s2_10, s2_20, s1, dem, probs, dates, net, ds, size=args.win - 14, length=args.length,
-                              sampler="expected", only_windows=set(E2E_WINDOWS), timings=tm)
+    ref = E.single_call_chain(s2_10, s2_20, s1, dem, probs, dates, net, ds, size=size or args.win - 14, length=length or args.length,
+                              sampler="expected", only_windows=set(E2E_WINDOWS), timings=tm, cache=cache)
+    if size is not None:                                  # a second geometry on the cached stages: reference values only
+        return ref, None
     n_model = max(1, len(ref["raw"]))
     tm["model"] = tm["model"] * 36.0 / n_model
     total = sum(tm.values())
@@ -175,6 +177,15 @@ def main():
             raise SystemExit(f"[bench] rank {rank}: init_process_group({backend}) failed: {e}\n  RCCL needs HSA_ENABLE_IPC_MODE_LEGACY=0 "
                              f"(dmabuf IPC) and MASTER_ADDR=127.0.0.1 on this image")
     dev = f"cuda:{local}"
+    comm_check = None
+    if world > 1:
+        # first contact: the path's two communication patterns with verified payloads (shard.smoke_check, also tools/rccl_smoke.py)
+        # BEFORE any bench time is spent; a failure names the pattern and ends the run
+        try:
+            comm_check = shard.smoke_check(rank, world, dev)
+        except Exception as e:
+            print(f"[bench] rank {rank}: communication smoke check over backend '{backend}' failed: {e}", file=sys.stderr, flush=True)
+            os._exit(3)
     weights = Wt.synth_weights(0)
 
     def make_sessions(precision, win=args.win, length=args.length, n=args.inflight):
@@ -340,6 +351,97 @@ def main():
                 "achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "bytes_per_tile": alg_bytes,
                 "tiles_flagged_for_staged_path": bad, "steps": steps, "dt": dt}
 
+    def job_level_leg(sessions, n_tiles):
+        """What the JOB sees per tile ("IO dominates once compute is 100x faster"): raw .hkl files on disk ->
+        ttc_read_hkl (job.py:684-714) -> pinned staging + H2D -> DEM median -> ttc_predict_tile WITH the cloud / shadow detection
+        (what the job runs, :839) -> D2H -> LZW GeoTIFF (io.py:229-263), through job.iter_raw_tiles + job.predict_tiles (the tile
+        loop of :1869-2091).  Files: chunked + deflate HDF5 as hickle writes them (tools/write_hdf5_fixture.py, libhdf5-readable),
+        written before the clock starts.  -> per-stage milliseconds of ONE tile run serially, and the pipelined rate."""
+        import importlib.util
+        import shutil
+        import tempfile
+        spec = importlib.util.spec_from_file_location("write_hdf5_fixture", os.path.join(ROOT, "tools", "write_hdf5_fixture.py"))
+        WF = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(WF)
+        root = tempfile.mkdtemp(prefix="ttc_job_") + "/"
+        out_dir = root + "tifs/"
+        os.makedirs(out_dir)
+
+        def dump(path, arr, chunks=None):
+            w = WF.Writer()
+            w.finish({"data": w.chunked_dataset(arr, chunks=chunks) if chunks else w.contiguous_dataset(arr)}, path)
+        disk = 0
+        for k in range(n_tiles):
+            s2_10, s2_20, probs, dates, s1, dem = pool[k % len(pool)][0]
+            f, idx = f"{root}{k}/0/raw/", f"{k}X0Y"
+            dump(f"{f}s2_10/{idx}.hkl", s2_10, (1, 155, 155, 4))
+            dump(f"{f}s2_20/{idx}.hkl", s2_20, (1, 155, 155, 6))
+            dump(f"{f}s1/{idx}.hkl", s1, (1, 155, 155, 2))
+            dump(f"{f}clouds/clouds_{idx}.hkl", probs.astype(np.float32), (1, 155, 155))
+            dump(f"{f}misc/dem_{idx}.hkl", (dem * 90.0).astype(np.float32), (155, 155))
+            dump(f"{f}misc/s2_dates_{idx}.hkl", np.asarray(dates, dtype=np.int64))
+            for dp, _, fn in os.walk(f):
+                disk += sum(os.path.getsize(os.path.join(dp, x)) for x in fn)
+        size = args.win - 14
+        sess = sessions[0]
+        bounds = [10.0, 5.0, 10.0 + 618 / 9000.0, 5.0 + 618 / 9000.0]
+        stages = {}
+        try:
+            # -- one tile, every stage on its own (synchronised): where the time goes
+            t0 = time.perf_counter()
+            raw = job.load_raw_tile(0, 0, root)
+            stages["read_hkl"] = time.perf_counter() - t0
+            st = torch.cuda.Stream(device=local)
+            stager = job._PinnedStager(torch, local, 1)
+            arrays = {"s2_10": raw["s2_10"], "s2_20": raw["s2_20"], "s1": raw["s1"], "dem": np.asarray(raw["dem"], dtype=np.float32),
+                      "dates": np.asarray(raw["dates"], dtype=np.int32)}
+            stager.upload(0, arrays, st); st.synchronize()              # first use allocates the pinned buffers: not a per-tile cost
+            t0 = time.perf_counter()
+            d = stager.upload(0, arrays, st); st.synchronize()
+            stages["pinned_stage+h2d"] = time.perf_counter() - t0
+            with torch.cuda.stream(st):
+                for rep in range(2):                                    # second pass timed (first touches the detection workspace)
+                    t0 = time.perf_counter()
+                    dem_m = sess.ctx.median5(d["dem"])
+                    dem90 = sess.ctx.divide(dem_m.clone(), 90.0)
+                    u8, f32, _, stw = sess.ctx.predict_tile_raw(d["s2_10"], d["s2_20"], d["s1"], dem90, None, d["dates"], job.min_all, job.max_all,
+                                                                size, dem_m=dem_m, flags=sess.ctx.TILE_DETECT, want_float=True)
+                    st.synchronize()
+                    stages["gpu_detect+predict_tile"] = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                host_u8, words = u8.cpu().numpy(), stw.cpu().numpy()
+                stages["d2h"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            job.write_tif(host_u8, bounds, 0, 0, out_dir)
+            stages["write_geotiff_lzw"] = time.perf_counter() - t0
+            # -- the tile loop, pipelined: reads ahead on host threads, K tiles in flight, GeoTIFFs written as results arrive
+            tm = {}
+            written = []
+
+            def on_result(k, res):
+                t1 = time.perf_counter()
+                written.append(job.write_tif(res[1], bounds, k, 0, out_dir))
+                tm["write_tif_host_s"] = tm.get("write_tif_host_s", 0.0) + time.perf_counter() - t1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k, 0) for k in range(n_tiles)], root, workers=4))
+            res = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tm, on_result=on_result)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        finally:
+            shutil.rmtree(root, ignore_errors=True)
+        gpu_ms = stages["gpu_detect+predict_tile"] * 1e3
+        host_ms = {k: v * 1e3 for k, v in stages.items() if k != "gpu_detect+predict_tile"}
+        slowest = max(host_ms, key=host_ms.get)
+        return {"value": n_tiles * TILE * TILE / wall, "unit": "px/s", "tiles": n_tiles, "ms_per_tile_pipelined": wall / n_tiles * 1e3,
+                "ms_per_stage_serial": {k: round(v * 1e3, 2) for k, v in stages.items()},
+                "host_seconds_in_loop": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
+                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": 4, "sessions": len(sessions),
+                "tiles_rerun_staged": int(sum(1 for r in res if r[3])),
+                "slowest_host_stage": {"name": slowest, "ms": round(host_ms[slowest], 2), "x_gpu_stage": round(host_ms[slowest] / gpu_ms, 2)},
+                "note": "job-level: files -> ttc_read_hkl -> pinned H2D -> detection + ttc_predict_tile -> D2H -> ttc_write_geotiff_u8; "
+                        "serial stage times are of tile 0 alone, the rate is the pipelined loop (job.iter_raw_tiles + job.predict_tiles)"}
+
     sessions = make_sessions(args.precision)
     if args.preprocess_only:
         pre = preprocess_leg(sessions, args.tiles, args.warmup)
@@ -364,9 +466,9 @@ def main():
     # ---- headline: EXACTLY K timed steps after W warm-up steps ------------------------------------------------------------
     dt, gates_ms, gates_n, bad = measure(sessions, args.steps, args.warmup)
     iso_ms = isolated_gates(sessions[0]) if (args.inflight > 1 and rank == 0) else None
-    ref, cpu = None, None
+    ref, cpu, stages = None, None, {}
     if world == 1 and not args.no_cpu_baseline:           # the CPU oracle pass (cpu_baseline + the e2e reference): N = 1 only
-        ref, cpu = oracle_pass(args, host_tile, weights)
+        ref, cpu = oracle_pass(args, host_tile, weights, cache=stages)
     dprob = max_dprob(sessions[0]) if (rank == 0 and not args.no_dprob) else None
     e2e = {args.precision: dprob_e2e(sessions[0], ref)} if (rank == 0 and not args.no_dprob) else {}
     if world > 1:
@@ -378,6 +480,10 @@ def main():
         extra["preprocess_only"] = {k: pre[k] for k in ("value", "unit", "tiles", "ms_per_tile", "achieved_GBps", "peak_GBps", "frac", "bytes_per_tile")}
         extra["preprocess_only"]["note"] = ("BASELINE configs[2] (python bench.py --preprocess-only --tiles 256 prints it as its own line): decode, "
                                             "bilinear, gap-fill, temporal stage, window assembly; algorithmic bytes per SURVEY 8(d); north_star target frac 0.40")
+        try:
+            extra["job_level"] = job_level_leg(sessions, 6)
+        except Exception as e:                                   # informational leg: never take the headline line down with it
+            extra["job_level"] = {"error": f"{type(e).__name__}: {e}"}
         close(sessions)
         for other in [p for p in ("fp16", "bf16", "fp32") if p != args.precision]:
             ss = make_sessions(other)
@@ -393,12 +499,15 @@ def main():
             close(ss)
         # BASELINE's "168x168", "12-step" wording: the 168-window / 12-step geometry (2.82 TFLOP of model per tile instead of 1.51)
         l12 = {"win_in": 168, "length": 12, "model_tflop_per_tile": 36 * model_flops(168, 12) / 1e12}
+        ref12 = None
+        if ref is not None and not args.no_dprob:           # the oracle at this geometry (gap-fill / DSen2 stages shared with the first pass)
+            ref12, _ = oracle_pass(args, host_tile, weights, size=154, length=12, cache=stages)
         for prec in ("fp32", "fp16"):
             ss = make_sessions(prec, win=168, length=12)
             steps12 = max(2, min(args.steps, 6))
             dt3, g3, _, _ = measure(ss, steps12, 1, size=154)
             l12[prec] = {"value": args.inflight * TILE * TILE * steps12 / dt3, "unit": "px/s", "ms_per_step": dt3 / steps12 * 1e3, "steps": steps12,
-                         "conv_gates_launch_ms": g3}
+                         "conv_gates_launch_ms": g3, "max_dprob_e2e": dprob_e2e(ss[0], ref12)}
             close(ss)
         extra["l12_w168"] = l12
 
@@ -439,7 +548,7 @@ def main():
                 "weights": "synthetic seed 0 (ConvGRU/U-Net weights absent from the reference checkout); DSen2 real",
                 "tiles_per_step_per_gpu": args.inflight, "streams_per_gpu": args.inflight, "distinct_tiles_per_gpu": len(pool),
                 "tile_ids": "k * world + rank", "gather_batch": B if world > 1 else None, "gathers_timed": state["gathers"] if world > 1 else None,
-                "tiles_flagged_for_staged_path": bad, "tiles_failed": state["failed"],
+                "tiles_flagged_for_staged_path": bad, "tiles_failed": state["failed"], "comm_smoke_check": comm_check,
                 "max_dprob_sample": "model only: HIP vs fp32 oracle on %d of the 36 windows of tile 0 (model inputs as the tile path assembled them)" % (len(E2E_WINDOWS),),
                 "win_in": args.win, "length": args.length, "dates": args.dates,
                 "model_tflop_per_tile": 36 * model_flops(args.win, args.length) / 1e12,

@@ -389,8 +389,11 @@ ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t 
  * ttc_debug_timing(ctx, level): 0 = off, 1 = every kernel family, 2 = conv-engine launches only
  * (cheap enough to leave on inside a timed benchmark region). */
 ttc_status ttc_debug_timing(ttc_ctx* ctx, int32_t enable);
-/* process-wide probe knobs of the 16-bit conv engine (tools/probes/h16_knobs.py): which 0 = persistent grid size (-1 default = 2 per
- * CU, 0 = one workgroup per tile), 1 = start offset of the odd wave slot in s_sleep(127) units (-1 default).  Test / probe aid. */
+/* PROBE ONLY -- not part of the drop-in surface.  Process-wide knobs of the 16-bit conv engine (tools/probes/h16_knobs.py, h16_trace.py):
+ * which 0 = persistent grid size (-1 default = 2 per CU, 0 = one workgroup per tile), 1 = start offset of the odd wave slot in
+ * s_sleep(127) units (-1 default), 2 | 3 = halves of a device pointer to a trace buffer, 4 = epilogue kind to trace.  They are plain
+ * process globals read at launch time by every context and stream, so the call is REFUSED (TTC_ERR_STATE) unless the process was
+ * started with TTC_ENABLE_PROBE_KNOBS=1 in its environment. */
 ttc_status ttc_debug_knob(int32_t which, int32_t value);
 ttc_status ttc_debug_kernel_ms(ttc_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 

@@ -30,13 +30,18 @@ class _Clock:
         self.last = now
 
 
-def _finish(s2, dates, interp, s1, dem90, net, dsen2, size, length, only_windows, clk):
+def _finish(s2, dates, interp, s1, dem90, net, dsen2, size, length, only_windows, clk, cache=None):
     """superresolve -> process_subtiles -> mosaic.  Returns a dict with the rounded windows, the model's raw
     (pre-mask, pre-rounding) probabilities of the windows it was run on, the model feeds, and the two rasters.
     only_windows: window indices (job.py:1295-1316 iteration order) to run the model on; the others get a constant 0.5
     (bench.py's bounded CPU sample) -- None = all."""
-    if dsen2 is not None:
-        s2[..., :10] = R.superresolve_large_tile(s2[..., :10], dsen2)
+    if cache is not None and "s2_sr" in cache:                       # the stages before the windows do not depend on size / length
+        s2 = cache["s2_sr"].copy()
+    else:
+        if dsen2 is not None:
+            s2[..., :10] = R.superresolve_large_tile(s2[..., :10], dsen2)
+        if cache is not None:
+            cache["s2_sr"] = s2.copy()
     clk.lap("dsen2")
     raws, spent = [], [0.0]
 
@@ -65,22 +70,29 @@ def _finish(s2, dates, interp, s1, dem90, net, dsen2, size, length, only_windows
 
 
 def single_call_chain(s2_10, s2_20, s1, dem90, mask, dates, net, dsen2, size=158, length=4, sampler="expected",
-                      only_windows=None, timings=None):
+                      only_windows=None, timings=None, cache=None):
     """What ttc_predict_tile computes for a tile on which none of process_tile's date-dropping rules fire (its status words
     stay zero): to_float32 + convert_to_db, bilinear 20 m -> 10 m, remove_cloud_and_shadows with the GIVEN mask and the
     deterministic expected-multiplicity sampler, process_tile's final clip, then the rest of the chain.
-    dem90: the elevation as process_tile returns it (median-filtered, / 90)."""
+    dem90: the elevation as process_tile returns it (median-filtered, / 90).
+    cache: a dict shared by passes over the SAME tile and sampler at different window geometries (size / length): the stages up
+    to and including DSen2 do not depend on the geometry and are computed by the first pass only."""
     clk = _Clock(timings)
-    s2_10f, s2_20f, s1db = R.to_float32(s2_10), R.to_float32(s2_20), R.s1_to_db(s1)
-    clk.lap("codecs")
-    s2 = R.upsample_20m(s2_10f, s2_20f)
-    clk.lap("bilinear")
-    s2, interp, to_remove = G.remove_cloud_and_shadows(s2, np.array(mask, dtype=np.float32, copy=True),
-                                                       np.zeros(s2.shape[1:3], bool), sampler)
-    s2 = np.clip(s2, 0, 1)
+    if cache is not None and "gapfilled" in cache:
+        s2, interp, to_remove, s1db = (np.array(v, copy=True) if isinstance(v, np.ndarray) else list(v) for v in cache["gapfilled"])
+    else:
+        s2_10f, s2_20f, s1db = R.to_float32(s2_10), R.to_float32(s2_20), R.s1_to_db(s1)
+        clk.lap("codecs")
+        s2 = R.upsample_20m(s2_10f, s2_20f)
+        clk.lap("bilinear")
+        s2, interp, to_remove = G.remove_cloud_and_shadows(s2, np.array(mask, dtype=np.float32, copy=True),
+                                                           np.zeros(s2.shape[1:3], bool), sampler)
+        s2 = np.clip(s2, 0, 1)
+        if cache is not None:
+            cache["gapfilled"] = (s2.copy(), np.array(interp, copy=True), list(to_remove), s1db.copy())
     clk.lap("gapfill")
     out = _finish(s2, np.asarray(dates).copy(), interp, s1db, np.asarray(dem90, dtype=np.float32), net, dsen2, size, length,
-                  only_windows, clk)
+                  only_windows, clk, cache)
     out["to_remove"] = list(to_remove)
     return out
 

@@ -309,13 +309,22 @@ class Context:
 
     TILE_DETECT, TILE_INPUTS_ONLY, TILE_NO_SUPERRES = 1, 2, 4
 
+    @staticmethod
+    def tile_needs_staged(status):
+        """status: the 4 words of ttc_predict_tile (host array / sequence).  True -> one of process_tile's date-dropping rules fired
+        on the device (words 0, 2, 3; word 1 is a count, not a flag): re-run the tile through the staged path."""
+        return bool(int(status[0]) or int(status[2]) or int(status[3]))
+
     def predict_tile_raw(self, s2_10, s2_20, s1, dem, mask, dates, min_all, max_all, size, dem_m=None, flags=0,
                          want_float=False, want_inputs=False, out=None, status=None):
         """ttc_predict_tile: the whole per-tile chain in ONE enqueue, no host round trip.  s2_10 [T, X, Y, 4] / s2_20
         [T, X/2, Y/2, 6] / s1 [12, X, Y, 2] uint16 as stored (cuda int16 / uint16 views or numpy), dem [X, Y] (/90), mask
         [T, X, Y] float32 cloud + shadow mask (None with TILE_DETECT), dates [T] (cuda int32 tensor or sequence).
         -> (u8 cuda [Y, X] | None, f32 | None, model inputs | None, status cuda int32[4]); read `status` after a stream
-        synchronisation: status[0] / status[2] != 0 -> the tile needs the staged calls (see ttc.h)."""
+        synchronisation and hand it to Context.tile_needs_staged: status[0] (a date the mosaic cannot align), status[2] (dates
+        the gap-fill marks fully interpolated) or status[3] (bit 1 a date with > 10 % missing pixels, bit 2 more than 10 snowy
+        dates, bit 4 a date > 90 % feathered) non-zero -> the rasters are NOT the reference's and the tile needs the staged
+        calls (job.predict_tile_raw_checked does that; see ttc.h).  status[1] = dates kept by the model-side screening."""
         t = self.torch
         dev = f"cuda:{self.device}"
 

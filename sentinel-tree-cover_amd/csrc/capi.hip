@@ -114,7 +114,7 @@ ttc_status ttc_forward_windows(ttc_ctx* c, const float* d_in, int32_t n, float* 
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
-    return model_forward_frames(c, n, d_out, s);
+    return model_forward_frames(c, n, d_out, s, FRAMES_PLANAR);
 }
 
 ttc_status ttc_forward_taps(ttc_ctx* c, const float* d_in, int32_t n, float* d_out, float* d_early, float* d_late, void* stream) {
@@ -123,7 +123,7 @@ ttc_status ttc_forward_taps(ttc_ctx* c, const float* d_in, int32_t n, float* d_o
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
-    TTC_CHECK(model_forward_frames(c, n, d_out, s));
+    TTC_CHECK(model_forward_frames(c, n, d_out, s, FRAMES_PLANAR));
     return model_taps(c, n, d_early, d_late, s);
 }
 
@@ -356,7 +356,12 @@ ttc_status ttc_divide(ttc_ctx* c, float* d_a, int64_t n, float divisor, void* st
 }
 #undef TTC_S
 
-ttc_status ttc_debug_knob(int32_t which, int32_t value) { h16_set_knob(which, value); return TTC_OK; }
+ttc_status ttc_debug_knob(int32_t which, int32_t value) {
+    static const bool enabled = [] { const char* e = getenv("TTC_ENABLE_PROBE_KNOBS"); return e && e[0] == '1'; }();
+    if (!enabled) return TTC_ERR_STATE;          // process-wide, unsynchronised probe state: only for processes that asked for it
+    h16_set_knob(which, value);
+    return TTC_OK;
+}
 
 ttc_status ttc_debug_clouds_stage(ttc_ctx* c, int32_t stage) {
     if (!c) return TTC_ERR_ARG;
@@ -376,6 +381,9 @@ ttc_status ttc_debug_fetch(ttc_ctx* c, const char* name, float* h_dst, size_t ca
     if (it == c->named.end()) return c->fail(TTC_ERR_ARG, std::string("unknown activation: ") + name);
     if (n_floats) *n_floats = it->second.second;
     if (!h_dst) return TTC_OK;
+    if (!c->frames_planar_valid && std::string(name) == "frames")
+        return c->fail(TTC_ERR_STATE, "frames: the last tile's windows were assembled in the 16-bit engine's blocked form only; pass d_model_in "
+                                      "to ttc_predict_tile or switch ttc_debug_keep on to have the fp32 planar frames written");
     TTC_HIP(c, hipDeviceSynchronize());
     const size_t n = it->second.second < cap ? it->second.second : cap;
     TTC_HIP(c, hipMemcpy(h_dst, it->second.first, n * sizeof(float), hipMemcpyDeviceToHost));

@@ -40,6 +40,7 @@
 //     what lets the prefetch above own the LDS during the epilogue, and removes 256 ds_write_b32 + 32 ds_read_b128 +
 //     4 barriers per tile.  The consumers (k_gru_apply*_b16, k_block_finalize_b16, k_head, k_tap_late) read those planes
 //     as 16-byte vectors (raw_load8, h16_common.h).
+#include <atomic>
 #include <algorithm>
 
 #include "h16_common.h"
@@ -583,6 +584,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
 // wave slot in units of s_sleep(127) (-1 = default), [2] | [3] low / high half of a device pointer to a trace buffer, [4] the
 // epilogue kind to trace
 int g_h16_knob[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+
+// 2 workgroups per CU of the CURRENT device (cached per device id; TTC_H16_PERSIST overrides for probes)
+int resident_workgroups() {
+    static const int forced = [] { const char* e = getenv("TTC_H16_PERSIST"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    static std::atomic<int> per_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+    int v = per_dev[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        v = 2 * cus;
+        per_dev[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 constexpr int kDesyncDefault = 0;
 
 template <int BF, int TERMS, int NCG, int EPI, int OUT>
@@ -598,12 +616,7 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
     const int nblk_q = conv_q_blocks(a.c.Hp, a.c.Wp);
     const int ntiles = nblk_q * pw.ncb * n;
     // persistent grid = the resident set: 2 workgroups per CU (TTC_H16_PERSIST overrides; 0 = one workgroup per tile)
-    static const int resident = [] {
-        if (const char* e = getenv("TTC_H16_PERSIST")) return atoi(e);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 2 * cus;
-    }();
+    const int resident = resident_workgroups();
     const int res = g_h16_knob[0] >= 0 ? g_h16_knob[0] : resident;
     const int grid = res > 0 ? std::min(ntiles, res) : ntiles;
     const int desync = g_h16_knob[1] >= 0 ? g_h16_knob[1] : kDesyncDefault;

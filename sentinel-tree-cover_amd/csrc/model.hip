@@ -148,6 +148,8 @@ struct FinArgs {
     int dst_coff;         // channel offset inside dst
     // 16-bit engine: channel-blocked destination instead of dst; dst_stride_n then counts 16-byte units and dst_coff blocks
     uint4* dhi = nullptr; uint4* dlo = nullptr;
+    int nraw = 0;         // 16-bit engine: the n the PRODUCING conv wrote the raw split planes with (the bottom plane starts after nraw * (C / 8) * PS
+                          // units) -- stated by the launcher, never derived from this kernel's own grid
 };
 
 template <int MODE>
@@ -239,10 +241,10 @@ __global__ __launch_bounds__(256) void k_block_finalize_1p(FinArgs a) {
 
 // final block tail + 1x1 head (train-model.py:226-231): sigmoid(sum_c hw[c] * z[c] + hb)
 // BLK: the raw conv output is the 16-bit engine's channel-blocked split planes (Raw16, h16_common.h), `yraw` = its top plane
-// and the bottom plane follows after gridDim.y * (C / 8) * PS units
+// and the bottom plane follows after nraw * (C / 8) * PS units (nraw = the n of the conv launch that wrote it)
 template <bool BLK>
 __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
-                       const float* __restrict__ headp, float* __restrict__ out, int C, int P, int ow, int tr) {
+                       const float* __restrict__ headp, float* __restrict__ out, int C, int P, int ow, int tr, int nraw) {
     extern __shared__ float sm[];            // scale shift ssew headw
     const int n = blockIdx.y, cpg = C / 8;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -260,7 +262,7 @@ __global__ void k_head(const float* __restrict__ yraw, const float* __restrict__
     float logit = headp[C];
     if constexpr (BLK) {
         const uint4* top = reinterpret_cast<const uint4*>(yraw);
-        const uint4* bot = top + (long)gridDim.y * (C / 8) * PS;
+        const uint4* bot = top + (long)nraw * (C / 8) * PS;
         float z = 0.f;                                                     // sum_c hw[c] * zn[c]: the gate multiplies it afterwards
         for (int k = 0; k < C / 8; ++k) {
             float v[8];
@@ -302,7 +304,7 @@ __global__ void k_tap_early(const float* __restrict__ gru_out, int H, int W, int
 // late = output of the last conv_swish_gn block after its sSE gate (`csse_out_mul/mul:0`), [n, o, o, C] NHWC
 template <bool BLK>
 __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restrict__ gn, const float* __restrict__ prm,
-                           float* __restrict__ out, int C, int P, int ow, int tr) {
+                           float* __restrict__ out, int C, int P, int ow, int tr, int nraw) {
     extern __shared__ float sm[];            // scale shift ssew
     const int n = blockIdx.y, cpg = C / 8;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -320,7 +322,7 @@ __global__ void k_tap_late(const float* __restrict__ yraw, const float* __restri
     float* o = out + ((long)n * P + (tr ? (p % ow) * oh + p / ow : p)) * C;
     if constexpr (BLK) {
         const uint4* top = reinterpret_cast<const uint4*>(yraw);
-        const uint4* bot = top + (long)gridDim.y * (C / 8) * PS;
+        const uint4* bot = top + (long)nraw * (C / 8) * PS;
         for (int k = 0; k < C / 8; ++k) {
             float v[8];
             raw_load8(top, bot, ((long)n * (C / 8) + k) * PS + s0, v);
@@ -450,7 +452,7 @@ __global__ void k_block_finalize_b16(FinArgs a) {
     }
     // raw conv output: the 16-bit engine's channel-blocked split planes (a.y = top plane, the bottom plane follows)
     const uint4* ytop = reinterpret_cast<const uint4*>(a.y);
-    const uint4* ybot = ytop + (long)gridDim.y * (C / 8) * PS;
+    const uint4* ybot = ytop + (long)a.nraw * (C / 8) * PS;
     const long ub = (long)n * (C / 8) * PS;
     float gate[NS];
 #pragma unroll
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256) void k_block_finalize_b16_1p(FinArgs a) {
     }
     const int src = MODE == G_COPY ? (iy + a.crop) * SP + ix + a.crop : (iy >> 1) * SP + (ix >> 1);
     const uint4* ytop = reinterpret_cast<const uint4*>(a.y);
-    const uint4* ybot = ytop + (long)gridDim.y * (C / 8) * PS;
+    const uint4* ybot = ytop + (long)a.nraw * (C / 8) * PS;
     const long ub = (long)n * (C / 8) * PS + src;
     float zn[C];
     float gate = a.prm[3 * C];
@@ -756,7 +758,7 @@ ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStrea
     const Geo g(c->cfg);
     KTimer kt(c, "frames_from_nhwc", s);
     dim3 grid((g.y.np * g.x.np + 255) / 256, g.L + 1, n);
-    c->frames16_ready = false;                   // fp32 planar frames: forward_h16 converts them
+    c->frames_planar_valid = true;
     hipLaunchKernelGGL(k_nhwc_to_frames, grid, dim3(256), 0, s, d_in, c->frames, g.L + 1, g.y.n, g.x.n, c->cfg.n_bands, g.tr ? 1 : 0);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
@@ -788,7 +790,7 @@ static ttc_status finalize(ttc_ctx* c, int mode, const FinArgs& a, int n, hipStr
 // ---------------------------------------------------------------------------------------
 // forward on the 16-bit engine: same graph, same launch order; every conv input is a channel-blocked hi / lo pair
 template <int BF>
-static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
+static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, FramesForm form) {
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
     const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
@@ -801,9 +803,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
 
     // frames (fp32 planar from the NHWC entry points / the border assembly) -> channel-blocked hi / lo; the tile path's window
     // assembly writes the blocked form itself (tile.hip k_assemble)
-    const bool have16 = c->frames16_ready;
-    c->frames16_ready = false;
-    if (!have16) {
+    if (form == FRAMES_PLANAR) {
         KTimer kt(c, "frames_to_b16", s);
         hipLaunchKernelGGL((k_planar_to_b16<BF>), dim3((unsigned)((PP + 255) / 256), N * (g.L + 1)), dim3(256), 0, s, c->frames,
                            Cx, PP, Cx8, c->frames16.hi, c->frames16.lo);
@@ -877,7 +877,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
     // src: raw conv output dims; dst: blocked destination, dims INCLUDING pad; cblk: its channel blocks per n; boff: block offset
     auto fin = [&](int b, int mode, const float* y, Dim src, const B16& dst, Dim d, int pad, int crop, int cblk, int boff) -> ttc_status {
         FinArgs f{y, gn_slot[b], prm(b), nullptr, kBlockCout[b], src.h, src.w, d.h, d.w, pad, crop, mode, (long)cblk * d.area(), boff,
-                  dst.hi, dst.lo};
+                  dst.hi, dst.lo, N};
         KTimer kt(c, "block_finalize", s);
         dim3 grid((f.Hd * f.Wd + 255) / 256, N);
         const size_t lds = 3 * f.C * sizeof(float);
@@ -925,19 +925,21 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
         KTimer kt(c, "head", s);
         const int Po = (int)o.area();
         hipLaunchKernelGGL(k_head<true>, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
-                           prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0);
+                           prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0, N);
         TTC_HIP(c, hipGetLastError());
     }
+    c->forward_n = N;
     return TTC_OK;
 }
 
-ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) {
+ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, FramesForm form) {
     if (!c->have_model) return c->fail(TTC_ERR_STATE, "ttc_load_weights has not been called");
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
     if (c->half()) {
         const int m = c->blk_mode();
-        return m == 1 ? forward_h16<1>(c, n, d_out, s) : forward_h16<0>(c, n, d_out, s);
+        return m == 1 ? forward_h16<1>(c, n, d_out, s, form) : forward_h16<0>(c, n, d_out, s, form);
     }
+    if (form != FRAMES_PLANAR) return c->fail(TTC_ERR_STATE, "blocked 16-bit frames handed to the fp32 engine");
     const Geo g(c->cfg);
     const int N = n, N2 = 2 * n, Hd = c->cfg.hidden, Cx = c->cfg.n_bands, F = c->cfg.base_filters;
     const int H = g.y.n, W = g.x.n, Hp = g.y.np, Wp = g.x.np;
@@ -1038,8 +1040,9 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
         KTimer kt(c, "head", s);
         const int Po = (int)o.area();
         hipLaunchKernelGGL(k_head<false>, dim3((Po + 255) / 256, N), dim3(256), 4 * F * sizeof(float), s, c->y_out, gn_slot[7],
-                           prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0);
+                           prm(7), sm + c->small_off["head/"], d_out, F, Po, o.w, g.tr ? 1 : 0, N);
         TTC_HIP(c, hipGetLastError());
+        c->forward_n = N;
     }
     return TTC_OK;
 }
@@ -1047,6 +1050,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s) 
 // the two feature tensors of the forward that has just run for the same n (buffers are still in the workspace)
 ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStream_t s) {
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
+    if (n > c->forward_n) return c->fail(TTC_ERR_STATE, "taps of more windows than the last forward ran");
     const Geo g(c->cfg);
     const int F = c->cfg.base_filters;
     KTimer kt(c, "taps", s);
@@ -1065,9 +1069,9 @@ ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStrea
         const int Po = g.y.o * g.x.o;
         const float* gn7 = c->gn + (size_t)7 * c->cfg.max_windows * 2 * 32;
         if (c->half()) hipLaunchKernelGGL(k_tap_late<true>, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
-                                          c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0);
+                                          c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0, c->forward_n);
         else hipLaunchKernelGGL(k_tap_late<false>, dim3((Po + 255) / 256, n), dim3(256), 3 * F * sizeof(float), s, c->y_out, gn7,
-                                c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0);
+                                c->d_small + c->small_off["out/"], d_late, F, Po, g.x.o, g.tr ? 1 : 0, c->forward_n);
     }
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;

@@ -408,11 +408,11 @@ ttc_status reseg_border_subtiles(ttc_ctx* c, const float* d_s2, const float* d_s
       const int PP = (H + 2) * (W + 2), tr = H < W ? 1 : 0;
       const int patches = ((H + 2 + 7) / 8) * ((W + 2 + 7) / 8);              // 8 x 8 patches, one per wave (transposed planes)
       const int blocks = tr ? (patches + 3) / 4 : (PP + 255) / 256;
-      c->frames16_ready = false;                   // fp32 planar frames: forward_h16 converts them
+      c->frames_planar_valid = true;
       hipLaunchKernelGGL(k_border_assemble, dim3(blocks, 5, n), dim3(256), 0, s, q, med, s1q, s1med, d_dem,
                          hist_align ? aff : nullptr, bt, nm, H, W, tr, npix, half, c->frames, flags);
       TTC_HIP(c, hipGetLastError()); }
-    TTC_CHECK(model_forward_frames(c, n, d_preds, s));
+    TTC_CHECK(model_forward_frames(c, n, d_preds, s, FRAMES_PLANAR));
     { KTimer kt(c, "border_seam_adjust", s);
       hipLaunchKernelGGL(k_seam_adjust, dim3(n), dim3(1024), 0, s, d_preds, flags, n_dates_ok >= 2 ? 1 : 0, oh, ow, dstats);
       TTC_HIP(c, hipGetLastError()); }

@@ -840,6 +840,7 @@ static ttc_status tile_core(ttc_ctx* c, const float* d_s2, int T, int X, int Y, 
       hipLaunchKernelGGL(k_tile_s1, dim3(gp), dim3(256), 0, s, d_s1, (int)npix, L, s1q, s1med);
       TTC_HIP(c, hipGetLastError()); }
     const int PP = (W + 2) * (W + 2);
+    bool blocked_frames = false;
     { KTimer kt(c, "assemble", s);
       const dim3 ag((PP + 255) / 256, L + 1, wt.n);
       // 16-bit engine: the blocked pairs directly, unless somebody wants to see the fp32 frames (model feed output, debug keep)
@@ -848,7 +849,8 @@ static ttc_status tile_core(ttc_ctx* c, const float* d_s2, int T, int X, int Y, 
       else if (c->blk_mode() == 1) hipLaunchKernelGGL(k_assemble<1>, ag, dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm, X, Y, W, L, nullptr,
                                                       c->frames16.hi, c->frames16.lo);
       else hipLaunchKernelGGL(k_assemble<0>, ag, dim3(256), 0, s, sm, med, s1q, s1med, d_dem, wt, nm, X, Y, W, L, nullptr, c->frames16.hi, c->frames16.lo);
-      c->frames16_ready = blocked;
+      c->frames_planar_valid = !blocked;
+      blocked_frames = blocked;
       TTC_HIP(c, hipGetLastError()); }
     if (stop_after_inputs) return TTC_OK;
     { KTimer kt(c, "bright", s);
@@ -859,7 +861,7 @@ static ttc_status tile_core(ttc_ctx* c, const float* d_s2, int T, int X, int Y, 
       TTC_HIP(c, cfg_bright.ensure(&k_bright_dist, lds));
       hipLaunchKernelGGL(k_bright_dist, dim3(wt.n), dim3(1024), lds, s, flags, W, size, d2);
       TTC_HIP(c, hipGetLastError()); }
-    TTC_CHECK(model_forward_frames(c, wt.n, probs, s));
+    TTC_CHECK(model_forward_frames(c, wt.n, probs, s, blocked_frames ? FRAMES_B16 : FRAMES_PLANAR));
     { KTimer kt(c, "post", s);
       unsigned char* cc = static_cast<unsigned char*>(c->scratch_buf("tile_clear", (size_t)npix));
       if (!cc) return c->fail(TTC_ERR_NOMEM, "clear-count map");

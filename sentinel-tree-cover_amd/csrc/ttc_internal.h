@@ -193,7 +193,10 @@ struct ttc_ctx {
     unsigned wmat_slot = 0;       // ring index of the host-built temporal operator (tile.hip)
     std::vector<hipEvent_t> wmat_events;   // per ring slot: the H2D copy that last read it
     bool want_planar_frames = false;   // the caller asked for the model feed (ttc_predict_tile d_model_in): keep the fp32 planar frames
-    bool frames16_ready = false;       // the window assembly wrote the 16-bit engine's blocked hi / lo frames itself (tile.hip)
+    // which form of the model frames the LAST writer left valid: every writer states it and hands it to model_forward_frames
+    // explicitly (a writer cannot "forget" a flag: the parameter is required); ttc_debug_fetch("frames") refuses a stale planar buffer
+    bool frames_planar_valid = false;
+    int forward_n = 0;            // windows of the last forward: the raw split planes of its last block were laid out with this n (model_taps)
     bool minv_ready = false;      // the constant Whittaker matrix has been uploaded (tile.hip)
 
     Timing timing;
@@ -210,7 +213,9 @@ struct ttc_ctx {
 // model.hip
 ttc_status model_alloc(ttc_ctx* c);
 ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n);
-ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s);
+enum FramesForm { FRAMES_PLANAR = 0,   // c->frames holds the fp32 planar padded frames (the 16-bit engine converts them first)
+                  FRAMES_B16 = 1 };    // c->frames16 holds the channel-blocked hi / lo pairs (tile.hip k_assemble<BF>); c->frames is stale
+ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, FramesForm form);
 ttc_status model_frames_from_nhwc(ttc_ctx* c, const float* d_in, int n, hipStream_t s);
 ttc_status model_taps(ttc_ctx* c, int n, float* d_early, float* d_late, hipStream_t s);
 // reseg.hip

@@ -338,6 +338,30 @@ def load_raw_tile(x, y, local_path):
             "dates": rd(f"{folder}raw/misc/s2_dates_{idx}.hkl")}
 
 
+def iter_raw_tiles(coords, local_path, workers=4, ahead=None):
+    """Generator over load_raw_tile(x, y, local_path) for (x, y) in coords, read AHEAD by a small thread pool: the HDF5 reader is
+    host C++ behind ctypes (the GIL is released for the duration of the call), so `workers` tiles are parsed / inflated in
+    parallel while the GPU works on earlier ones -- feed it to predict_tiles.  At most `ahead` (default 2 x workers) tiles are
+    resident.  Order is preserved; a failed read raises when its tile is reached."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    coords = list(coords)
+    ahead = int(ahead) if ahead else 2 * int(workers)
+    with ThreadPoolExecutor(max_workers=int(workers)) as pool:
+        q = deque()
+        it = iter(coords)
+        for xy in it:
+            q.append(pool.submit(load_raw_tile, xy[0], xy[1], local_path))
+            if len(q) >= ahead:
+                break
+        while q:
+            raw = q.popleft().result()
+            nxt = next(it, None)
+            if nxt is not None:
+                q.append(pool.submit(load_raw_tile, nxt[0], nxt[1], local_path))
+            yield raw
+
+
 def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True, sampler="reference", cloudshad=None):
     """The numeric flow of process_tile (job.py:641-995) on the device, from the arrays it loads from temp/raw/* :
     raw = {"s2_10": uint16 [T, X, Y, 4], "s2_20": uint16 [T, X/2, Y/2, 6], "s1": uint16 [12, X, Y, 2], "dem": float [X, Y] (m),
@@ -454,7 +478,7 @@ def predict_tile_raw_checked(raw, mask, sess, size=SIZE, to_host=True, sampler="
     u8, f32, _, status = ctx.predict_tile_raw(raw["s2_10"], raw["s2_20"], raw["s1"], dem90, mask, raw["dates"], min_all, max_all,
                                               size, want_float=True)
     st = status.cpu().numpy()                                                  # waits for the stream
-    staged = bool(st[0] or st[2] or st[3])
+    staged = ctx.tile_needs_staged(st)
     if staged:
         s2, dates, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None, clm=None), sess, sampler=sampler, cloudshad=mask)
         ctx.superresolve_tile(s2, quirks=True)                                                         # job.py:2001
@@ -464,7 +488,41 @@ def predict_tile_raw_checked(raw, mask, sess, size=SIZE, to_host=True, sampler="
     return (f32, u8, st, staged) if want_status else (f32, u8)
 
 
-def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, want_status=False, depth=None):
+class _PinnedStager:
+    """Page-locked staging of a tile's raw arrays: numpy -> pinned buffer (host memcpy) -> non_blocking H2D on the session's
+    stream, so enqueueing tile k + K never waits for tile k's kernels (a pageable .to(device) blocks the host behind everything
+    queued on that stream).  `slots` buffer sets are reused round-robin; a set is rewritten only after the H2D copies that
+    last read it have finished (event)."""
+
+    def __init__(self, torch, device, slots):
+        self.t, self.dev = torch, f"cuda:{device}"
+        self.sets = [dict() for _ in range(slots)]
+        self.done = [None] * slots
+
+    def upload(self, slot, arrays, stream):
+        """arrays: {name: numpy array}; uint16 travels as its int16 view.  -> {name: cuda tensor} (valid on `stream`)"""
+        t = self.t
+        if self.done[slot] is not None:
+            self.done[slot].synchronize()
+        out, bufs = {}, self.sets[slot]
+        for name, a in arrays.items():
+            a = np.ascontiguousarray(a)
+            if a.dtype == np.uint16:
+                a = a.view(np.int16)
+            b = bufs.get(name)
+            if b is None or tuple(b.shape) != a.shape or b.numpy().dtype != a.dtype:
+                b = bufs[name] = t.empty(a.shape, dtype=t.from_numpy(np.empty(0, a.dtype)).dtype, pin_memory=True)
+            b.numpy()[...] = a
+            with t.cuda.stream(stream):
+                out[name] = b.to(self.dev, non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record(stream)
+        self.done[slot] = ev
+        return out
+
+
+def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, want_status=False, depth=None, timings=None,
+                  on_result=None):
     """The job's TILE LOOP (job.py:1869-2091 processes one tile after the other) over a sequence of tiles, pipelined on one GPU:
     `sessions` = 1 .. K TTCSession of the same device; tile k is enqueued on session k % K, each session on its own HIP stream,
     with ONE ttc_predict_tile call and no host wait, so K tiles are in flight (bench.py: two saturate an MI355X -- one tile's
@@ -473,7 +531,11 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
     predict_tile_raw_checked does, on its own session, before its result is returned.
 
     tiles: iterable of (raw, mask) as predict_tile_raw_checked takes them (may be a generator that loads files lazily:
-    at most `depth` tiles are resident).  -> list of (float32 percent raster, uint8 product[, status int32[4], staged]) in
+    at most `depth` tiles are resident).  mask None = run the multi-temporal cloud / shadow DETECTION inside the call
+    (TTC_TILE_DETECT; what the job does: job.py:839), a flagged tile then re-runs process_tile with its own detection.
+    on_result(k, result): called in input order as soon as tile k is finished (e.g. write_tif), while later tiles are in flight.
+    timings: dict that receives host seconds spent staging uploads / waiting for results.  Raw arrays are staged through page-locked buffers and uploaded with non-blocking
+    copies on the tile's stream (_PinnedStager), so the host never waits behind a stream's queued kernels while enqueueing.  -> list of (float32 percent raster, uint8 product[, status int32[4], staged]) in
     input order, numpy with to_host else cuda tensors."""
     from collections import deque
     sessions = list(sessions)
@@ -486,13 +548,16 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
     streams = [t.cuda.Stream(device=dev) for _ in sessions]
     depth = int(depth) if depth else 2 * len(sessions)
     pending, results = deque(), []
+    stager = _PinnedStager(t, dev, 2 * len(sessions))
+    import time as _time
 
     def finish():
         k, raw, mask, u8, f32, status = pending.popleft()
         sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
+        t0 = _time.perf_counter()
         with t.cuda.stream(st):
             words = status.cpu().numpy()                                      # waits for this tile's stream only
-            staged = bool(words[0] or words[2] or words[3])
+            staged = sess.ctx.tile_needs_staged(words)
             if staged:
                 s2, dates, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None, clm=None), sess, sampler=sampler, cloudshad=mask)
                 sess.ctx.superresolve_tile(s2, quirks=True)
@@ -501,15 +566,29 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
                 f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
             else:
                 st.synchronize()
+        if timings is not None:
+            timings["wait_d2h_host_s"] = timings.get("wait_d2h_host_s", 0.0) + _time.perf_counter() - t0
+            timings["staged"] = timings.get("staged", 0) + int(staged)
         results.append((f32, u8, words, staged) if want_status else (f32, u8))
+        if on_result is not None:
+            on_result(k, results[-1])
 
     for k, (raw, mask) in enumerate(tiles):
         sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
         ctx = sess.ctx
+        t0 = _time.perf_counter()
+        arrays = {"s2_10": raw["s2_10"], "s2_20": raw["s2_20"], "s1": raw["s1"], "dem": np.asarray(raw["dem"], dtype=np.float32),
+                  "dates": np.asarray(raw["dates"], dtype=np.int32)}
+        if mask is not None:
+            arrays["mask"] = np.asarray(mask, dtype=np.float32)
+        d = stager.upload(k % (2 * len(sessions)), arrays, st)
+        if timings is not None:
+            timings["stage_h2d_host_s"] = timings.get("stage_h2d_host_s", 0.0) + _time.perf_counter() - t0
         with t.cuda.stream(st):
-            dem90 = ctx.divide(ctx.median5(np.ascontiguousarray(raw["dem"], dtype=np.float32)), 90.0)      # job.py:713, :993
-            u8, f32, _, status = ctx.predict_tile_raw(raw["s2_10"], raw["s2_20"], raw["s1"], dem90, mask, raw["dates"], min_all, max_all,
-                                                      size, want_float=True)
+            dem_m = ctx.median5(d["dem"])                                                                # job.py:713 (metres: the detector's unit)
+            dem90 = ctx.divide(dem_m.clone(), 90.0)                                                      # :993
+            u8, f32, _, status = ctx.predict_tile_raw(d["s2_10"], d["s2_20"], d["s1"], dem90, d.get("mask"), d["dates"], min_all, max_all,
+                                                      size, dem_m=dem_m, flags=0 if mask is not None else ctx.TILE_DETECT, want_float=True)
         pending.append((k, raw, mask, u8, f32, status))
         if len(pending) > depth:
             finish()

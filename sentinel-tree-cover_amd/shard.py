@@ -126,3 +126,62 @@ def exchange_border_strips(tiles: dict, n_tiles: int, rank: int, world: int, siz
         else:
             out[t] = neighbour_strip(tiles[t + 1], size)
     return out
+
+
+# ---- first-contact check of the collectives this path uses -------------------------------------------------------------------
+def smoke_check(rank: int, world: int, device=None, n_rasters: int = 4, tile: int = 618, size: int = 158):
+    """Runs the path's two communication patterns once on the initialised process group -- the batched raster gather to rank 0
+    (`gather_rasters`, the only collective of the tile path; job.py:1716-1717 / :1869 shard tiles with --start / --end instead)
+    and the point-to-point border-strip exchange (`exchange_border_strips`) -- with rank-stamped data, checks every value
+    that arrives and returns a dict (seconds per pattern, bytes moved, `ok`).  Raises on a mismatch.  `bench.py --gpus N > 1`
+    calls it before its warm-up and tools/rccl_smoke.py prints it as one JSON line: whoever first gets a multi-GPU node learns
+    in seconds whether the `nccl` (RCCL) branch works before spending a bench run on it."""
+    import time
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend() if world > 1 else "none"
+    dev = device if (device is not None and backend != "gloo") else "cpu"
+    out = {"backend": backend, "world": world, "ok": False}
+    # 1) gather: n_rasters x tile x tile uint8 per rank, value = 10 * rank + index
+    rasters = torch.stack([torch.full((tile, tile), (10 * rank + i) % 251, dtype=torch.uint8) for i in range(n_rasters)]).to(dev)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = gather_rasters(rasters, rank, world, 0)
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    out["gather_s"] = time.perf_counter() - t0
+    out["gather_bytes_per_rank"] = int(rasters.numel())
+    if rank == 0:
+        for r, g in enumerate(got):
+            want = torch.tensor([(10 * r + i) % 251 for i in range(n_rasters)], dtype=torch.uint8)
+            if not (torch.equal(g[:, 0, 0].cpu(), want) and torch.equal(g[:, -1, -1].cpu(), want) and int(g.cpu().to(torch.int64).sum()) == int(want.to(torch.int64).sum()) * tile * tile):
+                raise RuntimeError(f"smoke_check: gathered rasters of rank {r} are wrong")
+    # 2) border strips: one tile per rank in a row of `world` tiles, tile t keeps 3 + t % 2 dates, values stamped with the tile id
+    X = 64
+    T = 3 + rank % 2
+    mine = {rank: {"s2": torch.full((T, X, X, 10), float(rank), dtype=torch.float32, device=dev),
+                   "interp": torch.full((T, X, X), rank + 0.5, dtype=torch.float32, device=dev),
+                   "s1": torch.full((12, X, X, 2), -float(rank), dtype=torch.float32, device=dev),
+                   "dem": torch.full((X, X), 100.0 + rank, dtype=torch.float32, device=dev),
+                   "dates": [10 * rank + k for k in range(T)]}}
+    t0 = time.perf_counter()
+    strips = exchange_border_strips(mine, world, rank, world, size=32, device=None if dev == "cpu" else dev) if world > 1 else {}
+    if dev != "cpu":
+        torch.cuda.synchronize()
+    out["strips_s"] = time.perf_counter() - t0
+    for t, sdict in strips.items():
+        n = t + 1
+        Tn = 3 + n % 2
+        ok = (sdict["dates"] == [10 * n + k for k in range(Tn)] and sdict["s2"].shape[0] == Tn
+              and float(sdict["s2"].min()) == float(sdict["s2"].max()) == float(n)
+              and float(sdict["interp"].max()) == n + 0.5 and float(sdict["s1"].min()) == -float(n) and float(sdict["dem"].max()) == 100.0 + n)
+        if not ok:
+            raise RuntimeError(f"smoke_check: border strip of tile {n} arrived wrong on rank {rank}")
+    out["strips_received"] = len(strips)
+    # 3) the timing reduction bench.py uses
+    out["max_over_ranks_ok"] = max_over_ranks(1.0 + rank, dev, world) == float(world)
+    if not out["max_over_ranks_ok"]:
+        raise RuntimeError("smoke_check: all_reduce(MAX) returned the wrong value")
+    out["ok"] = True
+    return out

@@ -115,3 +115,18 @@ def test_border_strip_exchange_three_ranks():
     owned = [r[1] for r in res]
     assert owned == [[0, 3], [1, 4], [2, 5]]            # border t (tiles t, t + 1) belongs to rank t % 3
     assert all(all(r[2].values()) for r in res)
+
+
+def test_comm_smoke_check_two_ranks_gloo():
+    """tools/rccl_smoke.py (shard.smoke_check: verified raster gather + border-strip exchange + max-over-ranks) over gloo, the CPU
+    rehearsal of what bench.py --gpus N > 1 runs first over RCCL"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_smoke.py"), "--spawn", "2", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ok"] and out["ranks_ok"] == [0, 1] and out["rccl_smoke"]["strips_received"] == 1

@@ -1,6 +1,8 @@
 """GPU probe: sweep the 16-bit conv engine's knobs (persistent grid size, start offset of the odd wave slot) in ONE process and
 print the per-layer conv times of a 36-window forward + the DSen2 convs of one tile.  python tools/probes/h16_knobs.py [fp16|bf16]"""
 import os
+os.environ["TTC_ENABLE_PROBE_KNOBS"] = "1"     # ttc_debug_knob is refused otherwise (process-wide probe state)
+import os
 import sys
 import time
 

@@ -1,6 +1,8 @@
 """GPU probe: per-workgroup phase timeline of one 16-bit conv launch (s_memtime stamps of thread 0 at the tile boundaries).
 python tools/probes/h16_trace.py [fp16|bf16] [epi: 0 gates | 1 candidate | 2 swish blocks] [desync]"""
 import os
+os.environ["TTC_ENABLE_PROBE_KNOBS"] = "1"     # ttc_debug_knob is refused otherwise (process-wide probe state)
+import os
 import sys
 
 import numpy as np
