@@ -372,6 +372,15 @@ hipError_t launch_head(const ConvArgs& a, const PackedConv& pw, int n, hipStream
 int conv_q_blocks(int Hp, int Wp) { return ((Hp - 2) * Wp + kBQ - 1) / kBQ; }
 int conv_stat_slots(int Hp, int Wp) { return conv_q_blocks(Hp, Wp) * kWaves; }
 
+// TTC_WINOGRAD=0 keeps every fp32 layer on the direct kernel (A/B runs, parity tests of the direct form)
+bool conv_use_wino(const PackedConv& pw, int epi) {
+    static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
+    return on && pw.mode == 0 && pw.d_wu != nullptr && epi <= EPI_SWISH && pw.Cout % 32 == 0;
+}
+int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp) {
+    return conv_use_wino(pw, epi) ? conv_wino_stat_slots(Hp, Wp, pw.Cout) : conv_stat_slots(Hp, Wp);
+}
+
 int conv_pick_ck(int Cin) {
     // smallest K padding: 49 -> 5 x 10, 17 -> 3 x 6, 10 -> 1 x 10, multiples of 8 -> 8
     if (Cin % 8 == 0) return 8;
@@ -410,6 +419,12 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
     pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);
     if (!pc.d_w && !(pc.d_w = c->alloc_f(packed.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc weights");
     TTC_HIP(c, hipMemcpy(pc.d_w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (pc.mode == 0 && Cout % 32 == 0) {   // fp32 engine: Winograd images for the GroupNorm layers (conv3x3_wino.hip)
+        std::vector<float> pu;
+        pc.set_stride_w = conv_pack_wino(hwio, nsets, Cin, Cout, pu, &pc.nchunk_w);
+        if (!pc.d_wu && !(pc.d_wu = c->alloc_f(pu.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc Winograd weights");
+        TTC_HIP(c, hipMemcpy(pc.d_wu, pu.data(), pu.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (pc.mode >= 2) {                 // 16-bit engine: fp16 (2) / bf16 (3) hi | lo LDS images
         std::vector<uint16_t> ph;
         pc.set_stride_h = conv_pack_h16(hwio, nsets, Cin, C0 < 0 ? Cin : C0, Cout, pc.BN, pc.mode == 3, ph, &pc.nchunk_h);
@@ -422,6 +437,7 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
 }
 
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
+    if (conv_use_wino(pw, epi)) return conv_launch_wino(a, pw, epi, n, s);
     // only the (CK, BN, epilogue) combinations the two graphs need are instantiated
 #define TTC_CONV_CASE(ck, ncg, e) \
     if (pw.CK == ck && pw.BN == ncg * 32 && epi == e) return launch_t<ck, ncg, e>(a, pw, n, s);

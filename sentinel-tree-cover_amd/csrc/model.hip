@@ -656,7 +656,9 @@ ttc_status model_alloc(ttc_ctx* c) {
         B(u2in16, N * (4 * F / 8) * Pu2p, "u2in16"); B(u2a16, N * (4 * F / 8) * Pu2p, "u2cat16");
         B(u3in16, N * (2 * F / 8) * Pu3p, "u3in16"); B(oa16, N * (2 * F / 8) * Pu3, "ocat16");
     }
-    c->stats_floats = N2 * 16 * (size_t)conv_stat_slots(g.y.np, g.x.np) * 2 + 1024;
+    // GroupNorm partial sums: [n][Cout / 4][slots][2]; the Winograd kernels of the fp32 engine keep one slot per 16 x 8 region
+    // and contributing wave (more than the direct kernel's one per 512 positions and wave): size for the larger
+    c->stats_floats = N2 * 16 * (size_t)std::max(conv_stat_slots(g.y.np, g.x.np), conv_wino_stat_slots(g.y.np, g.x.np, 64)) * 2 + 1024;
     A(stats, c->stats_floats, "stats");
     A(gn, 10 * N2 * 32, "gn");
 #undef B
@@ -947,7 +949,6 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
     const float* sm = c->d_small;
     float* gn_slot[10];
     for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
-    const int nblk_full = conv_stat_slots(Hp, Wp);
 
     // ---------------- bi-directional ConvGRU ----------------
     TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
@@ -962,7 +963,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.out = c->yg; a.out_stride_n = 2L * Hd * Pr; a.out_plane = Pr; a.out_pitch = Wp; a.oy = a.ox = 0;
         a.stats = c->stats;
         { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
-        TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
+        TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, conv_stat_slots_for(c->w_gates, EPI_RAW, Hp, Wp), 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply1", s);
             hipLaunchKernelGGL(k_gru_apply1, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
@@ -974,7 +975,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.out = c->yc; a.out_stride_n = (long)Hd * Pr;
         a.aux = gp.base + 4 * 32; a.aux_set_stride = gp.dir_stride;
         { KTimer kt(c, "conv_cand", s); TTC_HIP(c, conv_launch(a, c->w_cand, EPI_SSE, N2, s)); }
-        TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
+        TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, conv_stat_slots_for(c->w_cand, EPI_SSE, Hp, Wp), 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
@@ -996,7 +997,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.out = out; a.out_stride_n = (long)a.Cout * Pro; a.out_plane = Pro; a.out_pitch = in.w; a.oy = a.ox = 0;
         a.stats = c->stats; a.same_pad = same;
         { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
-        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.Cout / 8) * Po, s);
+        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots_for(c->w_block[b], EPI_SWISH, in.h, in.w), (double)(a.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
     // src: raw conv output dims; dst: destination dims INCLUDING pad

@@ -83,6 +83,10 @@ struct PackedConv {      // device copy of one layer's packed weights
     int nchunk_h = 0;             // 8-channel blocks (padded per input segment)
     long set_stride_h = 0;        // 16-byte units between weight sets
     int terms = 3;                // MFMA products per K block: 1 (hi*hi) or 3 (lo*hi + hi*lo + hi*hi)
+    // fp32 engine, Winograd F(2x2, 3x3) form of the GroupNorm layers (conv3x3_wino.hip): U = G g G^T images
+    float* d_wu = nullptr;
+    int nchunk_w = 0;             // 8-channel chunks
+    long set_stride_w = 0;        // floats between weight sets
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the size configured on each device
@@ -137,6 +141,12 @@ long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, i
 int conv_q_blocks(int Hp, int Wp);   // 512-position tiles of a plane
 int conv_stat_slots(int Hp, int Wp); // GroupNorm partial sums per (window, channel quad): one per tile and wave
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+// Winograd F(2x2, 3x3) kernels of the fp32 engine (conv3x3_wino.hip): EPI_RAW / EPI_SSE / EPI_SWISH layers with Cout % 32 == 0
+long conv_pack_wino(const float* const* hwio, int nsets, int Cin, int Cout, std::vector<float>& out, int* nchunk);
+hipError_t conv_launch_wino(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+int conv_wino_stat_slots(int Hp, int Wp, int Cout);
+bool conv_use_wino(const PackedConv& pw, int epi);      // the fp32 engine takes the Winograd form for this layer
+int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp);   // GroupNorm partial-sum slots of the kernel conv_launch will pick
 // C0: real channels of the first input segment (its blocks are padded to a multiple of 8 on their own); bf: bf16 elements
 long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, bool bf, std::vector<uint16_t>& out,
                    int* nchunk);

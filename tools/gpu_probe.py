@@ -16,8 +16,14 @@ ctx.load_weights(weights.synth_weights(0))
 x = torch.from_numpy(synth.synth_windows(seed=1, N=N, L=L, W=W)).cuda()
 print("device bytes", ctx.device_bytes / 1e9, "GB")
 for _ in range(2):
-    ctx.forward_windows(x)
+    out0 = ctx.forward_windows(x)
 torch.cuda.synchronize()
+if os.environ.get("TTC_PROBE_DUMP"):                           # A/B of two builds / switches: dump the probabilities
+    np.save(os.environ["TTC_PROBE_DUMP"], out0.cpu().numpy())
+if os.environ.get("TTC_PROBE_REF"):                            # ... and compare with an earlier dump
+    ref = np.load(os.environ["TTC_PROBE_REF"])
+    d = np.abs(out0.cpu().numpy().astype(np.float64) - ref)
+    print(f"max|dprob| vs {os.environ['TTC_PROBE_REF']}: {d.max():.3e} (mean {d.mean():.3e}, nan {int(np.isnan(d).sum())})")
 t = time.time()
 K = 5
 for _ in range(K):
