@@ -375,10 +375,11 @@ int conv_stat_slots(int Hp, int Wp) { return conv_q_blocks(Hp, Wp) * kWaves; }
 // TTC_WINOGRAD=0 keeps every fp32 layer on the direct kernel (A/B runs, parity tests of the direct form)
 bool conv_use_wino(const PackedConv& pw, int epi) {
     static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
-    return on && pw.mode == 0 && pw.d_wu != nullptr && epi <= EPI_SWISH && pw.Cout % 32 == 0;
+    return on && pw.mode == 0 && pw.d_wu != nullptr && epi <= EPI_SWISH && pw.Cout % 32 == 0 && pw.nchunk_w >= 3;
 }
+// (the Winograd kernels stage 8-byte pairs: planes with an odd pitch stay on the direct kernel)
 int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp) {
-    return conv_use_wino(pw, epi) ? conv_wino_stat_slots(Hp, Wp, pw.Cout) : conv_stat_slots(Hp, Wp);
+    return (conv_use_wino(pw, epi) && !(Wp & 1)) ? conv_wino_stat_slots(Hp, Wp, pw.Cout) : conv_stat_slots(Hp, Wp);
 }
 
 int conv_pick_ck(int Cin) {
@@ -437,7 +438,7 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
 }
 
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
-    if (conv_use_wino(pw, epi)) return conv_launch_wino(a, pw, epi, n, s);
+    if (conv_use_wino(pw, epi) && !(a.Wp & 1)) return conv_launch_wino(a, pw, epi, n, s);
     // only the (CK, BN, epilogue) combinations the two graphs need are instantiated
 #define TTC_CONV_CASE(ck, ncg, e) \
     if (pw.CK == ck && pw.BN == ncg * 32 && epi == e) return launch_t<ck, ncg, e>(a, pw, n, s);

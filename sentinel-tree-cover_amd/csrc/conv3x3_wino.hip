@@ -19,7 +19,7 @@
 // TB patches (4 x 4 floats -> 16 values, 32 additions) into V[xi][k-half][tile][4 k-steps] -- written as consecutive floats by
 // consecutive lanes, read back as ONE ds_read_b128 per (xi, lane) = the B operands of four k-steps.  The A operands (U) are
 // not staged at all: they are read straight from global memory (a layer's U is <= 1.2 MB and lives in L2) as one 16-byte load
-// per (xi, lane) and chunk through a 4-deep register ring.  Back-to-back MFMAs on the same accumulator run at full rate, so a
+// per (xi, lane) and chunk, requested half a chunk ahead.  Back-to-back MFMAs on the same accumulator run at full rate, so a
 // wave's inner loop is xi-major: 8 x (1 ds_read_b128 + 1 global_load_dwordx4 + 4 v_mfma).
 // Output transform: the row half (A^T M) is local to a wave; the column half needs both waves of a pair -- each sends the two
 // partial sums of the OTHER output row through LDS (32 KB, the V buffers are free by then) and finishes its own row: wave & 1
@@ -27,6 +27,7 @@
 // sums and the flat [cout][y * Wp + x] output layout are those of conv_common.h's conv_epilogue_flat, so every consumer is
 // unchanged.  fp32 throughout; the transforms' constants are 0, +-1, +-1/2: max |delta| vs the direct kernel ~1e-6 relative.
 #include <algorithm>
+#include <type_traits>
 
 #include "conv_common.h"
 
@@ -46,77 +47,115 @@ __device__ __forceinline__ void wbarrier() {
     asm volatile("" ::: "memory");
 }
 
+struct WinoArgs {
+    ConvArgs a;
+    const float* U; long u_set_stride;
+    int nchunk, nks_last, RXn, RYn, ncp, ntiles;
+    int probe;           // ablation bits (TTC_WINO_PROBE, timing only -- results are wrong): 1 every tile stages tile 0's inputs, 2 no output
+                         // stores, 4 no input transform, 8 no A-operand refills, 16 no staging loads, 32 no epilogue, 64 no mid-chunk barrier / LDS stage store, 128 no chunk-start barrier
+};
+
 template <int NCB, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs a, const float* __restrict__ Uall, long u_set_stride, int nchunk, int nks_last,
-                                                        int RXn, int RYn, int ncp) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
+    // Persistent loop + ~60 dwords of arguments: read directly, hipcc keeps every field live in SGPRs across the whole walk (measured:
+    // 154 SGPR spills, which land in VGPR lanes and push the kernel into scratch).  The arguments are re-read from the kernarg
+    // segment (scalar loads, constant cache) where they are used, through a pointer the optimiser cannot see through
+    // (the same device as conv3x3_h16.hip).
+    typedef const __attribute__((address_space(4))) WinoArgs* KArgs;
+    const KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    auto args = [&]() { KArgs q = kp; asm volatile("" : "+s"(q)); return q; };
+    const int nchunk = args()->nchunk;
+    const int RXn = args()->RXn, RYn = args()->RYn;
+    const int probe = args()->probe;
     constexpr int TB = 2 / NCB;                  // tile blocks (of 32 tiles) per workgroup
     constexpr int NT = 32 * TB;                  // tiles per workgroup
     constexpr int RTY = 4 * TB;                  // tile rows of the region
     constexpr int IR = 2 * RTY + 2;              // staged rows
     constexpr int INE = kWCK * IR * kIC;         // floats of one staged chunk
-    constexpr int NE = (INE + 255) / 256;        // staging elements per thread
+    constexpr int INE2 = INE / 2;                // ... as float2
+    constexpr int NE = (INE2 + 255) / 256;       // staging pairs per thread
     constexpr int VBUF = 16 * 2 * NT * 4;        // floats of one V buffer
+    constexpr int EXF = 2 * 2 * 16 * 2 * 64;     // floats of the output-transform exchange: [pair][sender][r][jj][lane] = 32 KB
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* in_tile = smem;                       // [8][IR][18]
     float* Vb = smem + ((INE + 3) & ~3);         // [2][16 xi][2 k-half][NT][4]
+    float* exx = Vb + 2 * VBUF;                  // TB == 1 only: the second half of the exchange buffer (the first is the idle V buffer)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xh = wave & 1, oth = wave >> 1;
     const int cbw = NCB == 2 ? oth : 0, tbw = NCB == 2 ? 0 : oth;
     const int tcol = lane & 31, hsel = lane >> 5;
-
-    // XCD-aware work order (conv_common.h tile_index): consecutive ids of one XCD = neighbouring regions
-    int lid;
-    {
-        const int G = gridDim.x, id = blockIdx.x;
-        const int per = G >> 3, rem = G & 7, xcd = id & 7, slot = id >> 3;
-        lid = xcd * per + (xcd < rem ? xcd : rem) + slot;
-    }
-    const int rx = lid % RXn;
-    int rest = lid / RXn;
-    const int cp = rest % ncp; rest /= ncp;
-    const int ry = rest % RYn;
-    const int n = rest / RYn;
-    const int set = n / a.n_per_set, nn = n - set * a.n_per_set;
-
-    const int Wp = a.Wp, Hp = a.Hp, H = Hp - 2, W = Wp - 2;
+    const int Wp = args()->a.Wp, Hp = args()->a.Hp, H = Hp - 2, W = Wp - 2;
     const int plane = Hp * Wp;
-    const float* seg0 = a.seg[0].base + (long)nn * a.seg[0].stride_n + a.seg[0].set_off[set];
-    const float* seg1 = a.seg[1].C > 0 ? a.seg[1].base + (long)nn * a.seg[1].stride_n + a.seg[1].set_off[set] : seg0;
-    const int C0 = a.seg[0].C, Cin = a.Cin;
-    const float* aux = a.aux ? a.aux + (long)set * a.aux_set_stride : nullptr;
-    // U: [set][cout block][chunk][xi][k-half][cout 32][4 k-steps]
-    const float4* Uw = reinterpret_cast<const float4*>(Uall + (long)set * u_set_stride) + ((long)(cp * NCB + cbw) * nchunk) * (16 * 2 * 32)
-                       + hsel * 32 + tcol;
+    const int T = nchunk;
 
-    // ---- staging geometry: element e = tid + 256 k of the [8][IR][18] chunk image
-    const int y0 = ry * (2 * RTY), x0 = rx * (2 * kRTX);
-    int goff[NE];                                 // offset inside the plane (clamped into it) | channel << 24
+    // PERSISTENT walk (grid = the resident set, 2 workgroups per CU): workgroup id -> (id % 8) owns a contiguous slice of the logical
+    // tile list and the workgroups of one XCD step through it together with stride nx, so neighbouring regions (shared halos, the
+    // same inputs for the next cout pair) meet in that XCD's L2.  The chunk stream runs ACROSS tiles: during the last chunks of a
+    // tile the first chunks of the workgroup's next tile are already requested / staged / transformed, so a tile's start-up (two
+    // dependent memory round trips, measured ~6 us per tile in the one-tile-per-workgroup form) happens under matrix work.
+    const int P = gridDim.x, xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
+    const int nx = (P >> 3) + (xcd < (P & 7) ? 1 : 0);
+    const int ntiles = args()->ntiles;
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int tcnt = per + (xcd < rem ? 1 : 0), tstart = xcd * per + (xcd < rem ? xcd : rem);
+    if (wslot >= tcnt) return;
+
+    struct TileS {                               // what staging / operand loads / the epilogue need to know about a tile
+        const float* seg0; const float* seg1;
+        const float4* uw;                        // this lane's A operands: [chunk][xi] at stride 64
+        int goff[NE];                            // staging pairs: offset inside the plane (clamped into it) | channel << 24
+        int n, rx, ry, cp, set;
+    };
+    auto tile_of = [&](int lid) {
+        TileS t;
+        const KArgs ka = args();
+        const int ncp = ka->ncp;
+        t.rx = lid % RXn;
+        int rest = lid / RXn;
+        t.cp = rest % ncp; rest /= ncp;
+        t.ry = rest % RYn;
+        t.n = rest / RYn;
+        t.set = t.n / ka->a.n_per_set;
+        const int nn = t.n - t.set * ka->a.n_per_set;
+        t.seg0 = ka->a.seg[0].base + (long)nn * ka->a.seg[0].stride_n + ka->a.seg[0].set_off[t.set];
+        t.seg1 = ka->a.seg[1].C > 0 ? ka->a.seg[1].base + (long)nn * ka->a.seg[1].stride_n + ka->a.seg[1].set_off[t.set] : t.seg0;
+        // U: [set][cout block][chunk][xi][k-half][cout 32][4 k-steps]
+        t.uw = reinterpret_cast<const float4*>(ka->U + (long)t.set * ka->u_set_stride) + ((long)(t.cp * NCB + cbw) * T) * (16 * 2 * 32) + hsel * 32 + tcol;
+        const int y0 = (probe & 1) ? 0 : t.ry * (2 * RTY), x0 = (probe & 1) ? 0 : t.rx * (2 * kRTX);
+        if (probe & 1) { t.seg0 = ka->a.seg[0].base; t.seg1 = ka->a.seg[1].C > 0 ? ka->a.seg[1].base : t.seg0; }
 #pragma unroll
-    for (int k = 0; k < NE; ++k) {
-        int e = tid + 256 * k;
-        e = e < INE ? e : INE - 1;
-        const int cl = e / (IR * kIC), r2 = e - cl * (IR * kIC);
-        const int row = r2 / kIC, col = r2 - row * kIC;
-        const int yy = min(y0 + row, Hp - 1), xx = min(x0 + col, Wp - 1);
-        goff[k] = (yy * Wp + xx) | (cl << 24);
-    }
-    float g[NE];
-    auto stage_load = [&](int c) {
+        for (int k = 0; k < NE; ++k) {           // float2 element e = tid + 256 k of the [8][IR][18] chunk image (Wp is even: checked at launch)
+            int e = tid + 256 * k;
+            e = e < INE2 ? e : INE2 - 1;
+            const int cl = e / (IR * (kIC / 2)), r2 = e - cl * (IR * (kIC / 2));
+            const int row = r2 / (kIC / 2), col = 2 * (r2 - row * (kIC / 2));
+            const int yy = min(y0 + row, Hp - 1), xx = min(x0 + col, Wp - 2);
+            t.goff[k] = (yy * Wp + xx) | (cl << 24);
+        }
+        return t;
+    };
+
+    // a chunk's inputs are requested one chunk before they are written to LDS (memory returns in order: the A-operand loads that are
+    // interleaved with the MFMAs bound the useful lead to one chunk anyway)
+    float2 g[NE];
+    auto stage_load = [&](const TileS& t, int c) {
+        if (probe & 16) return;
+        const int Cin = args()->a.Cin, C0 = args()->a.seg[0].C;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            int ci = c * kWCK + (goff[k] >> 24);
+            int ci = c * kWCK + (t.goff[k] >> 24);
             ci = ci < Cin ? ci : Cin - 1;         // pad channels meet zero weights: any finite plane will do
-            const float* src = ci < C0 ? seg0 + (long)ci * plane : seg1 + (long)(ci - C0) * plane;
-            g[k] = src[goff[k] & 0xffffff];
+            const float* src = ci < C0 ? t.seg0 + (long)ci * plane : t.seg1 + (long)(ci - C0) * plane;
+            g[k] = *reinterpret_cast<const float2*>(src + (t.goff[k] & 0xffffff));
         }
     };
     auto stage_store = [&]() {
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             const int e = tid + 256 * k;
-            if (e < INE) in_tile[e] = g[k];
+            if (e < INE2) reinterpret_cast<float2*>(in_tile)[e] = g[k];
         }
     };
     // ---- input transform: thread -> (k-step j, tile, k-half hs) of each tile block: channel 2 j + hs of the chunk
@@ -155,184 +194,255 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs a, const float* 
     };
 
     f32x16 acc[8];                                // xi_l = 2 a + bl  <->  xi = 4 a + 2 xh + bl
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-
-    // A-operand ring: slot i & 3 holds (chunk, xi_l = i & 7) of the running sequence i = 8 c + xi_l; loads run 3 ahead
-    float4 aring[4];
-    const int total = 8 * nchunk;
-    auto a_load = [&](int i) {
-        const int c = i >> 3, xl = i & 7;
-        const int xi = 4 * (xl >> 1) + 2 * xh + (xl & 1);
-        return Uw[((long)c * 16 + xi) * (2 * 32)];
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     };
-#pragma unroll
-    for (int i = 0; i < 3; ++i) aring[i] = a_load(i < total ? i : total - 1);
+    // A operands: one 16-byte load per (xi, lane) and chunk straight from global memory (L2).  Slot xl is refilled with the NEXT
+    // chunk's operand (of this tile or, at a tile's last chunk, of the next one) right after its four MFMAs have issued -- a lead
+    // of seven xi (~ one chunk of matrix time) in 32 registers.
+    float4 A[8];
+    auto a_load1 = [&](const float4* uw, int c, int xl) { return uw[((long)c * 16 + 4 * (xl >> 1) + 2 * xh + (xl & 1)) * (2 * 32)]; };
 
-    // ---- prologue
-    stage_load(0);
+    int tk = wslot;
+    TileS cur = tile_of(tstart + tk);
+    bool has_next = tk + nx < tcnt;
+    TileS nxt = tile_of(tstart + (has_next ? tk + nx : tk));
+
+    // ---- start-up of the workgroup's first tile (T >= 3: checked at launch)
+#pragma unroll
+    for (int xl = 0; xl < 8; ++xl) A[xl] = a_load1(cur.uw, 0, xl);
+    stage_load(cur, 0);
     stage_store();
     __syncthreads();
-    if (nchunk > 1) stage_load(1);
+    stage_load(cur, 1);
     transform(0);
     __syncthreads();
-    if (nchunk > 1) stage_store();
+    stage_store();
+    stage_load(cur, 2);
 
     const float4* Vr = reinterpret_cast<const float4*>(Vb) + (hsel * NT + tbw * 32 + tcol);
-    for (int c = 0; c < nchunk; ++c) {
-        wbarrier();                               // V[c & 1] is complete, in_tile holds chunk c + 1
-        const bool more2 = c + 2 < nchunk, more1 = c + 1 < nchunk;
-        if (more2) stage_load(c + 2);
-        if (more1) transform((c + 1) & 1);
-        const float4* Vc = Vr + (c & 1) * (VBUF / 4);
-        const int nks = (c == nchunk - 1) ? nks_last : 4;
-        auto mfma_xi = [&](int xl) {
-            const int i = 8 * c + xl;
-            const int xi = 4 * (xl >> 1) + 2 * xh + (xl & 1);
-            const float4 b = Vc[xi * (2 * NT)];
-            const float4 av = aring[xl & 3];
-            const int inext = i + 3;
-            aring[(xl + 3) & 3] = a_load(inext < total ? inext : total - 1);
-            acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[xl], 0, 0, 0);
-            if (nks > 1) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[xl], 0, 0, 0);
-            if (nks > 2) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc[xl], 0, 0, 0);
-            if (nks > 3) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc[xl], 0, 0, 0);
+    int par = 0;                                  // V buffer of the running chunk: the chunk counter of the whole walk, mod 2
+
+    // one chunk c of the running tile; LAST = its final chunk (possibly fewer than four k-steps).  Stream position c + k of the
+    // running tile is chunk c + k - T of the next tile once it passes the end.  The B operand of xi + 1 is fetched before the MFMAs
+    // of xi issue; V[par] stays valid for the whole chunk, so that look-ahead also crosses the mid-chunk barrier.
+    auto chunk = [&](int c, auto LASTC) {
+        constexpr bool last = decltype(LASTC)::value;
+        if (!(probe & 128)) wbarrier();           // V[par] is complete, in_tile holds stream position c + 1
+        const float4* Vc = Vr + par * (VBUF / 4);
+        auto bload = [&](int xl) { return Vc[(4 * (xl >> 1) + 2 * xh + (xl & 1)) * (2 * NT)]; };
+        // MFMAs run in PAIRS of xi with their k-steps interleaved (x0 k0, x1 k0, x0 k1, ...): consecutive matrix instructions never
+        // share an accumulator, so the loads / transform arithmetic the compiler slots in between them do not land inside a
+        // dependent accumulate chain (MI355X_MICROARCH.md: one extra issue state between two MFMAs on the SAME accumulator costs
+        // +43 cycles, between different accumulators ~6)
+        float4 bq[2][2];
+        bq[0][0] = bload(0); bq[0][1] = bload(1);
+        const bool in1 = c + 1 < T, in2 = c + 2 < T, in3 = c + 3 < T;
+        if ((in1 || has_next) && !(probe & 4)) transform(par ^ 1);
+        const int nks = last ? args()->nks_last : 4;
+        const float4* uwn = in1 ? cur.uw : nxt.uw;
+        const int cn = in1 ? c + 1 : 0;
+        const bool refill = (in1 || has_next) && !(probe & 8);
+        auto mfma_pair = [&](int pp, const float4 (&b)[2]) {
+            const int x0 = 2 * pp, x1 = 2 * pp + 1;
+            const float4 a0 = A[x0], a1 = A[x1];
+            acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0].x, acc[x0], 0, 0, 0);
+            acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[1].x, acc[x1], 0, 0, 0);
+            if (!last || nks > 1) {
+                acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[0].y, acc[x0], 0, 0, 0);
+                acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[1].y, acc[x1], 0, 0, 0);
+            }
+            if (!last || nks > 2) {
+                acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b[0].z, acc[x0], 0, 0, 0);
+                acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b[1].z, acc[x1], 0, 0, 0);
+            }
+            if (!last || nks > 3) {
+                acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b[0].w, acc[x0], 0, 0, 0);
+                acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b[1].w, acc[x1], 0, 0, 0);
+            }
+            if (refill) { A[x0] = a_load1(uwn, cn, x0); A[x1] = a_load1(uwn, cn, x1); }
         };
 #pragma unroll
-        for (int xl = 0; xl < 4; ++xl) mfma_xi(xl);
-        wbarrier();                               // every transform of chunk c + 1 has read in_tile
-        if (more2) stage_store();
-#pragma unroll
-        for (int xl = 4; xl < 8; ++xl) mfma_xi(xl);
-    }
-
-    // ---- output transform.  acc[2 a + bl] = M[a][b = 2 xh + bl]
-    //   T0[b] = M0b + M1b + M2b, T1[b] = M1b - M2b - M3b;  Y[i][0] = Ti0 + Ti1 + Ti2, Y[i][1] = Ti1 - Ti2 - Ti3
-    //   xh = 0 holds b = 0, 1: p[i] = (Ti0 + Ti1, Ti1);  xh = 1 holds b = 2, 3: p[i] = (Ti2, -Ti2 - Ti3);  Y[i] = p0[i] + p1[i]
-    float keep[16][2], give[16][2];               // own output row (i = xh) | the other row, for the partner wave
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float T[2][2];
-#pragma unroll
-        for (int bl = 0; bl < 2; ++bl) {
-            T[0][bl] = acc[0 + bl][r] + acc[2 + bl][r] + acc[4 + bl][r];
-            T[1][bl] = acc[2 + bl][r] - acc[4 + bl][r] - acc[6 + bl][r];
+        for (int pp = 0; pp < 2; ++pp) {
+            bq[(pp + 1) & 1][0] = bload(2 * pp + 2); bq[(pp + 1) & 1][1] = bload(2 * pp + 3);
+            mfma_pair(pp, bq[pp & 1]);
         }
-        float p[2][2];
+        if (!(probe & 64)) wbarrier();            // every transform of stream position c + 1 has read in_tile
+        if ((in2 || has_next) && !(probe & 64)) stage_store();   // stream position c + 2, requested one chunk ago
+        if (in3) stage_load(cur, c + 3);
+        else if (has_next) stage_load(nxt, c + 3 - T);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            p[i][0] = xh == 0 ? T[i][0] + T[i][1] : T[i][0];
-            p[i][1] = xh == 0 ? T[i][1] : -T[i][0] - T[i][1];
+        for (int pp = 2; pp < 4; ++pp) {
+            if (pp + 1 < 4) { bq[(pp + 1) & 1][0] = bload(2 * pp + 2); bq[(pp + 1) & 1][1] = bload(2 * pp + 3); }
+            mfma_pair(pp, bq[pp & 1]);
         }
-        keep[r][0] = xh == 0 ? p[0][0] : p[1][0]; keep[r][1] = xh == 0 ? p[0][1] : p[1][1];
-        give[r][0] = xh == 0 ? p[1][0] : p[0][0]; give[r][1] = xh == 0 ? p[1][1] : p[0][1];
-    }
-    __syncthreads();                              // the V buffers are free
-    float* ex = Vb + (oth * 2) * (16 * 2 * 64);   // [pair][sender xh][r][jj][lane]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        ex[xh * (16 * 2 * 64) + (r * 2 + 0) * 64 + lane] = give[r][0];
-        ex[xh * (16 * 2 * 64) + (r * 2 + 1) * 64 + lane] = give[r][1];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        keep[r][0] += ex[(xh ^ 1) * (16 * 2 * 64) + (r * 2 + 0) * 64 + lane];
-        keep[r][1] += ex[(xh ^ 1) * (16 * 2 * 64) + (r * 2 + 1) * 64 + lane];
-    }
+        par ^= 1;
+    };
 
-    // ---- epilogue op, GroupNorm partial sums, stores.  This wave: output row 2 ty + xh, columns 2 tx, 2 tx + 1 of its 32 tiles
-    const int tile = tbw * 32 + tcol;
-    const int ty = ry * RTY + (tile >> 3), tx = rx * kRTX + (tile & 7);
-    const int y = 2 * ty + xh, xa = 2 * tx;
-    const bool vrow = y < H;
-    const bool v0 = vrow && xa < W, v1 = vrow && xa + 1 < W;
-    const int cbase = (cp * NCB + cbw) * 32;
-    if (EPI == EPI_SSE) {
-        float dot0 = 0.f, dot1 = 0.f;
+    for (;;) {
+        zero_acc();
+        for (int c = 0; c + 1 < T; ++c) chunk(c, std::false_type{});
+        chunk(T - 1, std::true_type{});
+
+        // ---- output transform.  acc[2 a + bl] = M[a][b = 2 xh + bl]
+        //   T0[b] = M0b + M1b + M2b, T1[b] = M1b - M2b - M3b;  Y[i][0] = Ti0 + Ti1 + Ti2, Y[i][1] = Ti1 - Ti2 - Ti3
+        //   xh = 0 holds b = 0, 1: p[i] = (Ti0 + Ti1, Ti1);  xh = 1 holds b = 2, 3: p[i] = (Ti2, -Ti2 - Ti3);  Y[i] = p0[i] + p1[i]
+        // The wave keeps output row i = xh and hands the partial sums of the other row to its partner through LDS: the V buffer the
+        // last chunk has just been multiplied from (`par` after the flip is the one that holds the NEXT tile's first chunk; the
+        // other one is idle until the transform of the next tile's second chunk, two barriers away) -- plus, for the 32-tile
+        // form whose V buffers are 16 KB, a second 16 KB region.
+        // exchange layout [r >> 3][pair][sender][r & 7][jj][lane]: one base register per half and direction, every access a
+        // compile-time offset from it (64 separately formed addresses were hoisted out of the tile walk as SGPR pairs and spilled)
+        float* ex0 = Vb + (par ^ 1) * VBUF;
+        float* ex1 = TB == 2 ? ex0 + EXF / 2 : exx;
+        const int exo_w = ((oth * 2 + xh) * 8 * 2) * 64 + lane, exo_r = ((oth * 2 + (xh ^ 1)) * 8 * 2) * 64 + lane;
+        float* exw[2] = {ex0 + exo_w, ex1 + exo_w};
+        const float* exr[2] = {ex0 + exo_r, ex1 + exo_r};
+        float keep[16][2];                        // own output row (i = xh)
+        if (probe & 32) {                         // ablation: no output transform / epilogue at all
+            if (!has_next) break;
+            tk += nx; cur = nxt; has_next = tk + nx < tcnt;
+            if (has_next) nxt = tile_of(tstart + tk + nx);
+            continue;
+        }
+        __syncthreads();                          // every wave has finished reading that V buffer
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float k1 = aux[(r & 3) + 8 * (r >> 2) + 4 * hsel];
-            dot0 += k1 * keep[r][0]; dot1 += k1 * keep[r][1];
-        }
-        dot0 += __shfl_xor(dot0, 32); dot1 += __shfl_xor(dot1, 32);
-        const float g0 = sigmoidf_(dot0), g1 = sigmoidf_(dot1);
+            float Tt[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { keep[r][0] *= g0; keep[r][1] *= g1; }
-    }
-    if (EPI == EPI_SWISH) {
-        float r0 = 1.0f, r1 = 1.0f;
-        if (a.same_pad) {
-            const bool ey = (y == 0) || (y == H - 1);
-            const bool ex0 = (xa == 0) || (xa == W - 1), ex1 = (xa + 1 == W - 1);
-            r0 = (ey && ex0) ? 2.25f : ((ey || ex0) ? 1.5f : 1.0f);
-            r1 = (ey && ex1) ? 2.25f : ((ey || ex1) ? 1.5f : 1.0f);
+            for (int bl = 0; bl < 2; ++bl) {
+                Tt[0][bl] = acc[0 + bl][r] + acc[2 + bl][r] + acc[4 + bl][r];
+                Tt[1][bl] = acc[2 + bl][r] - acc[4 + bl][r] - acc[6 + bl][r];
+            }
+            float p[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                p[i][0] = xh == 0 ? Tt[i][0] + Tt[i][1] : Tt[i][0];
+                p[i][1] = xh == 0 ? Tt[i][1] : -Tt[i][0] - Tt[i][1];
+            }
+            keep[r][0] = xh == 0 ? p[0][0] : p[1][0]; keep[r][1] = xh == 0 ? p[0][1] : p[1][1];
+            exw[r >> 3][((r & 7) * 2 + 0) * 64] = xh == 0 ? p[1][0] : p[0][0];
+            exw[r >> 3][((r & 7) * 2 + 1) * 64] = xh == 0 ? p[1][1] : p[0][1];
         }
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float u0 = keep[r][0] * r0, u1 = keep[r][1] * r1;
-            keep[r][0] = u0 * sigmoidf_(u0); keep[r][1] = u1 * sigmoidf_(u1);
+            keep[r][0] += exr[r >> 3][((r & 7) * 2 + 0) * 64];
+            keep[r][1] += exr[r >> 3][((r & 7) * 2 + 1) * 64];
         }
-    }
-    if (a.stats) {
-        float red[8];
+
+        // ---- epilogue op, GroupNorm partial sums, stores.  This wave: output row 2 ty + xh, columns 2 tx, 2 tx + 1 of its 32 tiles
+        {
+            const KArgs ka = args();
+            struct { const float* aux; long aux_set_stride; float* stats; float* out; long out_stride_n, out_plane; int Cout, same_pad; } a =
+                {ka->a.aux, ka->a.aux_set_stride, ka->a.stats, ka->a.out, ka->a.out_stride_n, ka->a.out_plane, ka->a.Cout, ka->a.same_pad};
+            const float* aux = a.aux ? a.aux + (long)cur.set * a.aux_set_stride : nullptr;
+            const int tile = tbw * 32 + tcol;
+            const int ty = cur.ry * RTY + (tile >> 3), tx = cur.rx * kRTX + (tile & 7);
+            const int y = 2 * ty + xh, xa = 2 * tx;
+            const bool vrow = y < H;
+            const bool v0 = vrow && xa < W, v1 = vrow && xa + 1 < W;
+            const int cbase = (cur.cp * NCB + cbw) * 32;
+            if (EPI == EPI_SSE) {
+                float dot0 = 0.f, dot1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float s = 0.f, q = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const float k1 = aux[(r & 3) + 8 * (r >> 2) + 4 * hsel];
+                    dot0 += k1 * keep[r][0]; dot1 += k1 * keep[r][1];
+                }
+                dot0 += __shfl_xor(dot0, 32); dot1 += __shfl_xor(dot1, 32);
+                const float g0 = sigmoidf_(dot0), g1 = sigmoidf_(dot1);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const float u0 = keep[4 * k + rr][0], u1 = keep[4 * k + rr][1];
-                if (v0) { s += u0; q += u0 * u0; }
-                if (v1) { s += u1; q += u1 * u1; }
+                for (int r = 0; r < 16; ++r) { keep[r][0] *= g0; keep[r][1] *= g1; }
             }
-            red[2 * k] = s; red[2 * k + 1] = q;
-        }
-        half_wave_sums(red);
-        if (tcol == 31) {
-            constexpr int SW = 4 / NCB;            // waves that contribute to one cout block of a region
-            const long slots = (long)RXn * RYn * SW;
-            const int slot = (ry * RXn + rx) * SW + (NCB == 2 ? xh : wave);
-            float2* base = reinterpret_cast<float2*>(a.stats) + (long)n * (a.Cout / 4) * slots + slot;
+            if (EPI == EPI_SWISH) {
+                float r0 = 1.0f, r1 = 1.0f;
+                if (a.same_pad) {
+                    const bool ey = (y == 0) || (y == H - 1);
+                    const bool ex0b = (xa == 0) || (xa == W - 1), ex1b = (xa + 1 == W - 1);
+                    r0 = (ey && ex0b) ? 2.25f : ((ey || ex0b) ? 1.5f : 1.0f);
+                    r1 = (ey && ex1b) ? 2.25f : ((ey || ex1b) ? 1.5f : 1.0f);
+                }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int quad = cbase / 4 + 2 * k + hsel;
-                if (quad * 4 < a.Cout) base[quad * slots] = make_float2(red[2 * k], red[2 * k + 1]);
+                for (int r = 0; r < 16; ++r) {
+                    float u0 = keep[r][0] * r0, u1 = keep[r][1] * r1;
+                    keep[r][0] = u0 * sigmoidf_(u0); keep[r][1] = u1 * sigmoidf_(u1);
+                }
+            }
+            if (a.stats) {
+                float red[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float sm_ = 0.f, q = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const float u0 = keep[4 * k + rr][0], u1 = keep[4 * k + rr][1];
+                        if (v0) { sm_ += u0; q += u0 * u0; }
+                        if (v1) { sm_ += u1; q += u1 * u1; }
+                    }
+                    red[2 * k] = sm_; red[2 * k + 1] = q;
+                }
+                half_wave_sums(red);
+                if (tcol == 31) {
+                    constexpr int SW = 4 / NCB;    // waves that contribute to one cout block of a region
+                    const long slots = (long)RXn * RYn * SW;
+                    const int slot = (cur.ry * RXn + cur.rx) * SW + (NCB == 2 ? xh : wave);
+                    float2* base = reinterpret_cast<float2*>(a.stats) + (long)cur.n * (a.Cout / 4) * slots + slot;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int quad = cbase / 4 + 2 * k + hsel;
+                        if (quad * 4 < a.Cout) base[quad * slots] = make_float2(red[2 * k], red[2 * k + 1]);
+                    }
+                }
+            }
+            float* outn = a.out + (long)cur.n * a.out_stride_n;
+            const long opix = (long)y * Wp + xa;
+            const bool vec = (((a.out_plane | (long)Wp) & 1L) == 0) && v1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (co >= a.Cout || (probe & 2)) continue;
+                float* o = outn + (long)co * a.out_plane + opix;
+                if (vec) *reinterpret_cast<float2*>(o) = make_float2(keep[r][0], keep[r][1]);
+                else {
+                    if (v0) o[0] = keep[r][0];
+                    if (v1) o[1] = keep[r][1];
+                }
             }
         }
-    }
-    float* outn = a.out + (long)n * a.out_stride_n;
-    const long opix = (long)y * Wp + xa;
-    const bool vec = (((a.out_plane | (long)Wp) & 1L) == 0) && v1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-        if (co >= a.Cout) continue;
-        float* o = outn + (long)co * a.out_plane + opix;
-        if (vec) *reinterpret_cast<float2*>(o) = make_float2(keep[r][0], keep[r][1]);
-        else {
-            if (v0) o[0] = keep[r][0];
-            if (v1) o[1] = keep[r][1];
-        }
+        if (!has_next) break;
+        tk += nx;
+        cur = nxt;
+        has_next = tk + nx < tcnt;
+        if (has_next) nxt = tile_of(tstart + tk + nx);
     }
 }
 
 template <int NCB, int EPI>
 hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t s) {
     constexpr int TB = 2 / NCB, NT = 32 * TB, IR = 2 * 4 * TB + 2;
-    const size_t lds = (size_t)(((kWCK * IR * kIC + 3) & ~3) + 2 * 16 * 2 * NT * 4) * sizeof(float);
+    const size_t lds = (size_t)(((kWCK * IR * kIC + 3) & ~3) + 2 * 16 * 2 * NT * 4 + (TB == 1 ? 16 * 2 * NT * 4 : 0)) * sizeof(float);
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_wino<NCB, EPI>, lds); e != hipSuccess) return e;
     const int H = a.Hp - 2, W = a.Wp - 2;
     const int TX = (W + 1) / 2, TY = (H + 1) / 2;
     const int RXn = (TX + kRTX - 1) / kRTX, RYn = (TY + 4 * TB - 1) / (4 * TB);
     const int ncp = (a.Cout + 32 * NCB - 1) / (32 * NCB);
-    if ((long)a.Hp * a.Wp >= (1L << 24)) return hipErrorInvalidValue;
+    if ((long)a.Hp * a.Wp >= (1L << 24) || (a.Wp & 1) || pw.nchunk_w < 3) return hipErrorInvalidValue;
     const int rem = a.Cin - kWCK * (pw.nchunk_w - 1);
     const int nks_last = (rem + 1) / 2;
-    hipLaunchKernelGGL((conv3x3_wino<NCB, EPI>), dim3((unsigned)((long)RXn * RYn * ncp * n)), dim3(256), lds, s, a, pw.d_wu, pw.set_stride_w,
-                       pw.nchunk_w, nks_last, RXn, RYn, ncp);
+    const long ntiles = (long)RXn * RYn * ncp * n;
+    static const int forced = [] { const char* e = getenv("TTC_WINO_PERSIST"); return e ? atoi(e) : -1; }();   // probe: 0 = one workgroup per tile
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long resident = forced >= 0 ? forced : 2L * cus;
+    const long grid = resident > 0 ? std::min(ntiles, resident) : ntiles;
+    static const int probe = [] { const char* e = getenv("TTC_WINO_PROBE"); return e ? atoi(e) : 0; }();
+    const WinoArgs wa{a, pw.d_wu, pw.set_stride_w, pw.nchunk_w, nks_last, RXn, RYn, ncp, (int)ntiles, probe};
+    hipLaunchKernelGGL((conv3x3_wino<NCB, EPI>), dim3((unsigned)grid), dim3(256), lds, s, wa);
     return hipGetLastError();
 }
 

@@ -1,0 +1,5 @@
+# ablation of the Winograd fp32 kernel (TTC_WINO_PROBE bits: see conv3x3_wino.hip WinoArgs.probe); timing only
+cd /root/repo
+for p in ${WINO_PROBES:-0 30}; do
+  echo "== probe $p"; TTC_WINO_PROBE=$p timeout 120 python tools/gpu_probe.py 172 4 36 fp32 2>&1 | grep -E "max|forward|conv_gates|conv_cand|up2 |conv_concat|conv_median"
+done

@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--smooth", action="store_true", help="spatially smooth inputs instead of white noise")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--two-product", action="store_true",
+                    help="round 4: the two 2-product forms of the hi/lo engine per layer -- x_hi*(w_hi+w_lo) = 16-bit activations, exact "
+                         "weights; (x_hi+x_lo)*w_hi = exact activations, 16-bit weights -- instead of the 1-product table")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     w = M.synth_weights(a.seed)
@@ -112,6 +115,15 @@ def main():
         print(f"  {tag:46s} max {d.max():.2e}  rms {np.sqrt((d ** 2).mean()):.2e}  p99.9 {np.quantile(d, 0.999):.2e}", flush=True)
         return d.max()
 
+    if a.two_product:
+        for m in ("f16", "bf16"):
+            print(f"  -- {m}: 2-product forms (the dropped cross term is the one with the rounded operand's lo part)")
+            run(f"all layers {m} x, exact w   [x_hi*w_hi + x_hi*w_lo]", {l: (m, "f32") for l in LAYERS})
+            run(f"all layers exact x, {m} w   [x_hi*w_hi + x_lo*w_hi]", {l: ("f32", m) for l in LAYERS})
+            for l in LAYERS:
+                run(f"only {l}: {m} x, exact w", {l: (m, "f32")})
+                run(f"only {l}: exact x, {m} w", {l: ("f32", m)})
+        return
     for m in ("f16", "bf16"):
         run(f"all layers {m} x {m}", {l: (m, m) for l in LAYERS})
     run("all layers f16 x exact-w", {l: ("f16", "f32") for l in LAYERS})
