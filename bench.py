@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3        # v_mfma_f32_32x32x2_f32, dense
 H16_MFMA_PEAK_TF = 2500.0        # v_mfma_f32_32x32x16_{f16,bf16}, dense
 DTYPES = {
-    "fp32": "f32 (fp32 MFMA, exact fp32 FMA chains)",
+    "fp32": "f32 (fp32 MFMA; GroupNorm-layer convs in the Winograd F(2x2,3x3) form, fp32 transforms)",
     "fp16": "fp16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
     "bf16": "bf16 hi+lo operand pairs, 3 MFMA products per term, f32 accumulate / GroupNorm / state",
 }
@@ -59,11 +59,16 @@ def model_flops(W, L):
                          + 128 * 64 * u3 * u3 + 128 * 64 * o * o) + 2.0 * 64 * o * o)
 
 
+def winograd_on():
+    """the fp32 engine runs its GroupNorm layers in the Winograd F(2x2, 3x3) form unless TTC_WINOGRAD=0 (conv3x3_mfma.hip conv_use_wino)"""
+    return os.environ.get("TTC_WINOGRAD", "1") != "0"
+
+
 def pmc_traffic(precision, win):
     """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the timed
     process).  Only valid for the configuration the counters were collected on."""
-    for name in {"fp32": ("r03_pmc_conv_f32_gates.json", "r01_c_pmc_conv_gates.json"),
-                 "fp16": ("r03_pmc_conv_h16_gates.json", "r02_pmc_conv_h16_gates.json")}.get(precision, ()):
+    for name in {"fp32": ("r04_pmc_conv_f32_gates.json",) if winograd_on() else ("r03_pmc_conv_f32_gates.json",),
+                 "fp16": ("r04_pmc_conv_h16_gates.json", "r03_pmc_conv_h16_gates.json")}.get(precision, ()):
         p = os.path.join(ROOT, "profiles", name)
         if win == 172 and os.path.exists(p):
             with open(p) as f:
@@ -77,6 +82,20 @@ def roofline(precision, win, n_windows, gates_ms, gates_n):
     flops = conv_gates_flops(win, n_windows)
     ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
     traffic, src = pmc_traffic(precision, win)
+    if precision == "fp32" and winograd_on():
+        # Winograd F(2x2, 3x3): 16 / 36 of the direct form's multiply-accumulates.  `achieved` stays the ALGORITHMIC rate
+        # (2 * 9 * Cin * Cout flops per output pixel / launch time: what SURVEY 8d prices), so it may exceed `peak`; the rate
+        # of the matrix instructions the kernel actually issues is reported beside it.
+        tiles = 2 * n_windows * (-(-(win // 2) // 8)) * (-(-(win // 2) // 4))           # 8 x 4-tile regions per plane, both directions
+        mfmas = tiles * 4 * (6 * 32 + 8)                                               # 4 waves x (6 full chunks x 32 + 1 k-step x 8) for Cin = 49
+        issued = mfmas * 2.0 * 32 * 32 * 2
+        return {"kernel": "conv3x3_wino<NCB=2,EPI_RAW> (ConvGRU gates, 49->64, both directions; Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
+                "traffic": traffic, "traffic_source": src, "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops,
+                "mfma_flops_issued_per_launch": issued,
+                "mfma_issue_frac": issued / (gates_ms * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12) if gates_ms > 0 else 0.0,
+                "note_winograd": "achieved / frac count the algorithmic 2*9*Cin*Cout flops per pixel; the kernel issues 4/9 of them "
+                                 "(+ region / channel padding): mfma_issue_frac is the matrix pipe's own utilisation"}
     if precision == "fp32":
         return {"kernel": "conv3x3_f32<CK=10,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)",
                 "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,

@@ -54,7 +54,7 @@ def test_aligned_mosaic_matches_reference(sess):
     mos = sess.ctx.aligned_mosaic(torch.from_numpy(tiles).cuda(), w).cpu().numpy()
     err = np.abs(mos[::2, ::2] - g["mosaic_sub"])
     print(f"[parity] aligned mosaic vs reference: max|d| = {err.max():.3e}")
-    assert err.max() < 2e-5
+    assert err.max() < 2e-6                               # measured 1.8e-7
     # a date that cannot be aligned (< 1000 clear px) is switched to fully interpolated, like CR.py:679-680
     p2 = probs.copy(); p2[1] = 1.0; p2[1, :20, :20] = 0.0
     wi = G.feather_stack(p2, 20)
@@ -62,7 +62,7 @@ def test_aligned_mosaic_matches_reference(sess):
     w2 = sess.ctx.feather(p2, closing=20)
     mos2 = sess.ctx.aligned_mosaic(torch.from_numpy(tiles).cuda(), w2).cpu().numpy()
     np.testing.assert_array_equal(w2.cpu().numpy(), wi)
-    assert np.abs(mos2 - ref).max() < 2e-5
+    assert np.abs(mos2 - ref).max() < 2e-6
 
 
 def test_remove_cloud_and_shadows_reference_replay(sess):
@@ -75,7 +75,7 @@ def test_remove_cloud_and_shadows_reference_replay(sess):
     np.testing.assert_array_equal(interp, g["interp"])
     err = np.abs(out[:, ::3, ::3, :] - g["tiles_sub"])
     print(f"[parity] gap-filled tiles vs reference: max|d| = {err.max():.3e}, mean = {err.mean():.3e}")
-    assert err.max() < 5e-4 and err.mean() < 1e-6       # NNLS from Gram matrices vs scipy's QR-based nnls
+    assert err.max() < 2e-5 and err.mean() < 1e-7       # measured 1.6e-6 / 7.3e-9: NNLS from Gram matrices vs scipy's QR-based nnls
     assert rem == list(g["to_remove"])
     clear = ~(g["interp"] > 0)
     np.testing.assert_array_equal(out[clear], tiles[clear])
@@ -93,7 +93,7 @@ def test_deterministic_sampler_is_close_and_reproducible(sess):
     err = np.abs(a[:, ::3, ::3, :] - g["tiles_sub"])
     # reference sampling noise: two different seeds of the reference itself differ by about this much
     print(f"[parity] deterministic vs seeded reference: max|d| = {err.max():.3e}, rms = {np.sqrt((err**2).mean()):.3e}")
-    assert err.max() < 0.03 and np.sqrt((err ** 2).mean()) < 2e-3
+    assert err.max() < 1e-2 and np.sqrt((err ** 2).mean()) < 5e-4       # measured 1.3e-3 / 5.8e-5 (one random draw of the reference's sampler)
 
 
 @pytest.mark.parametrize("T", [2, 3, 9, 20])
@@ -111,7 +111,7 @@ def test_gapfill_date_count_range(sess, T):
     assert grem == [int(v) for v in wrem]
     err = np.abs(got - want)
     print(f"[parity] gap-fill T={T}: max|d| = {err.max():.3e}, mean = {err.mean():.3e}")
-    assert err.max() < 2e-3 and err.mean() < 1e-5
+    assert err.max() < 1e-5 and err.mean() < 1e-7       # measured <= 9.5e-7 / 3.7e-9 over T = 2 .. 20
 
 
 def test_gapfill_at_bench_size_vs_oracle_and_sampler_effect_on_probabilities():
@@ -136,12 +136,12 @@ def test_gapfill_at_bench_size_vs_oracle_and_sampler_effect_on_probabilities():
     assert list(rep_rem) == list(ref_rem)
     e = np.abs(rep - ref)
     print(f"[parity] gap-fill 618^2 T=12, replayed sampler vs oracle: max|d| = {e.max():.3e}, mean = {e.mean():.2e}")
-    assert e.max() < 5e-4 and e.mean() < 1e-6
+    assert e.max() < 5e-5 and e.mean() < 1e-7           # measured 5.9e-6 / 7.6e-9
     det, det_i, _ = job.remove_cloud_and_shadows(tiles.copy(), probs, probs, dates, pf, sess=sess, sampler="expected")
     np.testing.assert_array_equal(det_i, ref_i)
     e2 = np.abs(det - rep)
     print(f"[parity] deterministic vs replayed sampler, reflectance: max|d| = {e2.max():.3e}, rms = {np.sqrt((e2 ** 2).mean()):.2e}")
-    assert e2.max() < 0.03
+    assert e2.max() < 1e-2                             # measured 2.3e-3
     # (iii) propagate both stacks to probabilities
     raws = []
     for stack in (rep, det):
@@ -154,4 +154,4 @@ def test_gapfill_at_bench_size_vs_oracle_and_sampler_effect_on_probabilities():
     print(f"[parity] deterministic vs replayed sampler, probabilities of the whole tile: max |dprob| = {dp.max():.3e}, "
           f"p99.9 = {np.quantile(dp, 0.999):.2e}, rms = {np.sqrt((dp ** 2).mean()):.2e}")
     # the reference itself draws a different sample on every run (global stdlib RNG): this is its run-to-run spread
-    assert np.quantile(dp, 0.999) < 5e-3
+    assert np.quantile(dp, 0.999) < 3e-3              # measured 6.6e-4

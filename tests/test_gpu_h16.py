@@ -16,7 +16,8 @@ from tests.helpers import synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = [("fp16", None, 1e-4), ("fp16", 1, 1e-3), ("bf16", None, 2.5e-4)]
+# max|dprob| bounds; measured (round 4): fp16 3-product <= 4.9e-6, fp16 1-product gates <= 6.4e-4, bf16 <= 1.0e-4
+MODES = [("fp16", None, 4e-5), ("fp16", 1, 1e-3), ("bf16", None, 2.5e-4)]
 
 
 def _setup(W, L, N, seed, precision, one_term, stored=True, dtype64=True):
@@ -89,7 +90,7 @@ def test_single_step_intermediates_16bit(precision):
                             ("y_c2", "conv2", 256, c2), ("y_u2", "up2", 128, u2), ("y_u2o", "up2_out", 128, u2),
                             ("y_u3", "up3", 64, u3), ("y_out", "out", 64, o)]:
         chk(buf, raw(buf, N, C, H, H), tr["raw_" + name])
-    ok, m = _cmp("prob", out, ref[..., 0], 2.5e-4 if precision == "bf16" else 1e-4); ok or fails.append(m)
+    ok, m = _cmp("prob", out, ref[..., 0], 2.5e-4 if precision == "bf16" else 4e-5); ok or fails.append(m)      # measured 4.1e-5 / 3.8e-6
     assert not fails, "\n".join(fails)
 
 
