@@ -443,7 +443,7 @@ def main():
                 tm["write_tif_host_s"] = tm.get("write_tif_host_s", 0.0) + time.perf_counter() - t1
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k, 0) for k in range(n_tiles)], root, workers=4))
+            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k, 0) for k in range(n_tiles)], root, workers=6))
             res = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tm, on_result=on_result)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
@@ -455,7 +455,7 @@ def main():
         return {"value": n_tiles * TILE * TILE / wall, "unit": "px/s", "tiles": n_tiles, "ms_per_tile_pipelined": wall / n_tiles * 1e3,
                 "ms_per_stage_serial": {k: round(v * 1e3, 2) for k, v in stages.items()},
                 "host_seconds_in_loop": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
-                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": 4, "sessions": len(sessions),
+                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": 6, "sessions": len(sessions),
                 "tiles_rerun_staged": int(sum(1 for r in res if r[3])),
                 "slowest_host_stage": {"name": slowest, "ms": round(host_ms[slowest], 2), "x_gpu_stage": round(host_ms[slowest] / gpu_ms, 2)},
                 "note": "job-level: files -> ttc_read_hkl -> pinned H2D -> detection + ttc_predict_tile -> D2H -> ttc_write_geotiff_u8; "

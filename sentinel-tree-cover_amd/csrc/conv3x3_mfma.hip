@@ -375,7 +375,12 @@ int conv_stat_slots(int Hp, int Wp) { return conv_q_blocks(Hp, Wp) * kWaves; }
 // TTC_WINOGRAD=0 keeps every fp32 layer on the direct kernel (A/B runs, parity tests of the direct form)
 bool conv_use_wino(const PackedConv& pw, int epi) {
     static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
-    return on && pw.mode == 0 && pw.d_wu != nullptr && epi <= EPI_SWISH && pw.Cout % 32 == 0 && pw.nchunk_w >= 3;
+    if (!on || pw.mode != 0 || pw.d_wu == nullptr || pw.nchunk_w < 3) return false;
+    // GroupNorm layers of the ConvGRU / U-Net only.  DSen2's 32 -> 32 layers were tried on the same kernel (bias / ReLU / residual
+    // epilogues with the reflect rim) and measured SLOWER than the direct form (2.6 / 3.1 vs 1.9 / 2.2 ms per tile: 118-px windows
+    // are 7.4 regions wide (15 % padding), a tile is only four chunks long, and the padded-plane output forces scalar stores):
+    // profiles/r04_dsen2_winograd_probe_kernel_stats.md, csrc/experiments/README.md
+    return epi <= EPI_SWISH && pw.Cout % 32 == 0;
 }
 // (the Winograd kernels stage 8-byte pairs: planes with an odd pitch stay on the direct kernel)
 int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp) {
