@@ -1164,23 +1164,43 @@ __global__ void k_sel_init_dates(SelState* __restrict__ st, const int* __restric
     SelState ss; ss.prefix = 0; ss.mask = 0; ss.k = n > 0 ? (n - 1) / 2 : 0;
     st[q] = ss;
 }
+// per (date, column): sum, sum of squares (double) over the valid rows; the key of the UPPER median (order statistic n / 2)
+struct ColStat { double sum, sq; unsigned min_above, up_key; };
+__global__ void k_stat_init(ColStat* cs) { cs[threadIdx.x].sum = 0.0; cs[threadIdx.x].sq = 0.0; cs[threadIdx.x].min_above = 0xffffffffu; cs[threadIdx.x].up_key = 0; }
 // One radix-select pass for the 20 problems (10 bands x {reference, date}) of date blockIdx.y.  Histograms live in LDS;
 // a lane aggregates its OWN consecutive hits of one bin in registers and touches LDS only when the bin changes: on the high
 // passes reflectances share their top key bytes from pixel to pixel (a handful of bins), on the low passes few keys still match
 // the prefix -- either way almost no atomics, and no wave collectives.
+// Round 4: the separate statistics pass over the stack (k_stat_all, 0.2 ms per tile: sums, sums of squares, and the count / successor
+// search that turned the lower median into the upper one) is gone.  MODE 1 (the first pass, shift 24) also accumulates sum and sum
+// of squares of every column in double -- they do not depend on the median; MODE 2 (the last pass, shift 0) also keeps, per column,
+// the smallest key ABOVE the 24-bit prefix range: with the last byte's histogram that is all k_pick_last needs to name the order
+// statistic that follows the lower median.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ ref_all, const float* __restrict__ tiles,
                                                    const unsigned* __restrict__ vmask, int npix, const SelState* __restrict__ st,
-                                                   int shift, unsigned* __restrict__ hist) {
+                                                   int shift, unsigned* __restrict__ hist, ColStat* __restrict__ cs) {
     __shared__ unsigned h[20 * 256];
     __shared__ unsigned pf[20], mk[20];
+    __shared__ double ssum[20], ssq[20];
+    __shared__ unsigned smin[20];
     const int i = blockIdx.y;
     for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x) h[k] = 0;
-    if (threadIdx.x < 20) { pf[threadIdx.x] = st[i * 20 + threadIdx.x].prefix; mk[threadIdx.x] = st[i * 20 + threadIdx.x].mask; }
+    if (threadIdx.x < 20) {
+        pf[threadIdx.x] = st[i * 20 + threadIdx.x].prefix; mk[threadIdx.x] = st[i * 20 + threadIdx.x].mask;
+        ssum[threadIdx.x] = 0.0; ssq[threadIdx.x] = 0.0; smin[threadIdx.x] = 0xffffffffu;
+    }
     __syncthreads();
     int cur[20];
     unsigned cnt[20];
+    double a1[MODE == 1 ? 20 : 1], a2[MODE == 1 ? 20 : 1];
+    unsigned mn[MODE == 2 ? 20 : 1];
 #pragma unroll
     for (int q = 0; q < 20; ++q) { cur[q] = -1; cnt[q] = 0; }
+#pragma unroll
+    for (int q = 0; q < (MODE == 1 ? 20 : 1); ++q) { a1[q] = 0.0; a2[q] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < (MODE == 2 ? 20 : 1); ++q) mn[q] = 0xffffffffu;
     const int stride = gridDim.x * blockDim.x;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
         if (!((vmask[p] >> i) & 1u)) continue;
@@ -1193,8 +1213,12 @@ __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ ref_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int q = 4 * c2 + j;
+                if (MODE == 1) { a1[q] += (double)v[j]; a2[q] += (double)v[j] * (double)v[j]; }
                 const unsigned k = fkey(v[j]);
-                if ((k & mk[q]) != pf[q]) continue;
+                if ((k & mk[q]) != pf[q]) {
+                    if (MODE == 2 && k > (pf[q] | 255u)) mn[q] = min(mn[q], k);
+                    continue;
+                }
                 const int bin = (int)((k >> shift) & 255u);
                 if (bin == cur[q]) { cnt[q]++; continue; }
                 if (cnt[q]) atomicAdd(&h[q * 256 + cur[q]], cnt[q]);
@@ -1205,57 +1229,70 @@ __global__ __launch_bounds__(256) void k_hist_all(const float* __restrict__ ref_
 #pragma unroll
     for (int q = 0; q < 20; ++q)
         if (cnt[q]) atomicAdd(&h[q * 256 + cur[q]], cnt[q]);
+    if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
+            for (int k = 32; k >= 1; k >>= 1) { a1[q] += __shfl_xor(a1[q], k); a2[q] += __shfl_xor(a2[q], k); }
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&ssum[q], a1[q]); atomicAdd(&ssq[q], a2[q]); }
+        }
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 20; ++q) {
+            for (int k = 32; k >= 1; k >>= 1) mn[q] = min(mn[q], (unsigned)__shfl_xor((int)mn[q], k));
+            if ((threadIdx.x & 63) == 0 && mn[q] != 0xffffffffu) atomicMin(&smin[q], mn[q]);
+        }
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < 20 * 256; k += blockDim.x)
         if (h[k]) atomicAdd(&hist[(long)i * 20 * 256 + k], h[k]);
+    if (MODE == 1 && threadIdx.x < 20) { atomicAdd(&cs[i * 20 + threadIdx.x].sum, ssum[threadIdx.x]); atomicAdd(&cs[i * 20 + threadIdx.x].sq, ssq[threadIdx.x]); }
+    if (MODE == 2 && threadIdx.x < 20 && smin[threadIdx.x] != 0xffffffffu) atomicMin(&cs[i * 20 + threadIdx.x].min_above, smin[threadIdx.x]);
 }
-// per (date, column): sum, sum of squares (double), #(v <= lower median), min key of (v > lower median)
-struct ColStat { double sum, sq; int n_le; unsigned min_gt; };
-__global__ void k_stat_init(ColStat* cs) { cs[threadIdx.x].sum = 0.0; cs[threadIdx.x].sq = 0.0; cs[threadIdx.x].n_le = 0; cs[threadIdx.x].min_gt = 0xffffffffu; }
-__global__ __launch_bounds__(256, 2) void k_stat_all(const float* __restrict__ ref_all, const float* __restrict__ tiles, const unsigned* __restrict__ vmask,
-                           int npix, const SelState* __restrict__ st, ColStat* __restrict__ out) {
-    __shared__ double ssum[20], ssq[20];
-    __shared__ int sle[20];
-    __shared__ unsigned smin[20];
-    __shared__ float med[20];
-    const int i = blockIdx.y;
-    if (threadIdx.x < 20) {
-        ssum[threadIdx.x] = 0.0; ssq[threadIdx.x] = 0.0; sle[threadIdx.x] = 0; smin[threadIdx.x] = 0xffffffffu;
-        med[threadIdx.x] = fkey_inv(st[i * 20 + threadIdx.x].prefix);
-    }
-    __syncthreads();
-    double a[20], a2[20];
-    int le[20];
-    unsigned mn[20];
+// The last pick (shift 0) of the date problems: the lower median like k_sel_pick, plus the key of the order statistic that follows it
+// (the upper median of an even count): the same key when its bin holds another element, else the next non-empty bin of this last-byte
+// histogram, else the smallest key above the whole 24-bit prefix range (ColStat.min_above).
+__global__ void k_pick_last(SelState* __restrict__ st, unsigned* __restrict__ hist, ColStat* __restrict__ cs) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    unsigned c[4];
+    unsigned mine = 0;
 #pragma unroll
-    for (int q = 0; q < 20; ++q) { a[q] = 0.0; a2[q] = 0.0; le[q] = 0; mn[q] = 0xffffffffu; }
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
-        if (!((vmask[p] >> i) & 1u)) continue;
-        const float* r = ref_all + ((long)i * npix + p) * 10;
-        const float* sv = tiles + ((long)i * npix + p) * 10;
+    for (int j = 0; j < 4; ++j) { c[j] = hist[q * 256 + 4 * lane + j]; mine += c[j]; hist[q * 256 + 4 * lane + j] = 0; }
+    unsigned incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const long long excl = (long long)incl - mine;
+    SelState ss = st[q];
+    const long long k = ss.k;
+    const bool here = k >= excl && k < (long long)incl;
+    const unsigned long long m = __ballot(here);
+    const int owner = m ? __ffsll((long long)m) - 1 : 63;
+    // per lane: the first non-empty bin of this lane (for the successor search)
+    int first_bin = -1;
 #pragma unroll
-        for (int q = 0; q < 20; ++q) {
-            const float v = (q & 1) ? sv[q >> 1] : r[q >> 1];
-            a[q] += (double)v; a2[q] += (double)v * (double)v;
-            le[q] += v <= med[q];
-            if (v > med[q]) mn[q] = min(mn[q], fkey(v));
-        }
+    for (int j = 3; j >= 0; --j) if (c[j]) first_bin = 4 * lane + j;
+    int b = 0;
+    long long r = 0;
+    if (lane == owner) {
+        r = k - excl;
+        for (; b < 3; ++b) { if (r < (long long)c[b]) break; r -= c[b]; }
     }
-#pragma unroll
-    for (int q = 0; q < 20; ++q) {
-        for (int k = 32; k >= 1; k >>= 1) {
-            a[q] += __shfl_xor(a[q], k); a2[q] += __shfl_xor(a2[q], k);
-            le[q] += __shfl_xor(le[q], k); mn[q] = min(mn[q], (unsigned)__shfl_xor((int)mn[q], k));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&ssum[q], a[q]); atomicAdd(&ssq[q], a2[q]); atomicAdd(&sle[q], le[q]); atomicMin(&smin[q], mn[q]);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 20) {
-        ColStat* o = out + i * 20 + threadIdx.x;
-        atomicAdd(&o->sum, ssum[threadIdx.x]); atomicAdd(&o->sq, ssq[threadIdx.x]);
-        atomicAdd(&o->n_le, sle[threadIdx.x]); atomicMin(&o->min_gt, smin[threadIdx.x]);
+    b = __shfl(b, owner);
+    const long long rr = __shfl((int)r, owner);
+    const unsigned cb = __shfl((int)c[0], owner) * (b == 0) + __shfl((int)c[1], owner) * (b == 1) + __shfl((int)c[2], owner) * (b == 2) + __shfl((int)c[3], owner) * (b == 3);
+    const int lo_bin = 4 * owner + b;
+    // next non-empty bin above lo_bin: inside the owner lane, else the first bin of the first later lane that has any
+    int nxt = -1;
+    if (lane == owner) { for (int j = 3; j > b; --j) if (c[j]) nxt = 4 * lane + j; }
+    nxt = __shfl(nxt, owner);
+    const unsigned long long later = __ballot(lane > owner && first_bin >= 0);
+    if (nxt < 0 && later) nxt = __shfl(first_bin, __ffsll((long long)later) - 1);
+    if (lane == 0) {
+        const unsigned lo_key = ss.prefix | (unsigned)lo_bin;
+        unsigned up_key = lo_key;
+        if (!(m && rr + 1 < (long long)cb)) up_key = nxt >= 0 ? (ss.prefix | (unsigned)nxt) : cs[q].min_above;
+        ss.prefix = lo_key; ss.mask |= 255u; ss.k = m ? rr : 0;
+        st[q] = ss;
+        cs[q].up_key = up_key;
     }
 }
 __global__ void k_params_all(const SelState* __restrict__ st, const ColStat* __restrict__ cs, const int* __restrict__ count,
@@ -1271,9 +1308,9 @@ __global__ void k_params_all(const SelState* __restrict__ st, const ColStat* __r
         for (int which = 0; which < 2; ++which) {
             const int q = i * 20 + b * 2 + which;
             const float lo = fkey_inv(st[q].prefix);
-            // upper median = order statistic n/2: the same value when enough elements are <= it, else the next larger one
+            // upper median = order statistic n / 2 = the one after the lower median of an even count (k_pick_last)
             float up = lo;
-            if (n > 0 && (n & 1) == 0 && cs[q].n_le < n / 2 + 1) up = fkey_inv(cs[q].min_gt);
+            if (n > 0 && (n & 1) == 0) up = fkey_inv(cs[q].up_key);
             med[which] = 0.5f * (lo + up);
             const double mean = cs[q].sum / (double)max(n, 1);
             double var = cs[q].sq / (double)max(n, 1) - mean * mean;
@@ -1368,13 +1405,16 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
         hipLaunchKernelGGL(k_count_land, dim3(64), blk, 0, s, water, npix, count + kMaxT);
         GF_T(k_ref_all, T, dim3(2048), blk, 0, s, d_tiles, d_w, water, T, npix, ref_all, vmask, count);
         hipLaunchKernelGGL(k_sel_init_dates, dim3((T * 20 + 63) / 64), dim3(64), 0, s, st, count, T);
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            // 128 x T workgroups: measured 64 / 128 / 256 / 512 -> 3.58 / 3.47 / 3.51 / 3.66 ms per tile for the whole preprocessing chain
-            hipLaunchKernelGGL(k_hist_all, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, shift, hist);
+        hipLaunchKernelGGL(k_stat_init, dim3(1), dim3(kMaxT * 20), 0, s, cs);
+        // 128 x T workgroups: measured 64 / 128 / 256 / 512 -> 3.58 / 3.47 / 3.51 / 3.66 ms per tile for the whole preprocessing chain
+        hipLaunchKernelGGL(k_hist_all<1>, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, 24, hist, cs);      // + the moments
+        hipLaunchKernelGGL(k_sel_pick, dim3(T * 20), dim3(64), 0, s, st, 24, hist);
+        for (int shift = 16; shift >= 8; shift -= 8) {
+            hipLaunchKernelGGL(k_hist_all<0>, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, shift, hist, cs);
             hipLaunchKernelGGL(k_sel_pick, dim3(T * 20), dim3(64), 0, s, st, shift, hist);
         }
-        hipLaunchKernelGGL(k_stat_init, dim3(1), dim3(kMaxT * 20), 0, s, cs);
-        hipLaunchKernelGGL(k_stat_all, dim3(192, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, cs);
+        hipLaunchKernelGGL(k_hist_all<2>, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, 0, hist, cs);       // + the successor key
+        hipLaunchKernelGGL(k_pick_last, dim3(T * 20), dim3(64), 0, s, st, hist, cs);
         hipLaunchKernelGGL(k_params_all, dim3(1), dim3(64), 0, s, st, cs, count, count + kMaxT, T, ap);
         TTC_HIP(c, hipGetLastError());
     }
