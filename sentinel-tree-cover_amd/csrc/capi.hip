@@ -20,6 +20,7 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
 ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, int ws, int cs, hipStream_t s);
 ttc_status tile_smooth_strip(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat, float* d_out, hipStream_t s);
 ttc_status upsample_20m(ttc_ctx* c, const float* d10, const float* d20, int T, int h, int w, float* d_out, hipStream_t s);
+ttc_status decode_upsample_u16(ttc_ctx* c, const uint16_t* d10, const uint16_t* d20, int T, int h, int w, float* d_out, hipStream_t s);
 
 ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y, int closing, int clip, float* d_w, hipStream_t s);
 ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic, hipStream_t s);
@@ -224,12 +225,10 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
     if (T < 1 || T > 32 || X < 2 || Y < 2 || (X & 1) || (Y & 1)) return c->fail(TTC_ERR_ARG, "predict_tile: T in [1,32], even X and Y");
     const int h = X / 2, w = Y / 2;
     const size_t npix = (size_t)X * Y;
-    float* f10 = static_cast<float*>(c->scratch_buf("pt_f10", sizeof(float) * T * npix * 4));
-    float* f20 = static_cast<float*>(c->scratch_buf("pt_f20", sizeof(float) * (size_t)T * h * w * 6));
     float* s1db = static_cast<float*>(c->scratch_buf("pt_s1", sizeof(float) * 12 * npix * 2));
     float* s2 = static_cast<float*>(c->scratch_buf("pt_s2", sizeof(float) * T * npix * 10));
     float* interp = static_cast<float*>(c->scratch_buf("pt_interp", sizeof(float) * T * npix));
-    if (!f10 || !f20 || !s1db || !s2 || !interp) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+    if (!s1db || !s2 || !interp) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
     // window grid (job.py:1295-1316): origins of the 6 x 6 output windows, iteration order x-major
     std::vector<int32_t> xy;
     {
@@ -249,10 +248,8 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
     c->named["pt_windows"] = {windows, (size_t)n_win * size * size};           // what the reference np.save()s per window
     c->named["pt_windows_raw"] = {windows_raw, (size_t)n_win * size * size};   // before np.around / the bright-surface product
     TTC_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t) * 4, s));
-    TTC_CHECK(codec_u16_to_f32(c, d_s2_10, (int64_t)T * npix * 4, f10, s));             // tof_downloading.py:64-72
-    TTC_CHECK(codec_u16_to_f32(c, d_s2_20, (int64_t)T * h * w * 6, f20, s));
     TTC_CHECK(codec_s1_to_db(c, d_s1, 12, X, Y, s1db, s));                              // job.py:699-708
-    TTC_CHECK(upsample_20m(c, f10, f20, T, h, w, s2, s));                               // job.py:734-782
+    TTC_CHECK(decode_upsample_u16(c, d_s2_10, d_s2_20, T, h, w, s2, s));                // tof_downloading.py:64-72 + job.py:734-782, one pass
     const float* mask = d_mask;
     const uint8_t* pf = nullptr;
     if (detect) {                                                                       // cloud_removal.py:1215-1677

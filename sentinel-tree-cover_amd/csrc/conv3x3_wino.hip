@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     // one chunk c of the running tile; LAST = its final chunk (possibly fewer than four k-steps).  Stream position c + k of the
     // running tile is chunk c + k - T of the next tile once it passes the end.  The B operand of xi + 1 is fetched before the MFMAs
     // of xi issue; V[par] stays valid for the whole chunk, so that look-ahead also crosses the mid-chunk barrier.
-    auto chunk = [&](int c, auto LASTC) {
+    auto chunk = [&](int c, auto LASTC, auto FIRSTC) {
         constexpr bool last = decltype(LASTC)::value;
+        constexpr bool first = decltype(FIRSTC)::value;
         if (!(probe & 128)) wbarrier();           // V[par] is complete, in_tile holds stream position c + 1
         const float4* Vc = Vr + par * (VBUF / 4);
         auto bload = [&](int xl) { return Vc[(4 * (xl >> 1) + 2 * xh + (xl & 1)) * (2 * NT)]; };
@@ -249,8 +250,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         auto mfma_pair = [&](int pp, const float4 (&b)[2]) {
             const int x0 = 2 * pp, x1 = 2 * pp + 1;
             const float4 a0 = A[x0], a1 = A[x1];
-            acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0].x, acc[x0], 0, 0, 0);
-            acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[1].x, acc[x1], 0, 0, 0);
+            if (first) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0].x, z, 0, 0, 0);
+                acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[1].x, z, 0, 0, 0);
+            } else {
+                acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b[0].x, acc[x0], 0, 0, 0);
+                acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b[1].x, acc[x1], 0, 0, 0);
+            }
             if (!last || nks > 1) {
                 acc[x0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b[0].y, acc[x0], 0, 0, 0);
                 acc[x1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b[1].y, acc[x1], 0, 0, 0);
@@ -283,9 +290,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     };
 
     for (;;) {
-        zero_acc();
-        for (int c = 0; c + 1 < T; ++c) chunk(c, std::false_type{});
-        chunk(T - 1, std::true_type{});
+        chunk(0, std::false_type{}, std::true_type{});
+        for (int c = 1; c + 1 < T; ++c) chunk(c, std::false_type{}, std::false_type{});
+        chunk(T - 1, std::true_type{}, std::false_type{});
 
         // ---- output transform.  acc[2 a + bl] = M[a][b = 2 xh + bl]
         //   T0[b] = M0b + M1b + M2b, T1[b] = M1b - M2b - M3b;  Y[i][0] = Ti0 + Ti1 + Ti2, Y[i][1] = Ti1 - Ti2 - Ti3

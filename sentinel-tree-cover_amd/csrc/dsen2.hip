@@ -202,6 +202,59 @@ __global__ void k_upsample_40m(const float* __restrict__ m, const float* __restr
     }
 }
 
+// The single-call tile path's form of the three kernels above, from the bands AS STORED (uint16, tof_downloading.py:51-61): decode
+// (x / 65535.0f, to_float32 :64-72), the 10 m copy, the four 20 m bilinear bands and the two 40 m bands (2x2 float32 mean evaluated
+// inline in k_mean2x2's order, then the same bilinear) in ONE pass that writes each pixel's 40-byte record once -- no float copies of
+// the raw bands (137 MB written + read back per T = 12 tile), no mean plane, one launch instead of five.  Same arithmetic, same order:
+// bit-identical to decode -> upsample_20m.
+__device__ __forceinline__ float dec16(unsigned short v) { return (float)v / 65535.0f; }
+__device__ __forceinline__ float mean4_u16(const unsigned short* __restrict__ b, long w6) {
+#pragma clang fp contract(off)
+    const float v00 = dec16(b[0]), v01 = dec16(b[6]), v10 = dec16(b[w6]), v11 = dec16(b[w6 + 6]);
+    return (((v00 + v01) + v10) + v11) / 4.0f;
+}
+__global__ void k_decode_upsample(const unsigned short* __restrict__ s10, const unsigned short* __restrict__ s20, int h, int w, int oy, int ox,
+                                  float* __restrict__ out) {
+    const int t = blockIdx.y, H = 2 * h, W = 2 * w, hh = (h - oy) / 2, ww = (w - ox) / 2;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, x = p % W;
+    float v[10];
+    const ushort4 a = *reinterpret_cast<const ushort4*>(s10 + ((long)t * H * W + p) * 4);
+    v[0] = dec16(a.x); v[1] = dec16(a.y); v[2] = dec16(a.z); v[3] = dec16(a.w);
+    const unsigned short* b = s20 + (long)t * h * w * 6;
+    {
+        const double sy = (y + 0.5) * 0.5 - 0.5, sx = (x + 0.5) * 0.5 - 0.5;
+        const int y0 = (int)floor(sy), x0 = (int)floor(sx);
+        const double fy = sy - y0, fx = sx - x0;
+        const int ya = reflect_idx(y0, h), yb = reflect_idx(y0 + 1, h), xa = reflect_idx(x0, w), xb = reflect_idx(x0 + 1, w);
+        for (int c = 0; c < 4; ++c) {
+            const double v00 = dec16(b[((long)ya * w + xa) * 6 + c]), v01 = dec16(b[((long)ya * w + xb) * 6 + c]);
+            const double v10 = dec16(b[((long)yb * w + xa) * 6 + c]), v11 = dec16(b[((long)yb * w + xb) * 6 + c]);
+            const double r0 = v00 * (1.0 - fy) + v10 * fy, r1 = v01 * (1.0 - fy) + v11 * fy;
+            v[4 + c] = (float)(r0 * (1.0 - fx) + r1 * fx);
+        }
+    }
+    for (int c = 0; c < 2; ++c) {
+        float r;
+        if (ox && x == 0) r = dec16(b[((long)(y / 2) * w) * 6 + 4 + c]);          // first column, written last (job.py:769)
+        else if (oy && y == 0) r = dec16(b[(long)(x / 2) * 6 + 4 + c]);           // first row
+        else {
+            const double sy = (y - oy + 0.5) * ((double)hh / (H - oy)) - 0.5, sx = (x - ox + 0.5) * ((double)ww / (W - ox)) - 0.5;
+            const int y0 = (int)floor(sy), x0 = (int)floor(sx);
+            const double fy = sy - y0, fx = sx - x0;
+            const int ya = reflect_idx(y0, hh), yb = reflect_idx(y0 + 1, hh), xa = reflect_idx(x0, ww), xb = reflect_idx(x0 + 1, ww);
+            auto m = [&](int my, int mx) { return (double)mean4_u16(b + ((long)(2 * my + oy) * w + 2 * mx + ox) * 6 + 4 + c, (long)w * 6); };
+            const double r0 = m(ya, xa) * (1.0 - fy) + m(yb, xa) * fy, r1 = m(ya, xb) * (1.0 - fy) + m(yb, xb) * fy;
+            r = (float)(r0 * (1.0 - fx) + r1 * fx);
+        }
+        v[8 + c] = r;
+    }
+    float2* dst = reinterpret_cast<float2*>(out + ((long)t * H * W + p) * 10);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) dst[c] = make_float2(v[2 * c], v[2 * c + 1]);
+}
+
 const char* kDsNames[6] = {"in_conv", "01_conv", "02_conv", "11_conv", "12_conv", "out_conv"};
 const int kDsCin[6] = {10, 32, 32, 32, 32, 32};
 const int kDsCout[6] = {32, 32, 32, 32, 32, 6};
@@ -421,6 +474,15 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
           }
           TTC_HIP(c, hipGetLastError()); }
     }
+    return TTC_OK;
+}
+
+ttc_status decode_upsample_u16(ttc_ctx* c, const uint16_t* d10, const uint16_t* d20, int T, int h, int w, float* d_out, hipStream_t s) {
+    if (!d10 || !d20 || !d_out || T < 1) return c->fail(TTC_ERR_ARG, "decode_upsample: bad argument");
+    KTimer kt(c, "upsample_20m", s);
+    const int P = 4 * h * w;
+    hipLaunchKernelGGL(k_decode_upsample, dim3((P + 255) / 256, T), dim3(256), 0, s, d10, d20, h, w, h % 2, w % 2, d_out);
+    TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }
 
