@@ -300,7 +300,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
         const long off1 = (long)nn * ka->seg[1].stride_n + ka->seg[1].set_off[set];
         t.hi0 = ka->seg[0].hi + off0; t.lo0 = ka->seg[0].lo + off0;
         t.hi1 = ka->seg[1].hi + off1; t.lo1 = ka->seg[1].lo + off1;
-        t.wsrc = ka->w + (long)set * ka->w_set_stride + (long)t.cb * nchunk * (2 * WUNITS);
+        const int npack = ka->nchunk_pack > 0 ? ka->nchunk_pack : nchunk;
+        t.wsrc = ka->w + (long)set * ka->w_set_stride + (long)t.cb * npack * (2 * WUNITS);
         return t;
     };
     auto ep_of = [&](const Src& t) {

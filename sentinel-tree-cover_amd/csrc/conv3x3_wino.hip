@@ -51,6 +51,8 @@ struct WinoArgs {
     ConvArgs a;
     const float* U; long u_set_stride;
     int nchunk, nks_last, RXn, RYn, ncp, ntiles;
+    int nrun, cin_run;   // chunks to run (<= nchunk, the packing stride of U) and the channels that are non-zero (the rest of the last
+                         // chunk is read as 0): ConvGRU step 0, whose hidden state is identically zero
     int probe;           // ablation bits (TTC_WINO_PROBE, timing only -- results are wrong): 1 every tile stages tile 0's inputs, 2 no output
                          // stores, 4 no input transform, 8 no A-operand refills, 16 no staging loads, 32 no epilogue, 64 no mid-chunk barrier / LDS stage store, 128 no chunk-start barrier
 };
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     const int tcol = lane & 31, hsel = lane >> 5;
     const int Wp = args()->a.Wp, Hp = args()->a.Hp, H = Hp - 2, W = Wp - 2;
     const int plane = Hp * Wp;
-    const int T = nchunk;
+    const int T = args()->nrun;                  // chunks of the stream per tile (nchunk stays the stride of the U images)
 
     // PERSISTENT walk (grid = the resident set, 2 workgroups per CU): workgroup id -> (id % 8) owns a contiguous slice of the logical
     // tile list and the workgroups of one XCD step through it together with stride nx, so neighbouring regions (shared halos, the
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         t.seg0 = ka->a.seg[0].base + (long)nn * ka->a.seg[0].stride_n + ka->a.seg[0].set_off[t.set];
         t.seg1 = ka->a.seg[1].C > 0 ? ka->a.seg[1].base + (long)nn * ka->a.seg[1].stride_n + ka->a.seg[1].set_off[t.set] : t.seg0;
         // U: [set][cout block][chunk][xi][k-half][cout 32][4 k-steps]
-        t.uw = reinterpret_cast<const float4*>(ka->U + (long)t.set * ka->u_set_stride) + ((long)(t.cp * NCB + cbw) * T) * (16 * 2 * 32) + hsel * 32 + tcol;
+        t.uw = reinterpret_cast<const float4*>(ka->U + (long)t.set * ka->u_set_stride) + ((long)(t.cp * NCB + cbw) * nchunk) * (16 * 2 * 32) + hsel * 32 + tcol;
         const int y0 = (probe & 1) ? 0 : t.ry * (2 * RTY), x0 = (probe & 1) ? 0 : t.rx * (2 * kRTX);
         if (probe & 1) { t.seg0 = ka->a.seg[0].base; t.seg1 = ka->a.seg[1].C > 0 ? ka->a.seg[1].base : t.seg0; }
 #pragma unroll
@@ -142,13 +144,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     float2 g[NE];
     auto stage_load = [&](const TileS& t, int c) {
         if (probe & 16) return;
-        const int Cin = args()->a.Cin, C0 = args()->a.seg[0].C;
+        const int Cin = args()->a.Cin, C0 = args()->a.seg[0].C, crun = args()->cin_run;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             int ci = c * kWCK + (t.goff[k] >> 24);
+            const bool zero = ci >= crun;         // channels declared zero by the caller (their weights are NOT zero)
             ci = ci < Cin ? ci : Cin - 1;         // pad channels meet zero weights: any finite plane will do
+            ci = zero ? 0 : ci;
             const float* src = ci < C0 ? t.seg0 + (long)ci * plane : t.seg1 + (long)(ci - C0) * plane;
-            g[k] = *reinterpret_cast<const float2*>(src + (t.goff[k] & 0xffffff));
+            const float2 v = *reinterpret_cast<const float2*>(src + (t.goff[k] & 0xffffff));
+            g[k] = zero ? make_float2(0.f, 0.f) : v;
         }
     };
     auto stage_store = [&]() {
@@ -439,7 +444,9 @@ hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     const int RXn = (TX + kRTX - 1) / kRTX, RYn = (TY + 4 * TB - 1) / (4 * TB);
     const int ncp = (a.Cout + 32 * NCB - 1) / (32 * NCB);
     if ((long)a.Hp * a.Wp >= (1L << 24) || (a.Wp & 1) || pw.nchunk_w < 3) return hipErrorInvalidValue;
-    const int rem = a.Cin - kWCK * (pw.nchunk_w - 1);
+    const int cin_run = (a.cin_run > 0 && a.cin_run < a.Cin) ? a.cin_run : a.Cin;
+    const int nrun = std::max(3, (cin_run + kWCK - 1) / kWCK);                // the cross-tile stream needs >= 3 chunks per tile
+    const int rem = std::min(a.Cin, nrun * kWCK) - kWCK * (nrun - 1);
     const int nks_last = (rem + 1) / 2;
     const long ntiles = (long)RXn * RYn * ncp * n;
     static const int forced = [] { const char* e = getenv("TTC_WINO_PERSIST"); return e ? atoi(e) : -1; }();   // probe: 0 = one workgroup per tile
@@ -448,7 +455,7 @@ hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     const long resident = forced >= 0 ? forced : 2L * cus;
     const long grid = resident > 0 ? std::min(ntiles, resident) : ntiles;
     static const int probe = [] { const char* e = getenv("TTC_WINO_PROBE"); return e ? atoi(e) : 0; }();
-    const WinoArgs wa{a, pw.d_wu, pw.set_stride_w, pw.nchunk_w, nks_last, RXn, RYn, ncp, (int)ntiles, probe};
+    const WinoArgs wa{a, pw.d_wu, pw.set_stride_w, pw.nchunk_w, nks_last, RXn, RYn, ncp, (int)ntiles, nrun, cin_run, probe};
     hipLaunchKernelGGL((conv3x3_wino<NCB, EPI>), dim3((unsigned)grid), dim3(256), lds, s, wa);
     return hipGetLastError();
 }

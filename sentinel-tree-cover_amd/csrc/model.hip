@@ -100,7 +100,8 @@ __global__ void k_gru_apply1(const float* __restrict__ yg, const float* __restri
 __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restrict__ gn, GruParams prm,
                              const float* __restrict__ yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
                              const float* __restrict__ hcur, float* __restrict__ hnext,
-                             float* __restrict__ gru_out, int H, int W, int N, float z) {
+                             float* __restrict__ gru_out, int H, int W, int N, float z, int h_zero) {
+    // h_zero: the incoming state is identically zero (step 0) and is NOT read (its buffer may hold a previous tile's state)
     const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,7 +126,7 @@ __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restri
         const float cand = tanh_fast((y[(long)c * P] - g[2 * gi]) * g[2 * gi + 1] * pr[160 + c] + pr[192 + c]);
         const float uv = sigm((yu[(long)c * P] - gu[2 * gi]) * gu[2 * gi + 1] * pr[64 + c] + pr[96 + c]);
         if (uk) uk[(long)c * (H * W)] = uv;
-        const float hv = h[(long)c * PP];
+        const float hv = h_zero ? 0.0f : h[(long)c * PP];
         const float hnew = uv * hv + (1.0f - uv) * cand;
         const float hz = hv * z + hnew * (1.0f - z);
         hn[(long)c * PP] = hz;
@@ -378,7 +379,8 @@ __global__ void k_gru_apply1_b16(Raw16 yg, const float* __restrict__ gn, GruPara
 template <int BF>
 __global__ void k_gru_apply2_b16(Raw16 yc, const float* __restrict__ gn, GruParams prm,
                                  Raw16 yg, const float* __restrict__ gn_gates, float* __restrict__ u_keep,
-                                 B16 hcur, B16 hnext, B16 gru_out, int H, int W, int N, float z) {
+                                 B16 hcur, B16 hnext, B16 gru_out, int H, int W, int N, float z, int h_zero) {
+    // h_zero: the incoming state is identically zero (step 0) and is NOT read
     const int Wp = W + 2, PP = (H + 2) * Wp, P = H * Wp;        // raw conv outputs keep the input pitch: [c][H][Wp]
     const int n = blockIdx.y, dir = n / N;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,7 +398,10 @@ __global__ void k_gru_apply2_b16(Raw16 yc, const float* __restrict__ gn, GruPara
     for (int k = 0; k < 4; ++k) {
         const long u = ((long)n * 4 + k) * PP + p;
         float hv[8], o[8], y[8], yu[8];
-        b16_load8<BF>(hcur.hi, hcur.lo, u, hv);
+        if (h_zero) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = 0.0f;
+        } else b16_load8<BF>(hcur.hi, hcur.lo, u, hv);
         raw_load8(yc.top, yc.bot, ((long)n * 4 + k) * P + s, y);
         raw_load8(yg.top, yg.bot, ((long)n * 8 + 4 + k) * P + s, yu);      // gates channels 32..63 = u
 #pragma unroll
@@ -818,8 +823,9 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
         return Raw16{top, top + (long)nseq * (C / 8) * plane};
     };
     auto launch = [&](H16Args& a, const PackedConv& pw, int epi, int nseq, float* raw) -> ttc_status {
-        a.nchunk = a.seg[0].C8 + a.seg[1].C8;
-        if (a.nchunk != pw.nchunk_h) return c->fail(TTC_ERR_STATE, "16-bit conv: channel blocks do not match the packed weights");
+        if (a.seg[0].C8 + a.seg[1].C8 != pw.nchunk_h) return c->fail(TTC_ERR_STATE, "16-bit conv: channel blocks do not match the packed weights");
+        a.nchunk_pack = pw.nchunk_h;
+        a.nchunk = a.nchunk ? a.nchunk : pw.nchunk_h;     // a caller may ask for the first segment's chunks only (second segment == 0)
         a.w = pw.d_wh; a.w_set_stride = pw.nsets > 1 ? pw.set_stride_h : 0;
         const long plane = (long)(a.c.Hp - 2) * a.c.Wp;
         const Raw16 r = raw_of(raw, nseq, a.c.Cout, plane);
@@ -830,8 +836,9 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
     };
 
     // ---------------- bi-directional ConvGRU ----------------
-    TTC_HIP(c, hipMemsetAsync(c->h16[0].hi, 0, (size_t)N2 * Hd8 * PP * 16, s));
-    TTC_HIP(c, hipMemsetAsync(c->h16[0].lo, 0, (size_t)N2 * Hd8 * PP * 16, s));
+    // Step 0 of both directions starts from h = 0: the gates and candidate convolutions run over the frame segment's chunks only
+    // (3 of 7; channel blocks are per segment, so the state tensors are not touched at all), r * h is never formed and the
+    // state buffers are neither cleared nor read -- the same sums minus terms that are exactly zero.
     const GruParams gp{sm + c->small_off["gru/fw/"], c->small_off["gru/bw/"] - c->small_off["gru/fw/"]};
     int cur = 0;
     for (int st = 0; st < g.L; ++st) {
@@ -840,15 +847,18 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
         a.seg[1] = {c->h16[cur].hi, c->h16[cur].lo, (long)Hd8 * PP, {0, (long)N * Hd8 * PP}, Hd8};
         a.c.Hp = Hp; a.c.Wp = Wp; a.c.Cout = 2 * Hd; a.c.n_per_set = N;
         a.c.stats = c->stats;
+        const bool h0 = st == 0;
+        a.nchunk = h0 ? Cx8 : 0;
         { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2, c->yg)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
-        {
+        if (!h0) {
             KTimer kt(c, "gru_apply1", s);
             hipLaunchKernelGGL((k_gru_apply1_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, raw_of(c->yg, N2, 2 * Hd, Pr), gn_slot[8], gp,
                                c->h16[cur], c->rh16, H, W, N);
             TTC_HIP(c, hipGetLastError());
         }
         a.seg[1].hi = c->rh16.hi; a.seg[1].lo = c->rh16.lo;
+        a.nchunk = h0 ? Cx8 : 0;
         a.c.Cout = Hd;
         a.c.aux = gp.base + 4 * 32; a.c.aux_set_stride = gp.dir_stride;
         { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2, c->yc)); }
@@ -857,7 +867,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL((k_gru_apply2_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, raw_of(c->yc, N2, Hd, Pr), gn_slot[9], gp,
                                raw_of(c->yg, N2, 2 * Hd, Pr), gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h16[cur], c->h16[cur ^ 1],
-                               st == g.L - 1 ? c->gru16 : B16{}, H, W, N, c->cfg.zoneout);
+                               st == g.L - 1 ? c->gru16 : B16{}, H, W, N, c->cfg.zoneout, h0 ? 1 : 0);
             TTC_HIP(c, hipGetLastError());
         }
         cur ^= 1;
@@ -951,7 +961,11 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
     for (int i = 0; i < 10; ++i) gn_slot[i] = c->gn + (size_t)i * c->cfg.max_windows * 2 * 32;
 
     // ---------------- bi-directional ConvGRU ----------------
-    TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
+    // Step 0 of both directions starts from h = 0: with the Winograd kernels (which can skip channels) the gates and candidate
+    // convolutions run over the 17 frame channels only (3 of 7 chunks), r * h is never formed and the state buffer is neither
+    // cleared nor read -- the same sums, minus terms that are exactly zero.
+    const bool skip_h0 = conv_use_wino(c->w_gates, EPI_RAW) && conv_use_wino(c->w_cand, EPI_SSE) && !(Wp & 1);
+    if (!skip_h0) TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
     const GruParams gp{sm + c->small_off["gru/fw/"], c->small_off["gru/bw/"] - c->small_off["gru/fw/"]};
     int cur = 0;
     for (int st = 0; st < g.L; ++st) {
@@ -962,9 +976,11 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.w = c->w_gates.d_w; a.w_set_stride = c->w_gates.set_stride; a.n_per_set = N;
         a.out = c->yg; a.out_stride_n = 2L * Hd * Pr; a.out_plane = Pr; a.out_pitch = Wp; a.oy = a.ox = 0;
         a.stats = c->stats;
+        const bool h0 = skip_h0 && st == 0;
+        a.cin_run = h0 ? Cx : 0;
         { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, conv_stat_slots_for(c->w_gates, EPI_RAW, Hp, Wp), 4.0 * P, s));
-        {
+        if (!h0) {
             KTimer kt(c, "gru_apply1", s);
             hipLaunchKernelGGL(k_gru_apply1, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
                                c->h[cur], c->rh, H, W, N);
@@ -980,7 +996,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
                                c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h[cur], c->h[cur ^ 1],
-                               st == g.L - 1 ? c->gru_out : nullptr, H, W, N, c->cfg.zoneout);
+                               st == g.L - 1 ? c->gru_out : nullptr, H, W, N, c->cfg.zoneout, h0 ? 1 : 0);
             TTC_HIP(c, hipGetLastError());
         }
         cur ^= 1;

@@ -66,6 +66,9 @@ struct ConvArgs {
     const float* res;    // EPI_BIAS_RES / _TANH_ADD: residual, same indexing as out
     int same_pad;        // EPI_SWISH: 1 -> multiply by the partial-conv ratio (zero-padded SAME conv)
     int reflect_out;     // EPI_BIAS*: 1 -> also write the 1-px reflect rim of the (padded) output plane
+    int cin_run;         // > 0: only the first cin_run input channels are non-zero (ConvGRU step 0: h = 0) -- a kernel MAY skip the rest
+                         // (the Winograd kernels run ceil(cin_run / 8) chunks and read the other channels of the last one as 0);
+                         // kernels that ignore it read every channel, so the caller still has to provide zeros there
     unsigned long long* trace;   // probe aid (TTC_F32_TRACE): per-workgroup s_memtime stamps of the traced instantiation, else nullptr
     // EPI <= EPI_SWISH (the GroupNorm layers): the output ALWAYS keeps the input pitch -- out_pitch == Wp, oy == ox == 0,
     // out_plane == (Hp-2)*Wp: out[co][q] for the tile's own flat positions q, junk columns included -- so that a tile leaves
@@ -122,7 +125,8 @@ struct H16Seg {
 };
 struct H16Args {
     H16Seg seg[2];
-    int nchunk;          // seg[0].C8 + seg[1].C8
+    int nchunk;          // chunks to run: seg[0].C8 + seg[1].C8, or seg[0].C8 alone when the second segment is identically zero (ConvGRU step 0)
+    int nchunk_pack;     // chunks per (set, cout block) of the packed weight images (their stride); 0 = nchunk
     const uint4* w;      // packed LDS images: [set][cout_block][chunk][hi|lo][plane_units]
     long w_set_stride;
     // channel-blocked output (OUT_B16 kernels): [n][Cout8][o_plane] hi (+ lo), pixel (y + c.oy) * c.out_pitch + x + c.ox for the
