@@ -77,9 +77,14 @@ def pmc_traffic(precision, win):
     return None, None
 
 
-def roofline(precision, win, n_windows, gates_ms, gates_n):
-    """dominant kernel family = the ConvGRU gates convolution (49 -> 64, both directions, all windows of a tile per launch)"""
-    flops = conv_gates_flops(win, n_windows)
+def roofline(precision, win, n_windows, gates_ms, gates_n, length=4):
+    """dominant kernel family = the ConvGRU gates convolution (49 -> 64, both directions, all windows of a tile per launch).
+    gates_ms is the mean over the L launches of a forward; the launch of step 0 (hidden state identically zero) convolves the 17
+    frame channels only when the engine can skip channels (16-bit engine; fp32 Winograd), so the mean launch is priced at the
+    mean work: ((L - 1) + 17 / 49) / L of a full launch -- zero-times-weight products are not counted as algorithmic flops."""
+    skip0 = precision != "fp32" or winograd_on()
+    share = ((length - 1) + 17.0 / 49.0) / length if skip0 else 1.0
+    flops = conv_gates_flops(win, n_windows) * share
     ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
     traffic, src = pmc_traffic(precision, win)
     if precision == "fp32" and winograd_on():
@@ -87,11 +92,13 @@ def roofline(precision, win, n_windows, gates_ms, gates_n):
         # (2 * 9 * Cin * Cout flops per output pixel / launch time: what SURVEY 8d prices), so it may exceed `peak`; the rate
         # of the matrix instructions the kernel actually issues is reported beside it.
         tiles = 2 * n_windows * (-(-(win // 2) // 8)) * (-(-(win // 2) // 4))           # 8 x 4-tile regions per plane, both directions
-        mfmas = tiles * 4 * (6 * 32 + 8)                                               # 4 waves x (6 full chunks x 32 + 1 k-step x 8) for Cin = 49
+        # 4 waves x (6 full chunks x 32 + 1 k-step x 8) MFMAs per tile for Cin = 49; 3 chunks x 32 for the step-0 launch (17 channels)
+        mfmas = tiles * 4 * ((length - 1) * (6 * 32 + 8) + 3 * 32) / length
         issued = mfmas * 2.0 * 32 * 32 * 2
         return {"kernel": "conv3x3_wino<NCB=2,EPI_RAW> (ConvGRU gates, 49->64, both directions; Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
                 "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF,
                 "traffic": traffic, "traffic_source": src, "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops,
+                "flops_note": "mean over the L launches of a forward; the step-0 launch (h = 0) is priced at its 17 live channels",
                 "mfma_flops_issued_per_launch": issued,
                 "mfma_issue_frac": issued / (gates_ms * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12) if gates_ms > 0 else 0.0,
                 "note_winograd": "achieved / frac count the algorithmic 2*9*Cin*Cout flops per pixel; the kernel issues 4/9 of them "
@@ -105,7 +112,7 @@ def roofline(precision, win, n_windows, gates_ms, gates_n):
     nbytes = 2.0 * n_windows * (56 * (win + 2) ** 2 * 4 + 64 * win * (win + 2) * 4)          # hi+lo blocked input planes + fp32 raw output
     # 7 chunks = 3 chunk pairs (28 K-block products each: tap 8 of the two hi-tile products shares a K block) + 1 single (15),
     # against 3 x 9 / 2 = 13.5 per chunk without any padding
-    issued = 3.0 * flops * (56.0 / 49) * (10.0 / 9) * (99.0 / 105)
+    issued = 3.0 * conv_gates_flops(win, n_windows) * (10.0 / 9) * (((length - 1) * (56.0 / 49) * (99.0 / 105) + (24.0 / 49) * (43.0 / 45)) / length)   # step 0: 3 chunks = 1 pair (28) + 1 single (15) of 45
     return {"kernel": "conv3x3_h16<TERMS=3,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)", "bound": "mfma", "achieved": ach,
             "peak": H16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / H16_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": src,
             "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops,
@@ -514,7 +521,7 @@ def main():
                                      "max_dprob_e2e": None if args.no_dprob else dprob_e2e(ss[0], ref),
                                      "note": "same step with the other conv engine; informational, not the headline value"}
             if other in ("fp16", "bf16"):
-                r16 = roofline(other, args.win, 36, g2, 0)
+                r16 = roofline(other, args.win, 36, g2, 0, args.length)
                 extra["alt_" + other]["roofline"] = {k: r16[k] for k in ("kernel", "achieved", "peak", "frac", "mfma_issue_frac", "hbm_frac")}
             close(ss)
         # BASELINE's "168x168", "12-step" wording: the 168-window / 12-step geometry (2.82 TFLOP of model per tile instead of 1.51)
@@ -573,7 +580,7 @@ def main():
                 "win_in": args.win, "length": args.length, "dates": args.dates,
                 "model_tflop_per_tile": 36 * model_flops(args.win, args.length) / 1e12,
             },
-            "roofline": roofline(args.precision, args.win, 36, gates_ms, gates_n),
+            "roofline": roofline(args.precision, args.win, 36, gates_ms, gates_n, args.length),
         }
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms

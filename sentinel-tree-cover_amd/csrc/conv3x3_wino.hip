@@ -51,8 +51,8 @@ struct WinoArgs {
     ConvArgs a;
     const float* U; long u_set_stride;
     int nchunk, nks_last, RXn, RYn, ncp, ntiles;
-    int nrun, cin_run;   // chunks to run (<= nchunk, the packing stride of U) and the channels that are non-zero (the rest of the last
-                         // chunk is read as 0): ConvGRU step 0, whose hidden state is identically zero
+    int nrun, cin_run;   // chunks to run (<= nchunk, the packing stride of U): ConvGRU step 0, whose hidden state is identically zero, runs
+                         // the chunks that hold the cin_run frame channels only (the caller keeps the rest of the last chunk's channels zero)
     int probe;           // ablation bits (TTC_WINO_PROBE, timing only -- results are wrong): 1 every tile stages tile 0's inputs, 2 no output
                          // stores, 4 no input transform, 8 no A-operand refills, 16 no staging loads, 32 no epilogue, 64 no mid-chunk barrier / LDS stage store, 128 no chunk-start barrier
 };
@@ -144,16 +144,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     float2 g[NE];
     auto stage_load = [&](const TileS& t, int c) {
         if (probe & 16) return;
-        const int Cin = args()->a.Cin, C0 = args()->a.seg[0].C, crun = args()->cin_run;
+        const int Cin = args()->a.Cin, C0 = args()->a.seg[0].C;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             int ci = c * kWCK + (t.goff[k] >> 24);
-            const bool zero = ci >= crun;         // channels declared zero by the caller (their weights are NOT zero)
             ci = ci < Cin ? ci : Cin - 1;         // pad channels meet zero weights: any finite plane will do
-            ci = zero ? 0 : ci;
             const float* src = ci < C0 ? t.seg0 + (long)ci * plane : t.seg1 + (long)(ci - C0) * plane;
-            const float2 v = *reinterpret_cast<const float2*>(src + (t.goff[k] & 0xffffff));
-            g[k] = zero ? make_float2(0.f, 0.f) : v;
+            g[k] = *reinterpret_cast<const float2*>(src + (t.goff[k] & 0xffffff));
         }
     };
     auto stage_store = [&]() {

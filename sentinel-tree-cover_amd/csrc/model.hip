@@ -65,6 +65,15 @@ __global__ void k_gn_finalize(const float* __restrict__ stats, float* __restrict
     }
 }
 
+// the first `cnt` floats of every sequence n of two tensors with `stride_n` floats per sequence := 0 (hipMemset2DAsync measured
+// 3 ms per call on this shape)
+__global__ void k_zero_planes(float* __restrict__ a, float* __restrict__ b, long stride_n, long cnt) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    a[(long)blockIdx.y * stride_n + i] = 0.0f;
+    b[(long)blockIdx.y * stride_n + i] = 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------
 // ConvGRU, after the gates conv (model.py:259-270):
 //   r = sigmoid(GN(y[:32])); writes r*h (reflect-padded).  The update gate u = sigmoid(GN(y[32:])) is formed where it
@@ -966,6 +975,15 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
     // cleared nor read -- the same sums, minus terms that are exactly zero.
     const bool skip_h0 = conv_use_wino(c->w_gates, EPI_RAW) && conv_use_wino(c->w_cand, EPI_SSE) && !(Wp & 1);
     if (!skip_h0) TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
+    else {
+        // the third chunk holds frame channel 16 and state channels 0 .. 6: those seven planes of h (gates) and r * h (candidate) are
+        // the only state the step-0 convolutions read -- clear them (61 MB each instead of 279 MB + a full r * h pass)
+        const int zc = 8 * ((Cx + 7) / 8) - Cx;
+        KTimer kt(c, "zero_state_planes", s);
+        const long cnt = (long)zc * PP;
+        hipLaunchKernelGGL(k_zero_planes, dim3((unsigned)((cnt + 255) / 256), N2), dim3(256), 0, s, c->h[0], c->rh, (long)Hd * PP, cnt);
+        TTC_HIP(c, hipGetLastError());
+    }
     const GruParams gp{sm + c->small_off["gru/fw/"], c->small_off["gru/bw/"] - c->small_off["gru/fw/"]};
     int cur = 0;
     for (int st = 0; st < g.L; ++st) {

@@ -66,9 +66,9 @@ struct ConvArgs {
     const float* res;    // EPI_BIAS_RES / _TANH_ADD: residual, same indexing as out
     int same_pad;        // EPI_SWISH: 1 -> multiply by the partial-conv ratio (zero-padded SAME conv)
     int reflect_out;     // EPI_BIAS*: 1 -> also write the 1-px reflect rim of the (padded) output plane
-    int cin_run;         // > 0: only the first cin_run input channels are non-zero (ConvGRU step 0: h = 0) -- a kernel MAY skip the rest
-                         // (the Winograd kernels run ceil(cin_run / 8) chunks and read the other channels of the last one as 0);
-                         // kernels that ignore it read every channel, so the caller still has to provide zeros there
+    int cin_run;         // > 0: only the first cin_run input channels are non-zero (ConvGRU step 0: h = 0) -- a kernel MAY skip whole
+                         // 8-channel chunks past them (the Winograd kernels run ceil(cin_run / 8) chunks); every channel of a chunk that
+                         // does run is still READ, so the caller provides zeros there (model.hip clears the 7 state planes of chunk 2)
     unsigned long long* trace;   // probe aid (TTC_F32_TRACE): per-workgroup s_memtime stamps of the traced instantiation, else nullptr
     // EPI <= EPI_SWISH (the GroupNorm layers): the output ALWAYS keeps the input pitch -- out_pitch == Wp, oy == ox == 0,
     // out_plane == (Hp-2)*Wp: out[co][q] for the tile's own flat positions q, junk columns included -- so that a tile leaves
