@@ -126,7 +126,7 @@ __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restri
     const float* yu = yg + ((long)n * 64 + 32) * P + s;
     const float* gu = gn_gates + (long)n * 32 + 16;   // gates groups 8-15 = u
     const float* h = hcur + (long)n * 32 * PP + p;
-    float* hn = hnext + (long)n * 32 * PP + p;
+    float* hn = hnext ? hnext + (long)n * 32 * PP + p : nullptr;     // nullptr on the last step: nobody reads the state afterwards
     float* go = gru_out ? gru_out + ((long)(n - dir * N) * 64 + dir * 32) * PP + p : nullptr;
     float* uk = (u_keep && interior) ? u_keep + (long)n * 32 * (H * W) + su : nullptr;
 #pragma unroll 4
@@ -138,7 +138,7 @@ __global__ void k_gru_apply2(const float* __restrict__ yc, const float* __restri
         const float hv = h_zero ? 0.0f : h[(long)c * PP];
         const float hnew = uv * hv + (1.0f - uv) * cand;
         const float hz = hv * z + hnew * (1.0f - z);
-        hn[(long)c * PP] = hz;
+        if (hn) hn[(long)c * PP] = hz;
         if (go) go[(long)c * PP] = interior ? hz : 0.0f;
     }
 }
@@ -422,7 +422,7 @@ __global__ void k_gru_apply2_b16(Raw16 yc, const float* __restrict__ gn, GruPara
             const float hnew = uv * hv[j] + (1.0f - uv) * cand;
             o[j] = hv[j] * z + hnew * (1.0f - z);
         }
-        b16_store8<BF>(hnext.hi, hnext.lo, u, o);
+        if (hnext.hi) b16_store8<BF>(hnext.hi, hnext.lo, u, o);      // not on the last step: nobody reads the state afterwards
         if (gru_out.hi) {
             if (!interior) {
 #pragma unroll
@@ -875,7 +875,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
         {
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL((k_gru_apply2_b16<BF>), dim3((PP + 255) / 256, N2), dim3(256), 0, s, raw_of(c->yc, N2, Hd, Pr), gn_slot[9], gp,
-                               raw_of(c->yg, N2, 2 * Hd, Pr), gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h16[cur], c->h16[cur ^ 1],
+                               raw_of(c->yg, N2, 2 * Hd, Pr), gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h16[cur], st == g.L - 1 ? B16{} : c->h16[cur ^ 1],
                                st == g.L - 1 ? c->gru16 : B16{}, H, W, N, c->cfg.zoneout, h0 ? 1 : 0);
             TTC_HIP(c, hipGetLastError());
         }
@@ -1013,7 +1013,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         {
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
-                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h[cur], c->h[cur ^ 1],
+                               c->yg, gn_slot[8], c->keep_debug ? c->ug : nullptr, c->h[cur], st == g.L - 1 ? nullptr : c->h[cur ^ 1],
                                st == g.L - 1 ? c->gru_out : nullptr, H, W, N, c->cfg.zoneout, h0 ? 1 : 0);
             TTC_HIP(c, hipGetLastError());
         }
