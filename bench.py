@@ -386,6 +386,7 @@ def main():
         import importlib.util
         import shutil
         import tempfile
+        os.environ.setdefault("TTC_IO_THREADS", "16")      # inflate threads per ttc_read_hkl call (read once, at the library's first read; default 8)
         spec = importlib.util.spec_from_file_location("write_hdf5_fixture", os.path.join(ROOT, "tools", "write_hdf5_fixture.py"))
         WF = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(WF)
@@ -451,7 +452,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n_loop = 4 * n_tiles                # the loop visits every tile folder four times (page-cache hot, like a job's re-reads)
-            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k % n_tiles, 0) for k in range(n_loop)], root, workers=6))
+            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k % n_tiles, 0) for k in range(n_loop)], root, workers=8))
             res = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tm, on_result=on_result)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
@@ -463,7 +464,7 @@ def main():
         return {"value": n_loop * TILE * TILE / wall, "unit": "px/s", "tiles": n_loop, "tile_folders": n_tiles, "ms_per_tile_pipelined": wall / n_loop * 1e3,
                 "ms_per_stage_serial": {k: round(v * 1e3, 2) for k, v in stages.items()},
                 "host_seconds_in_loop": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
-                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": 6, "sessions": len(sessions),
+                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": 8, "inflate_threads_per_read": int(os.environ.get("TTC_IO_THREADS", "8")), "sessions": len(sessions),
                 "tiles_rerun_staged": int(sum(1 for r in res if r[3])),
                 "slowest_host_stage": {"name": slowest, "ms": round(host_ms[slowest], 2), "x_gpu_stage": round(host_ms[slowest] / gpu_ms, 2)},
                 "note": "job-level: files -> ttc_read_hkl -> pinned H2D -> detection + ttc_predict_tile -> D2H -> ttc_write_geotiff_u8; "
