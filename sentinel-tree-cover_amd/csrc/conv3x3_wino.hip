@@ -27,6 +27,7 @@
 // sums and the flat [cout][y * Wp + x] output layout are those of conv_common.h's conv_epilogue_flat, so every consumer is
 // unchanged.  fp32 throughout; the transforms' constants are 0, +-1, +-1/2: max |delta| vs the direct kernel ~1e-6 relative.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -430,6 +431,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     }
 }
 
+// CUs of the current device, cached per device id (a process may drive several GPUs)
+int cus_of_current_device() {
+    static std::atomic<int> per_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = per_dev[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        v = 256;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+        per_dev[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 template <int NCB, int EPI>
 hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t s) {
     constexpr int TB = 2 / NCB, NT = 32 * TB, IR = 2 * 4 * TB + 2;
@@ -447,9 +462,7 @@ hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     const int nks_last = (rem + 1) / 2;
     const long ntiles = (long)RXn * RYn * ncp * n;
     static const int forced = [] { const char* e = getenv("TTC_WINO_PERSIST"); return e ? atoi(e) : -1; }();   // probe: 0 = one workgroup per tile
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const long resident = forced >= 0 ? forced : 2L * cus;
+    const long resident = forced >= 0 ? forced : 2L * cus_of_current_device();
     const long grid = resident > 0 ? std::min(ntiles, resident) : ntiles;
     static const int probe = [] { const char* e = getenv("TTC_WINO_PROBE"); return e ? atoi(e) : 0; }();
     const WinoArgs wa{a, pw.d_wu, pw.set_stride_w, pw.nchunk_w, nks_last, RXn, RYn, ncp, (int)ntiles, nrun, cin_run, probe};
