@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra legs (alt_fp16 / alt_bf16 / l12_w168 / preprocess_only)")
     ap.add_argument("--no-dprob", action="store_true", help="skip max |dprob| (HIP vs the oracle on windows of the bench's own tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle pass (also drops max_dprob_e2e)")
+    ap.add_argument("--job-level-only", action="store_true", help="run the job-level leg alone (files -> rasters -> GeoTIFFs) and print its JSON")
+    ap.add_argument("--job-readers", type=int, default=4, help="host threads that read tile folders ahead in the job-level leg")
     args = ap.parse_args()
 
     import torch
@@ -386,7 +388,6 @@ def main():
         import importlib.util
         import shutil
         import tempfile
-        os.environ.setdefault("TTC_IO_THREADS", "16")      # inflate threads per ttc_read_hkl call (read once, at the library's first read; default 8)
         spec = importlib.util.spec_from_file_location("write_hdf5_fixture", os.path.join(ROOT, "tools", "write_hdf5_fixture.py"))
         WF = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(WF)
@@ -452,7 +453,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n_loop = 4 * n_tiles                # the loop visits every tile folder four times (page-cache hot, like a job's re-reads)
-            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k % n_tiles, 0) for k in range(n_loop)], root, workers=8))
+            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k % n_tiles, 0) for k in range(n_loop)], root, workers=args.job_readers))
             res = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tm, on_result=on_result)
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
@@ -464,13 +465,16 @@ def main():
         return {"value": n_loop * TILE * TILE / wall, "unit": "px/s", "tiles": n_loop, "tile_folders": n_tiles, "ms_per_tile_pipelined": wall / n_loop * 1e3,
                 "ms_per_stage_serial": {k: round(v * 1e3, 2) for k, v in stages.items()},
                 "host_seconds_in_loop": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
-                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": 8, "inflate_threads_per_read": int(os.environ.get("TTC_IO_THREADS", "8")), "sessions": len(sessions),
+                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": args.job_readers, "inflate_threads_per_read": int(os.environ.get("TTC_IO_THREADS", "8")), "sessions": len(sessions),
                 "tiles_rerun_staged": int(sum(1 for r in res if r[3])),
                 "slowest_host_stage": {"name": slowest, "ms": round(host_ms[slowest], 2), "x_gpu_stage": round(host_ms[slowest] / gpu_ms, 2)},
                 "note": "job-level: files -> ttc_read_hkl -> pinned H2D -> detection + ttc_predict_tile -> D2H -> ttc_write_geotiff_u8; "
                         "serial stage times are of tile 0 alone, the rate is the pipelined loop (job.iter_raw_tiles + job.predict_tiles)"}
 
     sessions = make_sessions(args.precision)
+    if args.job_level_only:
+        print(json.dumps({"job_level": job_level_leg(sessions, 6)}))
+        return
     if args.preprocess_only:
         pre = preprocess_leg(sessions, args.tiles, args.warmup)
         if rank == 0:

@@ -11,6 +11,10 @@
 // in the layouts hickle 3.4, 4 and 5 produce (tools/gen_golden_hkl.py, run with /opt/conda/bin/python3.9: root arrays, container
 // groups, attributes, gzip with and without shuffle, contiguous int64 date lists).  hickle itself is not installed anywhere in the
 // image; tools/write_hdf5_fixture.py (a byte-level writer from the same specification) is kept for the malformed-file tests.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -28,8 +32,22 @@ namespace {
 
 constexpr uint64_t kUndef = ~0ull;
 
+// the file, memory-mapped read-only: nothing is copied (the query call and the read call of a caller each used to fread the whole
+// file -- 130 MB of memcpy per tile), inflate reads the compressed chunks straight from the page cache
+struct Bytes {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    const uint8_t& operator[](size_t i) const { return p[i]; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+};
 struct File {
-    std::vector<uint8_t> b;
+    Bytes b;
+    File() = default;
+    File(const File&) = delete;
+    File& operator=(const File&) = delete;
+    ~File() { if (b.p) munmap(const_cast<uint8_t*>(b.p), b.n); }
     bool ok(uint64_t off, uint64_t n) const { return off <= b.size() && n <= b.size() - off; }
     uint64_t u(uint64_t off, int n) const {          // little-endian unsigned of n bytes
         uint64_t v = 0;
@@ -317,15 +335,16 @@ ttc_status ttc_read_hkl(const char* path, const char* name, void* h_out, size_t 
     if (!path || !shape || !ndim || !elem_size || !type_class || !is_signed) return fail(TTC_ERR_ARG, "read_hkl: null argument");
     File f;
     {
-        FILE* fp = std::fopen(path, "rb");
-        if (!fp) return fail(TTC_ERR_IO, std::string("read_hkl: cannot open ") + path);
-        std::fseek(fp, 0, SEEK_END);
-        const long n = std::ftell(fp);
-        std::fseek(fp, 0, SEEK_SET);
-        f.b.resize(n > 0 ? (size_t)n : 0);
-        const size_t got = f.b.empty() ? 0 : std::fread(f.b.data(), 1, f.b.size(), fp);
-        std::fclose(fp);
-        if (got != f.b.size()) return fail(TTC_ERR_IO, "read_hkl: short read");
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return fail(TTC_ERR_IO, std::string("read_hkl: cannot open ") + path);
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); return fail(TTC_ERR_IO, "read_hkl: cannot stat the file"); }
+        if (sb.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); return fail(TTC_ERR_IO, "read_hkl: cannot map the file"); }
+            f.b.p = static_cast<const uint8_t*>(m); f.b.n = (size_t)sb.st_size;
+        }
+        close(fd);
     }
     static const uint8_t sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
     if (f.b.size() < 96 || std::memcmp(f.b.data(), sig, 8) != 0) return fail(TTC_ERR_ARG, "read_hkl: not an HDF5 file");
