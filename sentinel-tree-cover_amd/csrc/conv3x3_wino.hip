@@ -52,6 +52,7 @@ struct WinoArgs {
     ConvArgs a;
     const float* U; long u_set_stride;
     int nchunk, nks_last, RXn, RYn, ncp, ntiles;
+    unsigned long long m_rx, m_cp, m_ry, m_set;   // floor(2^40 / d) + 1 for d = RXn, ncp, RYn, n_per_set: x / d == (x * m) >> 40 while x * d < 2^40
     int nrun, cin_run;   // chunks to run (<= nchunk, the packing stride of U): ConvGRU step 0, whose hidden state is identically zero, runs
                          // the chunks that hold the cin_run frame channels only (the caller keeps the rest of the last chunk's channels zero)
     unsigned long long* trace;   // probe aid (TTC_WINO_TRACE): 64 x u64 per workgroup, s_memtime stamps of the workgroup's third tile
@@ -114,16 +115,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         int goff[NE];                            // staging pairs: offset inside the plane (clamped into it) | channel << 24
         int n, rx, ry, cp, set;
     };
+    // staging pair k of this thread inside the [8][IR][18] chunk image: row | col << 8 | channel << 24 (tile-independent)
+    int rc[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        int e = tid + 256 * k;
+        e = e < INE2 ? e : INE2 - 1;
+        const int cl = e / (IR * (kIC / 2)), r2 = e - cl * (IR * (kIC / 2));
+        const int row = r2 / (kIC / 2), col = 2 * (r2 - row * (kIC / 2));
+        rc[k] = row | (col << 8) | (cl << 24);
+    }
+    // tile id -> (window, region row, cout pair, region column): divisions by launch constants as multiply-shift on the scalar unit
+    // (the plain form is ~35 vector instructions per division, five of them per tile, with no matrix work beside them)
+    auto mdiv = [](int x, unsigned long long m) { return (int)(((unsigned long long)(unsigned)x * m) >> 40); };
     auto tile_of = [&](int lid) {
         TileS t;
         const KArgs ka = args();
         const int ncp = ka->ncp;
-        t.rx = lid % RXn;
-        int rest = lid / RXn;
-        t.cp = rest % ncp; rest /= ncp;
-        t.ry = rest % RYn;
-        t.n = rest / RYn;
-        t.set = t.n / ka->a.n_per_set;
+        int rest = mdiv(lid, ka->m_rx);
+        t.rx = lid - rest * RXn;
+        int q = mdiv(rest, ka->m_cp);
+        t.cp = rest - q * ncp; rest = q;
+        q = mdiv(rest, ka->m_ry);
+        t.ry = rest - q * RYn;
+        t.n = q;
+        t.set = mdiv(t.n, ka->m_set);
         const int nn = t.n - t.set * ka->a.n_per_set;
         t.seg0 = ka->a.seg[0].base + (long)nn * ka->a.seg[0].stride_n + ka->a.seg[0].set_off[t.set];
         t.seg1 = ka->a.seg[1].C > 0 ? ka->a.seg[1].base + (long)nn * ka->a.seg[1].stride_n + ka->a.seg[1].set_off[t.set] : t.seg0;
@@ -132,13 +148,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         const int y0 = (probe & 1) ? 0 : t.ry * (2 * RTY), x0 = (probe & 1) ? 0 : t.rx * (2 * kRTX);
         if (probe & 1) { t.seg0 = ka->a.seg[0].base; t.seg1 = ka->a.seg[1].C > 0 ? ka->a.seg[1].base : t.seg0; }
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {           // float2 element e = tid + 256 k of the [8][IR][18] chunk image (Wp is even: checked at launch)
-            int e = tid + 256 * k;
-            e = e < INE2 ? e : INE2 - 1;
-            const int cl = e / (IR * (kIC / 2)), r2 = e - cl * (IR * (kIC / 2));
-            const int row = r2 / (kIC / 2), col = 2 * (r2 - row * (kIC / 2));
-            const int yy = min(y0 + row, Hp - 1), xx = min(x0 + col, Wp - 2);
-            t.goff[k] = (yy * Wp + xx) | (cl << 24);
+        for (int k = 0; k < NE; ++k) {           // float2 element e = tid + 256 k of the chunk image (Wp is even: checked at launch)
+            const int yy = min(y0 + (rc[k] & 0xff), Hp - 1), xx = min(x0 + ((rc[k] >> 8) & 0xff), Wp - 2);
+            t.goff[k] = (yy * Wp + xx) | (rc[k] & 0xff000000);
         }
         return t;
     };
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         tk += nx;
         cur = nxt;
         has_next = tk + nx < tcnt;
-        if (has_next) nxt = tile_of(tstart + tk + nx);
+        if (has_next) nxt = tile_of(tstart + tk + nx);   // (located behind the first chunk instead: measured slower, 0.626 vs 0.617 ms gates, more spills in the 32-channel form)
         phase(3);
     }
 }
@@ -538,7 +550,11 @@ hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     const long resident = forced >= 0 ? forced : 2L * cus_of_current_device();
     const long grid = resident > 0 ? std::min(ntiles, resident) : ntiles;
     static const int probe = [] { const char* e = getenv("TTC_WINO_PROBE"); return e ? atoi(e) : 0; }();
-    WinoArgs wa{a, pw.d_wu, pw.set_stride_w, pw.nchunk_w, nks_last, RXn, RYn, ncp, (int)ntiles, nrun, cin_run, nullptr, probe};
+    auto magic = [](long d) { return (1ULL << 40) / (unsigned long long)d + 1ULL; };
+    // x / d == (x * magic(d)) >> 40 needs x * d < 2^40: tile ids stay below 2^24 and the divisors below 2^12
+    if (ntiles >= (1L << 24) || RXn >= 4096 || RYn >= 4096 || ncp >= 4096 || a.n_per_set >= 4096 || a.n_per_set < 1) return hipErrorInvalidValue;
+    WinoArgs wa{a, pw.d_wu, pw.set_stride_w, pw.nchunk_w, nks_last, RXn, RYn, ncp, (int)ntiles,
+                magic(RXn), magic(ncp), magic(RYn), magic(a.n_per_set), nrun, cin_run, nullptr, probe};
     {   // probe aid: TTC_WINO_TRACE=<file> traces ONE full-length launch of the layer kind TTC_WINO_TRACE_EPI (default 0 = the ConvGRU gates)
         static const char* trace_path = getenv("TTC_WINO_TRACE");
         static const int trace_epi = [] { const char* e = getenv("TTC_WINO_TRACE_EPI"); return e ? atoi(e) : (int)EPI_RAW; }();
