@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     unsigned long long* trbase = (TRACE && args()->trace && tid == 0) ? args()->trace + (long)blockIdx.x * 64 : nullptr;
     unsigned long long* tr = nullptr;
     auto stamp = [&](int i) { if constexpr (TRACE == 2) { if (tr) tr[i] = __builtin_amdgcn_s_memtime(); } };
-    unsigned long long ph_t = 0, ph_sum[4] = {0, 0, 0, 0};   // TRACE: chunk loop / output transform / epilogue / tile advance cycles of this wave, all tiles
+    unsigned long long ph_t = 0, ph_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // TRACE: cycles of this wave over all tiles: 0 chunk loop, 1 exchange reads + adds, 2 output stores, 3 tile advance,
+                                                                // 4 wait at the first exchange barrier, 5 row transform + exchange writes, 6 wait at the second barrier, 7 epilogue op / args / GroupNorm sums
     auto phase = [&](int i) {
         if constexpr (TRACE != 0) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -366,18 +367,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         // last chunk has just been multiplied from (`par` after the flip is the one that holds the NEXT tile's first chunk; the
         // other one is idle until the transform of the next tile's second chunk, two barriers away) -- plus, for the 32-tile
         // form whose V buffers are 16 KB, a second 16 KB region.
-        // exchange layout [r >> 3][pair][sender][r & 7][jj][lane]: one base register per half and direction, every access a
-        // compile-time offset from it (64 separately formed addresses were hoisted out of the tile walk as SGPR pairs and spilled)
+        // exchange layout [r >> 3][pair][sender][(r & 7) >> 1][lane][r & 1][jj]: a lane's four values of two accumulator rows travel as
+        // ONE 16-byte LDS access (8 writes + 8 reads per wave); one base register per half and direction, every access a compile-time
+        // offset from it (64 separately formed addresses were hoisted out of the tile walk as SGPR pairs and spilled)
         stamp(57);
         phase(0);
         float* ex0 = Vb + (par ^ 1) * VBUF;
         float* ex1 = TB == 2 ? ex0 + EXF / 2 : exx;
-        const int exo_w = ((oth * 2 + xh) * 8 * 2) * 64 + lane, exo_r = ((oth * 2 + (xh ^ 1)) * 8 * 2) * 64 + lane;
-        float* exw[2] = {ex0 + exo_w, ex1 + exo_w};
-        const float* exr[2] = {ex0 + exo_r, ex1 + exo_r};
+        // (the 16-byte form is the gates kernel's: measured on one box, gates 0.616 -> 0.600 ms with it, the swish layers 0.60 -> 0.63 ms
+        // and the 32-channel kernels +4 % -- those keep one value per LDS access, layout [r >> 3][pair][sender][r & 7][jj][lane])
+        constexpr bool WIDE_EX = NCB == 2 && EPI == EPI_RAW;
+        const int exo_w = WIDE_EX ? ((oth * 2 + xh) * 4) * 64 + lane : ((oth * 2 + xh) * 8 * 2) * 64 + lane;
+        const int exo_r = WIDE_EX ? ((oth * 2 + (xh ^ 1)) * 4) * 64 + lane : ((oth * 2 + (xh ^ 1)) * 8 * 2) * 64 + lane;
+        float4* exw[2] = {reinterpret_cast<float4*>(ex0) + exo_w, reinterpret_cast<float4*>(ex1) + exo_w};
+        const float4* exr[2] = {reinterpret_cast<const float4*>(ex0) + exo_r, reinterpret_cast<const float4*>(ex1) + exo_r};
+        float* exw1[2] = {ex0 + exo_w, ex1 + exo_w};
+        const float* exr1[2] = {ex0 + exo_r, ex1 + exo_r};
         float keep[16][2];                        // own output row (i = xh)
         if (probe & 32) {                         // ablation: no output transform / epilogue at all
-            if constexpr (TRACE != 0) { if (trbase && !has_next) { trbase[61] = __builtin_amdgcn_s_memrealtime(); trbase[63] = __builtin_amdgcn_s_memtime(); trbase[7] = ph_sum[0]; trbase[15] = ph_sum[1]; trbase[23] = ph_sum[2]; trbase[39] = ph_sum[3]; trbase[31] = (unsigned long long)(ti + 1); } }
+            if constexpr (TRACE != 0) { if (trbase && !has_next) { trbase[61] = __builtin_amdgcn_s_memrealtime(); trbase[63] = __builtin_amdgcn_s_memtime(); trbase[7] = ph_sum[0]; trbase[15] = ph_sum[1]; trbase[23] = ph_sum[2]; trbase[39] = ph_sum[3]; trbase[47] = ph_sum[4]; trbase[55] = ph_sum[5]; trbase[32] = ph_sum[6]; trbase[33] = ph_sum[7]; trbase[31] = (unsigned long long)(ti + 1); } }
             if (!has_next) break;
             tk += nx; cur = nxt; has_next = tk + nx < tcnt;
             if (has_next) nxt = tile_of(tstart + tk + nx);
@@ -385,29 +393,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
             continue;
         }
         __syncthreads();                          // every wave has finished reading that V buffer
+        phase(4);
+        if constexpr (WIDE_EX) {
+            // two code paths under a wave-uniform branch (written with per-value selects on xh the compiler produced ~400 instructions
+            // here, a third of them register moves feeding packed adds)
+            if (xh == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float Tt[2][2];
+                for (int rp = 0; rp < 8; ++rp) {
+                    float4 snd;
 #pragma unroll
-            for (int bl = 0; bl < 2; ++bl) {
-                Tt[0][bl] = acc[0 + bl][r] + acc[2 + bl][r] + acc[4 + bl][r];
-                Tt[1][bl] = acc[2 + bl][r] - acc[4 + bl][r] - acc[6 + bl][r];
+                    for (int q = 0; q < 2; ++q) {
+                        const int r = 2 * rp + q;
+                        const float t00 = acc[0][r] + acc[2][r] + acc[4][r], t01 = acc[1][r] + acc[3][r] + acc[5][r];
+                        const float t10 = acc[2][r] - acc[4][r] - acc[6][r], t11 = acc[3][r] - acc[5][r] - acc[7][r];
+                        keep[r][0] = t00 + t01; keep[r][1] = t01;
+                        if (q == 0) { snd.x = t10 + t11; snd.y = t11; } else { snd.z = t10 + t11; snd.w = t11; }
+                    }
+                    exw[rp >> 2][(rp & 3) * 64] = snd;
+                }
+            } else {
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    float4 snd;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int r = 2 * rp + q;
+                        const float t00 = acc[0][r] + acc[2][r] + acc[4][r], t01 = acc[1][r] + acc[3][r] + acc[5][r];
+                        const float t10 = acc[2][r] - acc[4][r] - acc[6][r], t11 = acc[3][r] - acc[5][r] - acc[7][r];
+                        keep[r][0] = t10; keep[r][1] = -t10 - t11;
+                        if (q == 0) { snd.x = t00; snd.y = -t00 - t01; } else { snd.z = t00; snd.w = -t00 - t01; }
+                    }
+                    exw[rp >> 2][(rp & 3) * 64] = snd;
+                }
             }
-            float p[2][2];
+        } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                p[i][0] = xh == 0 ? Tt[i][0] + Tt[i][1] : Tt[i][0];
-                p[i][1] = xh == 0 ? Tt[i][1] : -Tt[i][0] - Tt[i][1];
+            for (int r = 0; r < 16; ++r) {
+                float Tt[2][2];
+#pragma unroll
+                for (int bl = 0; bl < 2; ++bl) {
+                    Tt[0][bl] = acc[0 + bl][r] + acc[2 + bl][r] + acc[4 + bl][r];
+                    Tt[1][bl] = acc[2 + bl][r] - acc[4 + bl][r] - acc[6 + bl][r];
+                }
+                float p[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    p[i][0] = xh == 0 ? Tt[i][0] + Tt[i][1] : Tt[i][0];
+                    p[i][1] = xh == 0 ? Tt[i][1] : -Tt[i][0] - Tt[i][1];
+                }
+                keep[r][0] = xh == 0 ? p[0][0] : p[1][0]; keep[r][1] = xh == 0 ? p[0][1] : p[1][1];
+                exw1[r >> 3][((r & 7) * 2 + 0) * 64] = xh == 0 ? p[1][0] : p[0][0];
+                exw1[r >> 3][((r & 7) * 2 + 1) * 64] = xh == 0 ? p[1][1] : p[0][1];
             }
-            keep[r][0] = xh == 0 ? p[0][0] : p[1][0]; keep[r][1] = xh == 0 ? p[0][1] : p[1][1];
-            exw[r >> 3][((r & 7) * 2 + 0) * 64] = xh == 0 ? p[1][0] : p[0][0];
-            exw[r >> 3][((r & 7) * 2 + 1) * 64] = xh == 0 ? p[1][1] : p[0][1];
         }
+        phase(5);
         __syncthreads();
+        phase(6);
+        if constexpr (WIDE_EX) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            keep[r][0] += exr[r >> 3][((r & 7) * 2 + 0) * 64];
-            keep[r][1] += exr[r >> 3][((r & 7) * 2 + 1) * 64];
+            for (int rp = 0; rp < 8; ++rp) {
+                const float4 v = exr[rp >> 2][(rp & 3) * 64];
+                keep[2 * rp][0] += v.x; keep[2 * rp][1] += v.y;
+                keep[2 * rp + 1][0] += v.z; keep[2 * rp + 1][1] += v.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                keep[r][0] += exr1[r >> 3][((r & 7) * 2 + 0) * 64];
+                keep[r][1] += exr1[r >> 3][((r & 7) * 2 + 1) * 64];
+            }
         }
 
         stamp(58);
@@ -459,10 +513,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const float u0 = keep[4 * k + rr][0], u1 = keep[4 * k + rr][1];
-                        if (v0) { sm_ += u0; q += u0 * u0; }
-                        if (v1) { sm_ += u1; q += u1 * u1; }
+                        sm_ += u0; q += u0 * u0;
+                        sm_ += u1; q += u1 * u1;
                     }
-                    red[2 * k] = sm_; red[2 * k + 1] = q;
+                    // W is even in this kernel (checked at launch): a tile's two columns are inside the image together, so ONE select
+                    // per sum replaces the 16 per-value ones (same additions in the same order for the pixels that count)
+                    red[2 * k] = v1 ? sm_ : 0.f; red[2 * k + 1] = v1 ? q : 0.f;
                 }
                 half_wave_sums(red);
                 if (tcol == 31) {
@@ -477,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
                     }
                 }
             }
+            phase(7);
             float* outn = a.out + (long)cur.n * a.out_stride_n;
             const bool even_pitch = ((a.out_plane | (long)Wp) & 1L) == 0;           // wave-uniform
             const long opix = (long)y * Wp + xa;
@@ -506,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         }
         stamp(59);
         phase(2);
-        if constexpr (TRACE != 0) { if (trbase && !has_next) { trbase[61] = __builtin_amdgcn_s_memrealtime(); trbase[63] = __builtin_amdgcn_s_memtime(); trbase[7] = ph_sum[0]; trbase[15] = ph_sum[1]; trbase[23] = ph_sum[2]; trbase[39] = ph_sum[3]; trbase[31] = (unsigned long long)(ti + 1); } }
+        if constexpr (TRACE != 0) { if (trbase && !has_next) { trbase[61] = __builtin_amdgcn_s_memrealtime(); trbase[63] = __builtin_amdgcn_s_memtime(); trbase[7] = ph_sum[0]; trbase[15] = ph_sum[1]; trbase[23] = ph_sum[2]; trbase[39] = ph_sum[3]; trbase[47] = ph_sum[4]; trbase[55] = ph_sum[5]; trbase[32] = ph_sum[6]; trbase[33] = ph_sum[7]; trbase[31] = (unsigned long long)(ti + 1); } }
         if (!has_next) break;
         tk += nx;
         cur = nxt;

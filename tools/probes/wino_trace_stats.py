@@ -7,10 +7,16 @@ fine = (a[:, 56] > 0).any()
 whole = a[a[:, 61] > 0]
 if len(whole):
     nt = whole[:, 31].astype(float)
-    names4 = ["chunk loop", "output transform + exchange", "epilogue (op, stats, stores)", "tile advance (tile_of)"]
-    per = [np.median(whole[:, k] / nt) for k in (7, 15, 23, 39)]
-    print("cycles per tile, wave 0 of each workgroup, mean over its whole walk (median over workgroups): " +
-          "  ".join(f"{n} {v:.0f}" for n, v in zip(names4, per)) + f"  sum {sum(per):.0f}  tiles/workgroup {np.median(nt):.0f}")
+    names8 = ["chunk loop", "wait exchange barrier 1", "row transform + exchange writes", "wait exchange barrier 2", "exchange reads + adds",
+              "epilogue op / args / GroupNorm sums", "output stores", "tile advance (tile_of)"]
+    per = [np.median(whole[:, k] / nt) for k in (7, 47, 55, 32, 15, 33, 23, 39)]
+    print("cycles per tile, wave 0 of each workgroup, mean over its whole walk (median over workgroups):")
+    for n, v in zip(names8, per):
+        print(f"  {n:38s} {v:8.0f}")
+    print(f"  {'sum':38s} {sum(per):8.0f}   tiles/workgroup {np.median(nt):.0f}")
+    ref = (whole[:, 61] - whole[:, 60]) / 100e6
+    clk = (whole[:, 63] - whole[:, 62]) / ref
+    print(f"  whole walk {np.median(ref) * 1e3:.3f} ms (median), shader clock {np.median(clk) / 1e9:.3f} GHz")
 if not fine:
     a = a[:0]
 a = a[a[:, 56] > 0]
