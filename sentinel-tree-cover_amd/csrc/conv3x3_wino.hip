@@ -165,8 +165,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         for (int k = 0; k < NE; ++k) {
             int ci = c * kWCK + (goff[k] >> 24);
             ci = ci < Cin ? ci : Cin - 1;         // pad channels meet zero weights: any finite plane will do
-            const float* src = ci < C0 ? s0 + (long)ci * plane : s1 + (long)(ci - C0) * plane;
-            g[k] = *reinterpret_cast<const float2*>(src + (goff[k] & 0xffffff));
+            // channel * plane < 2^31 floats, both factors < 2^24 (checked at launch): one 24-bit multiply-add instead of the 64-bit
+            // product's three quarter-rate multiplies, per request and chunk
+            const bool lo = ci < C0;
+            const float* base = lo ? s0 : s1;
+            const unsigned off = __umul24((unsigned)(lo ? ci : ci - C0), (unsigned)plane) + (unsigned)(goff[k] & 0xffffff);
+            g[k] = *reinterpret_cast<const float2*>(base + off);
         }
     };
     auto stage_load = [&](const TileS& t, int c) { stage_load_from(t.seg0, t.seg1, t.goff, c); };
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         // offset from it (64 separately formed addresses were hoisted out of the tile walk as SGPR pairs and spilled)
         stamp(57);
         phase(0);
+        __builtin_amdgcn_s_setprio(2);            // the tile's tail (vector / LDS / store work only) goes first on the issue ports it shares with the partner's matrix stream
         float* ex0 = Vb + (par ^ 1) * VBUF;
         float* ex1 = TB == 2 ? ex0 + EXF / 2 : exx;
         // (the 16-byte form is the gates kernel's: measured on one box, gates 0.616 -> 0.600 ms with it, the swish layers 0.60 -> 0.63 ms
@@ -568,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
         tk += nx;
         cur = nxt;
         has_next = tk + nx < tcnt;
+        __builtin_amdgcn_s_setprio(0);
         if (has_next) nxt = tile_of(tstart + tk + nx);   // (located behind the first chunk instead: measured slower, 0.626 vs 0.617 ms gates, more spills in the 32-channel form)
         phase(3);
     }
@@ -597,7 +603,7 @@ hipError_t launch_w(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     const int TX = (W + 1) / 2, TY = (H + 1) / 2;
     const int RXn = (TX + kRTX - 1) / kRTX, RYn = (TY + 4 * TB - 1) / (4 * TB);
     const int ncp = (a.Cout + 32 * NCB - 1) / (32 * NCB);
-    if ((long)a.Hp * a.Wp >= (1L << 24) || (a.Wp & 1) || pw.nchunk_w < 3) return hipErrorInvalidValue;
+    if ((long)a.Hp * a.Wp >= (1L << 24) || (a.Wp & 1) || pw.nchunk_w < 3 || (long)a.Cin * a.Hp * a.Wp >= (1L << 31)) return hipErrorInvalidValue;
     const int cin_run = (a.cin_run > 0 && a.cin_run < a.Cin) ? a.cin_run : a.Cin;
     const int nrun = std::max(3, (cin_run + kWCK - 1) / kWCK);                // the cross-tile stream needs >= 3 chunks per tile
     const int rem = std::min(a.Cin, nrun * kWCK) - kWCK * (nrun - 1);
