@@ -194,6 +194,11 @@ __global__ __launch_bounds__(kThreads, (NCG == 1 && CK <= 8) ? 3 : 2) void conv3
         return;
     }
     conv_epilogue<NCG, EPI>(a, acc, n, cb, bq, nblk_q, aux, tid);
+    if (TRACE && tr) {
+        tr[3] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tr[4] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 template <int CK, int NCG, int EPI>
@@ -201,12 +206,16 @@ hipError_t launch_t(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t 
     constexpr int BN = NCG * 32;
     const int TL = kBQ + 2 * a.Wp + 2;
     const int TLp = (TL + 3) & ~3;
-    const size_t lds = std::max((size_t)(CK * TLp + 9 * CK * BN) * sizeof(float), kFlatLdsBytes);
+    // the LDS transpose of the flat epilogue (66 KB) exists in the GroupNorm layers only.  (Requested for every layer it held DSen2's
+    // 32 -> 32 kernels -- 33 KB of staging, 151 VGPRs -- at two workgroups per CU instead of three; measured: 5.06 ms per tile either
+    // way.  The traced launch shows why: 3 x 36.9 k of 133 k cycles per tile are MFMA issue, 83 % of the pipe, at a 1.8 GHz clock.)
+    const size_t lds_main = (size_t)(CK * TLp + 9 * CK * BN) * sizeof(float);
+    const size_t lds = EPI <= EPI_SWISH ? std::max(lds_main, kFlatLdsBytes) : lds_main;
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_f32<CK, NCG, EPI>, lds); e != hipSuccess) return e;
     const int nblk_q = conv_q_blocks(a.Hp, a.Wp);
     dim3 grid(nblk_q * pw.ncb * n);
-    if constexpr (NCG == 2 && ((CK == 10 && EPI == EPI_RAW) || (CK == 8 && EPI == EPI_SWISH))) {   // probe aid: one traced launch
+    if constexpr ((NCG == 2 && ((CK == 10 && EPI == EPI_RAW) || (CK == 8 && EPI == EPI_SWISH))) || (NCG == 1 && CK == 8 && EPI == EPI_BIAS_RELU)) {   // probe aid: one traced launch
         static const char* trace_path = getenv("TTC_F32_TRACE");           // of the gates conv (or, TTC_F32_TRACE_EPI=2, of the first
         static const int trace_epi = [] { const char* e = getenv("TTC_F32_TRACE_EPI"); return e ? atoi(e) : (int)EPI_RAW; }();   // big U-Net block)
         static int trace_left = trace_path ? 1 : 0;
