@@ -26,7 +26,7 @@ def parse(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04_e"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04_g"
     rnd = tag.split("_")[0]
     algo = {"f32": {"read": 72 * 49 * 174 ** 2 * 4, "write": 72 * 64 * 172 * 174 * 4,
                     "what": "read 72 planes-sets x 49 ch x 174^2 x 4 B, write 72 x 64 x 172 x 174 x 4 B (input pitch)"},
