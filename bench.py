@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle pass (also drops max_dprob_e2e)")
     ap.add_argument("--job-level-only", action="store_true", help="run the job-level leg alone (files -> rasters -> GeoTIFFs) and print its JSON")
     ap.add_argument("--job-readers", type=int, default=4, help="host threads that read tile folders ahead in the job-level leg")
+    ap.add_argument("--job-no-arena", action="store_true", help="job-level leg: stage the raw arrays through pinned buffers on the loop's thread instead of reading into a PinnedArena")
     args = ap.parse_args()
 
     import torch
@@ -446,16 +447,29 @@ def main():
             tm = {}
             written = []
 
+            from concurrent.futures import ThreadPoolExecutor
+            writer = ThreadPoolExecutor(max_workers=2)       # LZW + file write happen in the library (GIL released): off the loop's thread
+
             def on_result(k, res):
                 t1 = time.perf_counter()
-                written.append(job.write_tif(res[1], bounds, k, 0, out_dir))
+                written.append(writer.submit(job.write_tif, res[1], bounds, k, 0, out_dir))
                 tm["write_tif_host_s"] = tm.get("write_tif_host_s", 0.0) + time.perf_counter() - t1
+            ahead, depth = 2 * args.job_readers, 2 * len(sessions)
+            arena = None if args.job_no_arena else job.PinnedArena(torch, ahead + depth + 3)    # raw arrays are inflated straight into page-locked sets
+            if arena is not None:                            # first use allocates the pinned buffers: not a per-tile cost
+                for _ in arena.sets:
+                    aset = arena.acquire()
+                    job.load_raw_tile(0, 0, root, alloc=arena.allocator(aset))
+                for aset in range(len(arena.sets)):
+                    arena.release(aset)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n_loop = 4 * n_tiles                # the loop visits every tile folder four times (page-cache hot, like a job's re-reads)
-            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k % n_tiles, 0) for k in range(n_loop)], root, workers=args.job_readers))
-            res = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tm, on_result=on_result)
+            gen = ((raw_k, None) for raw_k in job.iter_raw_tiles([(k % n_tiles, 0) for k in range(n_loop)], root, workers=args.job_readers, arena=arena))
+            res = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tm, on_result=on_result, arena=arena)
             torch.cuda.synchronize()
+            written = [w.result() for w in written]
+            writer.shutdown()
             wall = time.perf_counter() - t0
         finally:
             shutil.rmtree(root, ignore_errors=True)
@@ -465,7 +479,7 @@ def main():
         return {"value": n_loop * TILE * TILE / wall, "unit": "px/s", "tiles": n_loop, "tile_folders": n_tiles, "ms_per_tile_pipelined": wall / n_loop * 1e3,
                 "ms_per_stage_serial": {k: round(v * 1e3, 2) for k, v in stages.items()},
                 "host_seconds_in_loop": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
-                "raw_bytes_on_disk_per_tile": disk // n_tiles, "read_threads": args.job_readers, "inflate_threads_per_read": int(os.environ.get("TTC_IO_THREADS", "8")), "sessions": len(sessions),
+                "raw_bytes_on_disk_per_tile": disk // n_tiles, "pinned_arena_sets": 0 if arena is None else len(arena.sets), "read_threads": args.job_readers, "inflate_threads_per_read": int(os.environ.get("TTC_IO_THREADS", "8")), "sessions": len(sessions),
                 "tiles_rerun_staged": int(sum(1 for r in res if r[3])),
                 "slowest_host_stage": {"name": slowest, "ms": round(host_ms[slowest], 2), "x_gpu_stage": round(host_ms[slowest] / gpu_ms, 2)},
                 "note": "job-level: files -> ttc_read_hkl -> pinned H2D -> detection + ttc_predict_tile -> D2H -> ttc_write_geotiff_u8; "

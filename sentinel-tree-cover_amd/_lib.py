@@ -143,9 +143,10 @@ def write_geotiff_u8(path, raster, west, south, east, north):
     return str(path)
 
 
-def read_hkl(path, name=None):
+def read_hkl(path, name=None, alloc=None):
     """ttc_read_hkl: the numeric array of a hickle file (hkl.load for the raw folder's arrays, job.py:684-714) -> numpy array.
-    Host-side, no GPU needed."""
+    Host-side, no GPU needed.  alloc(shape, dtype) -> C-contiguous numpy array to fill (e.g. a view of page-locked memory, so that
+    the array can be uploaded without a staging copy: job.PinnedArena); default np.empty."""
     lib = load()
     lib.ttc_read_hkl.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -160,7 +161,10 @@ def read_hkl(path, name=None):
             raise RuntimeError(f"ttc_read_hkl: status {st}: {lib.ttc_read_hkl_error().decode()}")
     call(None, 0)
     kind = "f" if tc.value == 1 else ("i" if sg.value else "u")
-    out = np.empty(tuple(shape[i] for i in range(nd.value)), dtype=np.dtype(f"<{kind}{es.value}"))
+    shp, dt = tuple(shape[i] for i in range(nd.value)), np.dtype(f"<{kind}{es.value}")
+    out = np.empty(shp, dtype=dt) if alloc is None else alloc(shp, dt)
+    if out.shape != shp or out.dtype != dt or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError("read_hkl: alloc() must return a C-contiguous array of the requested shape and dtype")
     call(out.ctypes.data_as(C.c_void_p), out.nbytes)
     return out
 

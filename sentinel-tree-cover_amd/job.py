@@ -322,43 +322,105 @@ def adjust_shape(arr, width, height):
     return arr.squeeze()
 
 
-def load_raw_tile(x, y, local_path):
+def load_raw_tile(x, y, local_path, alloc=None):
     """The file loads at the top of process_tile (job.py:669-714): the arrays of `{local_path}{x}/{y}/raw/` as the `raw` dict
     that process_tile (below) takes.  hkl.load is replaced by the library's own HDF5 reader (ttc_read_hkl, host code);
-    the Sen2Cor mask is returned at its stored 20 m resolution, the clean-up of :687-694 happens on the device."""
+    the Sen2Cor mask is returned at its stored 20 m resolution, the clean-up of :687-694 happens on the device.
+    alloc(name) -> allocator for _lib.read_hkl (PinnedArena.allocator): the arrays the tile call uploads are then read straight
+    into page-locked memory."""
     x, y = str(int(x)), str(int(y))
     folder = f"{local_path}{x}/{y}/"
     idx = f"{x}X{y}Y"
-    rd = _lib.read_hkl
+
+    def rd(path, name=None):
+        return _lib.read_hkl(path, alloc=alloc(name) if (alloc is not None and name is not None) else None)
     clm_file = f"{folder}raw/clouds/cloudmask_{idx}.hkl"
     return {"clouds": rd(f"{folder}raw/clouds/clouds_{idx}.hkl"),
             "clm": rd(clm_file) if os.path.exists(clm_file) else None,
-            "s1": rd(f"{folder}raw/s1/{idx}.hkl"), "s2_10": rd(f"{folder}raw/s2_10/{idx}.hkl"),
-            "s2_20": rd(f"{folder}raw/s2_20/{idx}.hkl"), "dem": rd(f"{folder}raw/misc/dem_{idx}.hkl"),
+            "s1": rd(f"{folder}raw/s1/{idx}.hkl", "s1"), "s2_10": rd(f"{folder}raw/s2_10/{idx}.hkl", "s2_10"),
+            "s2_20": rd(f"{folder}raw/s2_20/{idx}.hkl", "s2_20"), "dem": rd(f"{folder}raw/misc/dem_{idx}.hkl", "dem"),
             "dates": rd(f"{folder}raw/misc/s2_dates_{idx}.hkl")}
 
 
-def iter_raw_tiles(coords, local_path, workers=4, ahead=None):
+class PinnedArena:
+    """Page-locked buffer sets for the raw arrays of tiles that are read ahead (iter_raw_tiles) and uploaded by predict_tiles: the
+    HDF5 reader inflates straight into them, so the tile loop's main thread does not copy 90 MB per tile into a staging buffer
+    (measured: 10 ms of a 34 ms tile period).  Sets are handed out round-robin in tile order; a set is reused only after the tile
+    that used it was FINISHED (predict_tiles keeps the raw arrays until then: a flagged tile re-runs from them)."""
+
+    def __init__(self, torch, nsets):
+        import threading
+        self.t = torch
+        self.sets = [dict() for _ in range(int(nsets))]
+        self.free = [True] * int(nsets)
+        self.cv = threading.Condition()
+        self.nxt = 0
+
+    def acquire(self):
+        """-> index of the next set, waiting until the tile that last used it has been released"""
+        with self.cv:
+            i = self.nxt
+            self.nxt = (i + 1) % len(self.sets)
+            while not self.free[i]:
+                if not self.cv.wait(timeout=120.0):
+                    raise RuntimeError("PinnedArena: no free set after 120 s -- it needs more sets than iter_raw_tiles reads ahead "
+                                       "plus the tiles predict_tiles keeps in flight (ahead + depth + 2)")
+            self.free[i] = False
+            return i
+
+    def release(self, i):
+        with self.cv:
+            self.free[i] = True
+            self.cv.notify_all()
+
+    def allocator(self, i):
+        """-> alloc(name) -> alloc(shape, dtype) for _lib.read_hkl: a numpy view of set i's pinned buffer `name`"""
+        t, bufs = self.t, self.sets[i]
+
+        def for_name(name):
+            def alloc(shape, dtype):
+                dtype = np.dtype(dtype)
+                nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+                b = bufs.get(name)
+                if b is None or b.numel() < nbytes:
+                    b = bufs[name] = t.empty(max(nbytes, 1), dtype=t.uint8, pin_memory=True)
+                return b.numpy()[:nbytes].view(dtype).reshape(shape)
+            return alloc
+        return for_name
+
+
+def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None):
     """Generator over load_raw_tile(x, y, local_path) for (x, y) in coords, read AHEAD by a small thread pool: the HDF5 reader is
     host C++ behind ctypes (the GIL is released for the duration of the call), so `workers` tiles are parsed / inflated in
     parallel while the GPU works on earlier ones -- feed it to predict_tiles.  At most `ahead` (default 2 x workers) tiles are
-    resident.  Order is preserved; a failed read raises when its tile is reached."""
+    resident.  Order is preserved; a failed read raises when its tile is reached.
+    arena (PinnedArena with MORE sets than `ahead` + the tiles predict_tiles keeps in flight): the uploaded arrays are read into
+    its page-locked sets (raw["_arena_set"] names the set; predict_tiles(arena=...) releases it when the tile is finished)."""
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     coords = list(coords)
     ahead = int(ahead) if ahead else 2 * int(workers)
+
+    def load(xy, aset):
+        raw = load_raw_tile(xy[0], xy[1], local_path, alloc=arena.allocator(aset) if arena is not None else None)
+        if arena is not None:
+            raw["_arena_set"] = aset
+        return raw
+
+    def submit(pool, xy):                       # sets are taken in tile order, on the consumer's thread
+        return pool.submit(load, xy, arena.acquire() if arena is not None else None)
     with ThreadPoolExecutor(max_workers=int(workers)) as pool:
         q = deque()
         it = iter(coords)
         for xy in it:
-            q.append(pool.submit(load_raw_tile, xy[0], xy[1], local_path))
+            q.append(submit(pool, xy))
             if len(q) >= ahead:
                 break
         while q:
             raw = q.popleft().result()
             nxt = next(it, None)
             if nxt is not None:
-                q.append(pool.submit(load_raw_tile, nxt[0], nxt[1], local_path))
+                q.append(submit(pool, nxt))
             yield raw
 
 
@@ -509,9 +571,14 @@ class _PinnedStager:
             a = np.ascontiguousarray(a)
             if a.dtype == np.uint16:
                 a = a.view(np.int16)
+            ta = t.from_numpy(a)
+            if ta.is_pinned():                                   # read straight into page-locked memory (PinnedArena): no staging copy
+                with t.cuda.stream(stream):
+                    out[name] = ta.to(self.dev, non_blocking=True)
+                continue
             b = bufs.get(name)
             if b is None or tuple(b.shape) != a.shape or b.numpy().dtype != a.dtype:
-                b = bufs[name] = t.empty(a.shape, dtype=t.from_numpy(np.empty(0, a.dtype)).dtype, pin_memory=True)
+                b = bufs[name] = t.empty(a.shape, dtype=ta.dtype, pin_memory=True)
             b.numpy()[...] = a
             with t.cuda.stream(stream):
                 out[name] = b.to(self.dev, non_blocking=True)
@@ -522,7 +589,7 @@ class _PinnedStager:
 
 
 def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, want_status=False, depth=None, timings=None,
-                  on_result=None):
+                  on_result=None, arena=None):
     """The job's TILE LOOP (job.py:1869-2091 processes one tile after the other) over a sequence of tiles, pipelined on one GPU:
     `sessions` = 1 .. K TTCSession of the same device; tile k is enqueued on session k % K, each session on its own HIP stream,
     with ONE ttc_predict_tile call and no host wait, so K tiles are in flight (bench.py: two saturate an MI355X -- one tile's
@@ -535,7 +602,9 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
     (TTC_TILE_DETECT; what the job does: job.py:839), a flagged tile then re-runs process_tile with its own detection.
     on_result(k, result): called in input order as soon as tile k is finished (e.g. write_tif), while later tiles are in flight.
     timings: dict that receives host seconds spent staging uploads / waiting for results.  Raw arrays are staged through page-locked buffers and uploaded with non-blocking
-    copies on the tile's stream (_PinnedStager), so the host never waits behind a stream's queued kernels while enqueueing.  -> list of (float32 percent raster, uint8 product[, status int32[4], staged]) in
+    copies on the tile's stream (_PinnedStager), so the host never waits behind a stream's queued kernels while enqueueing; arrays that
+    already live in page-locked memory (iter_raw_tiles(arena=PinnedArena)) are uploaded from where they are, and `arena` gets each
+    tile's set back when the tile is finished.  -> list of (float32 percent raster, uint8 product[, status int32[4], staged]) in
     input order, numpy with to_host else cuda tensors."""
     from collections import deque
     sessions = list(sessions)
@@ -569,6 +638,8 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         if timings is not None:
             timings["wait_d2h_host_s"] = timings.get("wait_d2h_host_s", 0.0) + _time.perf_counter() - t0
             timings["staged"] = timings.get("staged", 0) + int(staged)
+        if arena is not None and isinstance(raw, dict) and raw.get("_arena_set") is not None:
+            arena.release(raw["_arena_set"])                     # its H2D copies finished long ago (the tile's results are back)
         results.append((f32, u8, words, staged) if want_status else (f32, u8))
         if on_result is not None:
             on_result(k, results[-1])
