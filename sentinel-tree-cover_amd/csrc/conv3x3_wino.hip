@@ -26,6 +26,13 @@
 // = row of the 2 x 2 output tile.  Epilogue ops (sSE gate, partial-conv ratio + swish), the deterministic GroupNorm partial
 // sums and the flat [cout][y * Wp + x] output layout are those of conv_common.h's conv_epilogue_flat, so every consumer is
 // unchanged.  fp32 throughout; the transforms' constants are 0, +-1, +-1/2: max |delta| vs the direct kernel ~1e-6 relative.
+//
+// What the measurements of round 4 say about this kernel (experiments/README.md): the launches run at 2.1-2.3 GHz and
+// the bare MFMA stream reaches ~90 % of the matrix pipe at that clock, but nothing else hides under the partner workgroup's MFMAs as
+// well as "two workgroups per CU" suggests -- every removed instruction returned its own cost.  Hence: the chunk loop is straight-line
+// (no branch around a load: the compiler must be able to COUNT the requests in flight), tile ids are decomposed by multiply-shift on
+// the scalar unit, outputs leave as 8-byte stores under a wave-uniform branch, the file is built without SLP vectorisation
+// (Makefile), and the ablation / trace switches live in their own instantiations (TRACE != 0).
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
