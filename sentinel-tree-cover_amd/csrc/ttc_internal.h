@@ -197,6 +197,7 @@ struct ttc_ctx {
     struct B16 { uint4* hi = nullptr; uint4* lo = nullptr; };
     B16 frames16, h16[2], rh16, gru16, z_med16, p1_16, p2_16, u2in16, u2a16, u3in16, oa16;
     float *stats = nullptr, *gn = nullptr;      // GN partial sums / (mean, rstd)
+    int cd_wins_T = 0;                          // cloud detection: the date-window table on the device was built for this many dates (0 = none)
     size_t stats_floats = 0;
     int clouds_debug_stage = 0;   // ttc_debug_clouds_stage: return the flags after that stage of the cloud detector (test aid)
     bool keep_debug = false;      // ttc_debug_keep: also materialise intermediates that the fused kernels never write (test aid)

@@ -644,7 +644,17 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         if on_result is not None:
             on_result(k, results[-1])
 
-    for k, (raw, mask) in enumerate(tiles):
+    it = iter(tiles)
+    k = -1
+    while True:
+        t0 = _time.perf_counter()
+        try:
+            raw, mask = next(it)                                     # a lazy generator reads / waits for the tile's files here
+        except StopIteration:
+            break
+        k += 1
+        if timings is not None:
+            timings["next_tile_host_s"] = timings.get("next_tile_host_s", 0.0) + _time.perf_counter() - t0
         sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
         ctx = sess.ctx
         t0 = _time.perf_counter()
@@ -655,11 +665,14 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         d = stager.upload(k % (2 * len(sessions)), arrays, st)
         if timings is not None:
             timings["stage_h2d_host_s"] = timings.get("stage_h2d_host_s", 0.0) + _time.perf_counter() - t0
+        t0 = _time.perf_counter()
         with t.cuda.stream(st):
             dem_m = ctx.median5(d["dem"])                                                                # job.py:713 (metres: the detector's unit)
             dem90 = ctx.divide(dem_m.clone(), 90.0)                                                      # :993
             u8, f32, _, status = ctx.predict_tile_raw(d["s2_10"], d["s2_20"], d["s1"], dem90, d.get("mask"), d["dates"], min_all, max_all,
                                                       size, dem_m=dem_m, flags=0 if mask is not None else ctx.TILE_DETECT, want_float=True)
+        if timings is not None:
+            timings["enqueue_host_s"] = timings.get("enqueue_host_s", 0.0) + _time.perf_counter() - t0
         pending.append((k, raw, mask, u8, f32, status))
         if len(pending) > depth:
             finish()
