@@ -604,6 +604,8 @@ def main():
         if iso_ms:
             out["roofline"]["isolated_launch_ms"] = iso_ms
             out["roofline"]["isolated_frac"] = out["roofline"]["frac"] * gates_ms / iso_ms
+            if out["roofline"].get("mfma_issue_frac") is not None:      # the matrix pipe's own utilisation (against the 2.4 GHz peak) of that launch
+                out["roofline"]["isolated_mfma_issue_frac"] = out["roofline"]["mfma_issue_frac"] * gates_ms / iso_ms
             out["roofline"]["note"] = ("launch_ms / frac are live values with %d tiles in flight (kernels of the other tile share the CUs); "
                                        "isolated_* = the same launch with one tile in flight" % args.inflight)
         out.update(extra)

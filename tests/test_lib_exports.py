@@ -62,3 +62,17 @@ def test_weights_match_oracle_generator_and_validate():
     for k in a:
         np.testing.assert_array_equal(a[k], back[k])
     assert sum(v.size for v in W.load_dsen2().values()) == 41638
+
+
+def test_multiply_shift_division_of_the_winograd_tile_walk():
+    """conv3x3_wino.hip decomposes a tile id with x / d == (x * (2^40 / d + 1)) >> 40 (launch_w refuses ids >= 2^24 and divisors >= 2^12):
+    exact on that whole domain -- checked here on the boundaries of every divisor and a random sample"""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for d in range(1, 4096):
+        m = (1 << 40) // d + 1
+        xs = np.concatenate([np.arange(0, min(4 * d, 1 << 24)), (1 << 24) - 1 - np.arange(0, 2 * d),
+                             (rng.integers(0, 1 << 24, 64) // d) * d, (rng.integers(1, 1 << 24, 64) // d) * d - 1]).astype(np.uint64)
+        xs = xs[xs < (1 << 24)]
+        q = (xs * np.uint64(m)) >> np.uint64(40)
+        assert np.array_equal(q, xs // np.uint64(d)), d
