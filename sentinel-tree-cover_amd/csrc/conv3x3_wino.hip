@@ -254,10 +254,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
     stage_load(cur, 2);
 
     const float4* Vr = reinterpret_cast<const float4*>(Vb) + (hsel * NT + tbw * 32 + tcol);
-    int par = 0;
-    // probe aid: wave 0's thread 0 stamps s_memtime at the phase boundaries of the workgroup's THIRD tile (steady state of the walk):
+    int par = 0;                                 // V buffer of the running chunk: the chunk counter of the whole walk, mod 2
+    // probe aid (TRACE == 2): wave 0's thread 0 stamps s_memtime at the phase boundaries of the workgroup's THIRD tile (steady state of the walk):
     // [8 c + 0] chunk start, [+1] past the chunk-start barrier, [+2] transform done, [+3] first MFMA half issued, [+4] past the mid-chunk
-    // barrier, [+5] staging issued, [+6] second half issued; [56..59] tile start / chunk loop end / output transform done / epilogue end
+    // barrier, [+5] staging issued, [+6] second half issued; [56..59] tile start / chunk loop end / output transform done / epilogue end.
+    // TRACE >= 1: per-phase cycle SUMS of the whole walk in registers (phase(), written once at the end into slots 7 / 15 / 23 / 39 / 47 /
+    // 55 / 32 / 33, tiles in 31) and s_memrealtime / s_memtime at both ends (60 .. 63): tools/probes/wino_trace_stats.py
     unsigned long long* trbase = (TRACE && args()->trace && tid == 0) ? args()->trace + (long)blockIdx.x * 64 : nullptr;
     unsigned long long* tr = nullptr;
     auto stamp = [&](int i) { if constexpr (TRACE == 2) { if (tr) tr[i] = __builtin_amdgcn_s_memtime(); } };
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(WinoArgs wa) {
             if (i >= 0) ph_sum[i] += now - ph_t;
             ph_t = now;
         }
-    };                                  // V buffer of the running chunk: the chunk counter of the whole walk, mod 2
+    };
 
     // one chunk c of the running tile; LAST = its final chunk (possibly fewer than four k-steps).  Stream position c + k of the
     // running tile is chunk c + k - T of the next tile once it passes the end.  The B operand of xi + 1 is fetched before the MFMAs
