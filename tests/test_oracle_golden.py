@@ -1,5 +1,7 @@
 """Pin the CPU oracle (oracle/restate_numpy.py) against golden vectors captured by
 RUNNING the reference (tools/gen_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -148,9 +150,17 @@ def test_resize_matches_real_skimage():
     RS = importlib.import_module("sentinel-tree-cover_amd.resegment")
     g = golden("resize.npz")
     assert str(g["skimage_version"]) == "0.18.3"
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from resize_cases import cases as resize_cases          # the inputs are code (the fixture holds outputs + a checksum per input)
+    cases = resize_cases()
+    assert len(cases) == int(g["n"])
     worst32, worst64 = 0.0, 0.0
-    for k in range(int(g["n"])):
-        a, shape, want = g[f"in_{k}"], tuple(int(v) for v in g[f"shape_{k}"]), g[f"out_{k}"]
+    for k, (a, shape) in enumerate(cases):
+        want = g[f"out_{k}"]
+        assert tuple(int(v) for v in g[f"shape_{k}"]) == tuple(shape)
+        chk = np.array([np.asarray(a, np.float64).sum(), np.abs(np.asarray(a, np.float64)).max()])
+        np.testing.assert_allclose(chk, g[f"insum_{k}"], rtol=1e-12, err_msg=f"input {k} is not the one the fixture was generated from")
         got = O.resize_bilinear(a, shape)
         assert got.shape == want.shape
         e = float(np.abs(got - want).max())
