@@ -381,7 +381,8 @@ hipError_t launch_head(const ConvArgs& a, const PackedConv& pw, int n, hipStream
 int conv_q_blocks(int Hp, int Wp) { return ((Hp - 2) * Wp + kBQ - 1) / kBQ; }
 int conv_stat_slots(int Hp, int Wp) { return conv_q_blocks(Hp, Wp) * kWaves; }
 
-// TTC_WINOGRAD=0 keeps every fp32 layer on the direct kernel (A/B runs, parity tests of the direct form)
+// TTC_WINOGRAD=0 keeps every fp32 layer on the direct kernel (A/B runs, parity tests of the direct form); TTC_WINO4=0 keeps the
+// F(2x2, 3x3) kernels for the layers the F(4x4, 3x3) form would take
 bool conv_use_wino(const PackedConv& pw, int epi) {
     static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
     if (!on || pw.mode != 0 || pw.d_wu == nullptr || pw.nchunk_w < 3) return false;
@@ -391,9 +392,29 @@ bool conv_use_wino(const PackedConv& pw, int epi) {
     // profiles/r04_dsen2_winograd_probe_kernel_stats.md, csrc/experiments/README.md
     return epi <= EPI_SWISH && pw.Cout % 32 == 0;
 }
-// (the Winograd kernels stage 8-byte pairs: planes with an odd pitch stay on the direct kernel)
-int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp) {
-    return (conv_use_wino(pw, epi) && !(Wp & 1)) ? conv_wino_stat_slots(Hp, Wp, pw.Cout) : conv_stat_slots(Hp, Wp);
+// the launch limits of the F(2x2) kernels (conv3x3_wino.hip launch_w), as a predicate: a configuration outside them falls back to the
+// direct kernel instead of failing the forward with hipErrorInvalidValue
+static bool conv_wino2_ok(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set) {
+    if (!conv_use_wino(pw, epi) || (Wp & 1)) return false;
+    if ((long)Hp * Wp >= (1L << 24) || (long)Cin * Hp * Wp >= (1L << 31) || n_per_set < 1 || n_per_set >= 4096) return false;
+    const int ncb = pw.Cout >= 64 ? 2 : 1, tb = 2 / ncb;
+    const long TX = (Wp - 2 + 1) / 2, TY = (Hp - 2 + 1) / 2;
+    const long RXn = (TX + 7) / 8, RYn = (TY + 4 * tb - 1) / (4 * tb), ncp = (pw.Cout + 32 * ncb - 1) / (32 * ncb);
+    return RXn < 4096 && RYn < 4096 && ncp < 4096 && RXn * RYn * ncp * n < (1L << 24);
+}
+ConvKernel conv_kernel_for(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set) {
+    static const int on4 = [] { const char* e = getenv("TTC_WINO4"); return e ? atoi(e) : 0; }();   // opt-in until it beats F(2x2)
+    static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
+    if (on && on4 && pw.mode == 0 && conv_wino4_ok(pw, epi, Hp, Wp, Cin, n, n_per_set)) return CONV_WINO4;
+    if (conv_wino2_ok(pw, epi, Hp, Wp, Cin, n, n_per_set)) return CONV_WINO2;
+    return CONV_DIRECT;
+}
+int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set) {
+    switch (conv_kernel_for(pw, epi, Hp, Wp, Cin, n, n_per_set)) {
+        case CONV_WINO4: return conv_wino4_stat_slots(Hp, Wp);
+        case CONV_WINO2: return conv_wino_stat_slots(Hp, Wp, pw.Cout);
+        default: return conv_stat_slots(Hp, Wp);
+    }
 }
 
 int conv_pick_ck(int Cin) {
@@ -439,6 +460,11 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
         pc.set_stride_w = conv_pack_wino(hwio, nsets, Cin, Cout, pu, &pc.nchunk_w);
         if (!pc.d_wu && !(pc.d_wu = c->alloc_f(pu.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc Winograd weights");
         TTC_HIP(c, hipMemcpy(pc.d_wu, pu.data(), pu.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (Cout % 64 == 0) {           // ... and the F(4x4, 3x3) images for the 64-cout-multiple layers (conv3x3_wino4.hip)
+            pc.set_stride_w4 = conv_pack_wino4(hwio, nsets, Cin, Cout, pu, &pc.nchunk_w4);
+            if (!pc.d_wu4 && !(pc.d_wu4 = c->alloc_f(pu.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc Winograd F(4x4) weights");
+            TTC_HIP(c, hipMemcpy(pc.d_wu4, pu.data(), pu.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     if (pc.mode >= 2) {                 // 16-bit engine: fp16 (2) / bf16 (3) hi | lo LDS images
         std::vector<uint16_t> ph;
@@ -452,7 +478,11 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
 }
 
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
-    if (conv_use_wino(pw, epi) && !(a.Wp & 1)) return conv_launch_wino(a, pw, epi, n, s);
+    switch (conv_kernel_for(pw, epi, a.Hp, a.Wp, a.Cin, n, a.n_per_set)) {
+        case CONV_WINO4: return conv_launch_wino4(a, pw, epi, n, s);
+        case CONV_WINO2: return conv_launch_wino(a, pw, epi, n, s);
+        default: break;
+    }
     // only the (CK, BN, epilogue) combinations the two graphs need are instantiated
 #define TTC_CONV_CASE(ck, ncg, e) \
     if (pw.CK == ck && pw.BN == ncg * 32 && epi == e) return launch_t<ck, ncg, e>(a, pw, n, s);

@@ -672,7 +672,7 @@ ttc_status model_alloc(ttc_ctx* c) {
     }
     // GroupNorm partial sums: [n][Cout / 4][slots][2]; the Winograd kernels of the fp32 engine keep one slot per 16 x 8 region
     // and contributing wave (more than the direct kernel's one per 512 positions and wave): size for the larger
-    c->stats_floats = N2 * 16 * (size_t)std::max(conv_stat_slots(g.y.np, g.x.np), conv_wino_stat_slots(g.y.np, g.x.np, 64)) * 2 + 1024;
+    c->stats_floats = N2 * 16 * (size_t)std::max({conv_stat_slots(g.y.np, g.x.np), conv_wino_stat_slots(g.y.np, g.x.np, 64), conv_wino4_stat_slots(g.y.np, g.x.np)}) * 2 + 1024;
     A(stats, c->stats_floats, "stats");
     A(gn, 10 * N2 * 32, "gn");
 #undef B
@@ -973,7 +973,8 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
     // Step 0 of both directions starts from h = 0: with the Winograd kernels (which can skip channels) the gates and candidate
     // convolutions run over the 17 frame channels only (3 of 7 chunks), r * h is never formed and the state buffer is neither
     // cleared nor read -- the same sums, minus terms that are exactly zero.
-    const bool skip_h0 = conv_use_wino(c->w_gates, EPI_RAW) && conv_use_wino(c->w_cand, EPI_SSE) && !(Wp & 1);
+    const bool skip_h0 = conv_kernel_for(c->w_gates, EPI_RAW, Hp, Wp, Cx + Hd, N2, N) != CONV_DIRECT &&
+                         conv_kernel_for(c->w_cand, EPI_SSE, Hp, Wp, Cx + Hd, N2, N) != CONV_DIRECT;
     if (!skip_h0) TTC_HIP(c, hipMemsetAsync(c->h[0], 0, (size_t)N2 * Hd * PP * sizeof(float), s));
     else {
         // the third chunk holds frame channel 16 and state channels 0 .. 6: those seven planes of h (gates) and r * h (candidate) are
@@ -997,7 +998,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         const bool h0 = skip_h0 && st == 0;
         a.cin_run = h0 ? Cx : 0;
         { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
-        TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, conv_stat_slots_for(c->w_gates, EPI_RAW, Hp, Wp), 4.0 * P, s));
+        TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, conv_stat_slots_for(c->w_gates, EPI_RAW, Hp, Wp, a.Cin, N2, N), 4.0 * P, s));
         if (!h0) {
             KTimer kt(c, "gru_apply1", s);
             hipLaunchKernelGGL(k_gru_apply1, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yg, gn_slot[8], gp,
@@ -1009,7 +1010,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.out = c->yc; a.out_stride_n = (long)Hd * Pr;
         a.aux = gp.base + 4 * 32; a.aux_set_stride = gp.dir_stride;
         { KTimer kt(c, "conv_cand", s); TTC_HIP(c, conv_launch(a, c->w_cand, EPI_SSE, N2, s)); }
-        TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, conv_stat_slots_for(c->w_cand, EPI_SSE, Hp, Wp), 4.0 * P, s));
+        TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, conv_stat_slots_for(c->w_cand, EPI_SSE, Hp, Wp, a.Cin, N2, N), 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply2", s);
             hipLaunchKernelGGL(k_gru_apply2, dim3((PP + 255) / 256, N2), dim3(256), 0, s, c->yc, gn_slot[9], gp,
@@ -1031,7 +1032,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.out = out; a.out_stride_n = (long)a.Cout * Pro; a.out_plane = Pro; a.out_pitch = in.w; a.oy = a.ox = 0;
         a.stats = c->stats; a.same_pad = same;
         { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
-        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots_for(c->w_block[b], EPI_SWISH, in.h, in.w), (double)(a.Cout / 8) * Po, s);
+        return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots_for(c->w_block[b], EPI_SWISH, in.h, in.w, a.Cin, N, N), (double)(a.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
     // src: raw conv output dims; dst: destination dims INCLUDING pad

@@ -90,6 +90,10 @@ struct PackedConv {      // device copy of one layer's packed weights
     float* d_wu = nullptr;
     int nchunk_w = 0;             // 8-channel chunks
     long set_stride_w = 0;        // floats between weight sets
+    // ... and the Winograd F(4x4, 3x3) form of the layers with Cout % 64 == 0 (conv3x3_wino4.hip)
+    float* d_wu4 = nullptr;
+    int nchunk_w4 = 0;
+    long set_stride_w4 = 0;
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember the size configured on each device
@@ -149,8 +153,15 @@ hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, 
 long conv_pack_wino(const float* const* hwio, int nsets, int Cin, int Cout, std::vector<float>& out, int* nchunk);
 hipError_t conv_launch_wino(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
 int conv_wino_stat_slots(int Hp, int Wp, int Cout);
-bool conv_use_wino(const PackedConv& pw, int epi);      // the fp32 engine takes the Winograd form for this layer
-int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp);   // GroupNorm partial-sum slots of the kernel conv_launch will pick
+// Winograd F(4x4, 3x3) kernels (conv3x3_wino4.hip): EPI_RAW / EPI_SWISH layers with Cout % 64 == 0
+long conv_pack_wino4(const float* const* hwio, int nsets, int Cin, int Cout, std::vector<float>& out, int* nchunk);
+hipError_t conv_launch_wino4(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+int conv_wino4_stat_slots(int Hp, int Wp);
+bool conv_wino4_ok(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set);   // launch limits of the F(4x4) kernels
+// which fp32 kernel conv_launch runs for a layer: ONE decision shared by the launch, the GroupNorm slot count and the ConvGRU step-0 shortcut
+enum ConvKernel : int { CONV_DIRECT = 0, CONV_WINO2 = 1, CONV_WINO4 = 2 };
+ConvKernel conv_kernel_for(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set);
+int conv_stat_slots_for(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set);   // GroupNorm partial-sum slots of that kernel
 // C0: real channels of the first input segment (its blocks are padded to a multiple of 8 on their own); bf: bf16 elements
 long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cout, int BN, bool bf, std::vector<uint16_t>& out,
                    int* nchunk);
