@@ -4,7 +4,7 @@ import re, sys, collections
 src = open(sys.argv[1]).read().split("\n")
 key = sys.argv[2]
 start = next(i for i, l in enumerate(src) if l.startswith("_ZN") and key in l and l.rstrip().split(";")[0].strip().endswith(":"))
-end = next(i for i in range(start, len(src)) if "s_endpgm" in src[i])
+end = next(i for i in range(start, len(src)) if src[i].startswith(".Lfunc_end"))
 def cls(op):
     if op.startswith("v_mfma"): return "mfma"
     if op.startswith("scratch_"): return "scratch"
