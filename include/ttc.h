@@ -66,6 +66,14 @@ typedef struct {
                             * 618^2 tile with as-stored-scale kernels (tools/probes/tile_dprob_probe.py): ANY bit set moves
                             * max |dprob| to 3.0e-3 (bit 0) .. 2.7e-2, OUTSIDE the 1e-3 contract; all-zero: fp16 5e-5,
                             * bf16 3.7e-4.  Set bits only for workloads with a looser accuracy budget.                 */
+    int32_t fp32_conv_form; /* precision 0 only: which form of the 3x3 convolution the GroupNorm layers run (the sums are the same
+                            * fp32 sums; the forms differ in rounding, because Winograd's transforms cancel large intermediates):
+                            * 0 = fastest: Winograd F(4x4,3x3) for the layers with a multiple of 64 output channels (ConvGRU gates
+                            *     and the eight conv_swish_gn blocks), F(2x2,3x3) for the rest (ConvGRU candidate).  Raw conv
+                            *     outputs up to 2e-4 from the fp64 oracle (values of magnitude 6), probabilities <= 5e-5;
+                            * 1 = F(2x2,3x3) only (rounds 4's engine): raw outputs <= 5e-5, probabilities <= 3e-5;
+                            * 2 = direct implicit GEMM only (9 multiply-accumulates per tap: the slowest, <= 2e-5).
+                            * The contract of the path is 1e-3 on probabilities (BASELINE.json).                          */
 } ttc_config;
 
 /* A named host tensor in TensorFlow layout (conv kernels HWIO). */

@@ -81,6 +81,8 @@ ttc_status ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg) {
         return c->fail(TTC_ERR_ARG, "precision: 0 (exact fp32 MFMA), 2 (fp16) / 3 (bf16) hi + lo pairs on the 16-bit engine; 1 and 4 named the retired "
                                     "bf16x3 / fp32-blocked engines (csrc/experiments/)");
     if (cfg->max_windows < 1 || cfg->length < 1) return c->fail(TTC_ERR_ARG, "max_windows and length must be >= 1");
+    if (cfg->fp32_conv_form < 0 || cfg->fp32_conv_form > 2)
+        return c->fail(TTC_ERR_ARG, "fp32_conv_form: 0 (Winograd F(4x4,3x3) where it applies), 1 (F(2x2,3x3) at most), 2 (direct only)");
     return model_alloc(c);
 }
 

@@ -385,7 +385,7 @@ int conv_stat_slots(int Hp, int Wp) { return conv_q_blocks(Hp, Wp) * kWaves; }
 // F(2x2, 3x3) kernels for the layers the F(4x4, 3x3) form would take
 bool conv_use_wino(const PackedConv& pw, int epi) {
     static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
-    if (!on || pw.mode != 0 || pw.d_wu == nullptr || pw.nchunk_w < 3) return false;
+    if (!on || pw.mode != 0 || pw.form >= 2 || pw.d_wu == nullptr || pw.nchunk_w < 3) return false;
     // GroupNorm layers of the ConvGRU / U-Net only.  DSen2's 32 -> 32 layers were tried on the same kernel (bias / ReLU / residual
     // epilogues with the reflect rim) and measured SLOWER than the direct form (2.6 / 3.1 vs 1.9 / 2.2 ms per tile: 118-px windows
     // are 7.4 regions wide (15 % padding), a tile is only four chunks long, and the padded-plane output forces scalar stores):
@@ -403,9 +403,9 @@ static bool conv_wino2_ok(const PackedConv& pw, int epi, int Hp, int Wp, int Cin
     return RXn < 4096 && RYn < 4096 && ncp < 4096 && RXn * RYn * ncp * n < (1L << 24);
 }
 ConvKernel conv_kernel_for(const PackedConv& pw, int epi, int Hp, int Wp, int Cin, int n, int n_per_set) {
-    static const int on4 = [] { const char* e = getenv("TTC_WINO4"); return e ? atoi(e) : 0; }();   // opt-in until it beats F(2x2)
+    static const int on4 = [] { const char* e = getenv("TTC_WINO4"); return e ? atoi(e) : 1; }();
     static const int on = [] { const char* e = getenv("TTC_WINOGRAD"); return e ? atoi(e) : 1; }();
-    if (on && on4 && pw.mode == 0 && conv_wino4_ok(pw, epi, Hp, Wp, Cin, n, n_per_set)) return CONV_WINO4;
+    if (on && on4 && pw.mode == 0 && pw.form == 0 && conv_wino4_ok(pw, epi, Hp, Wp, Cin, n, n_per_set)) return CONV_WINO4;
     if (conv_wino2_ok(pw, epi, Hp, Wp, Cin, n, n_per_set)) return CONV_WINO2;
     return CONV_DIRECT;
 }
@@ -451,6 +451,7 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
     pc.CK = conv_pick_ck(Cin); pc.BN = BN;
     pc.nchunk = (Cin + pc.CK - 1) / pc.CK; pc.ncb = (Cout + pc.BN - 1) / pc.BN;
     pc.mode = c->cfg.precision;
+    pc.form = c->cfg.fp32_conv_form;
     std::vector<float> packed;
     pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);
     if (!pc.d_w && !(pc.d_w = c->alloc_f(packed.size()))) return c->fail(TTC_ERR_NOMEM, "hipMalloc weights");

@@ -184,8 +184,11 @@ __global__ __launch_bounds__(kThreads4, 2) void conv3x3_wino4(Wino4Args wa) {
         // the six pieces (sub-region sb, j) = 3 sb + j of a channel pair are dealt to the SIMD's two waves so that both reach the chunk barrier
         // together: the transform wave takes (0, 0) and the short (0, 2), the other wave the remaining four (measured: 6 / 6 left the
         // transform waves 1.5 k cycles per chunk behind, 0 / 12 the others 3.4 k)
-        constexpr int NPC = ROLE == 0 ? 2 : 4;
-        constexpr int PCS[4] = {ROLE == 0 ? 0 : 1, ROLE == 0 ? 2 : 3, 4, 5};
+#ifndef TTC_W4_SPLIT
+#define TTC_W4_SPLIT 2
+#endif
+        constexpr int NPC = ROLE == 0 ? TTC_W4_SPLIT : 6 - TTC_W4_SPLIT;
+        constexpr int PCS[5] = {ROLE == 0 ? 0 : (TTC_W4_SPLIT == 1 ? 1 : 1), ROLE == 0 ? 2 : (TTC_W4_SPLIT == 1 ? 2 : 3), TTC_W4_SPLIT == 1 ? 3 : 4, TTC_W4_SPLIT == 1 ? 4 : 5, 5};
         int spo_cur[NPC], spo_nxt[NPC];
         float2 g[2 * NPC];                       // [h 2][piece]
         // positions past the plane's end (the 18 x 18 image of an edge sub-region) only feed outputs that are never stored: any finite
@@ -222,18 +225,21 @@ __global__ __launch_bounds__(kThreads4, 2) void conv3x3_wino4(Wino4Args wa) {
         const float* tsrc = in_tile + ttb * kSUB + tkq * kKQ + ((4 * (tt16 >> 2) + thalf) * kIP + 4 * (tt16 & 3)) * 2;
         float* tdst = Vb + (18 * thalf) * 256 + tkq * 64 + tt16 * 4 + ttb * 2;
         v2f tt[3][6];                            // B^T d rows of this half
-        // column pair p of the half patch -> tt[.][2 p], tt[.][2 p + 1]
-        auto tr_cols = [&](const float* tin, int p2) {
-            v2f d[5][2];
+        // column pair p of the half patch -> tt[.][2 p], tt[.][2 p + 1].  The five 16-byte reads are issued two groups before the arithmetic
+        // that consumes them (tr_load / tr_cols): issued together, every column pair exposed one LDS round trip to the wave
+        v2f td[5][2];
+        auto tr_load = [&](const float* tin, int p2) {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const float4 v = *reinterpret_cast<const float4*>(tin + (r * kIP + 2 * p2) * 2);
-                d[r][0] = v2f{v.x, v.y}; d[r][1] = v2f{v.z, v.w};
+                td[r][0] = v2f{v.x, v.y}; td[r][1] = v2f{v.z, v.w};
             }
+        };
+        auto tr_cols = [&](int p2) {
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
                 const int c = 2 * p2 + cc;
-                const v2f e0 = d[0][cc], e1 = d[1][cc], e2 = d[2][cc], e3 = d[3][cc], e4 = d[4][cc];
+                const v2f e0 = td[0][cc], e1 = td[1][cc], e2 = td[2][cc], e3 = td[3][cc], e4 = td[4][cc];
                 if (thalf == 0) {                // rows 0, 1, 2 of B^T from input rows 0 .. 4
                     tt[0][c] = pk_fma(4.f, e0, pk_fma(-5.f, e2, e4));
                     tt[1][c] = pk_fma(-4.f, e1 + e2, e3 + e4);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(kThreads4, 2) void conv3x3_wino4(Wino4Args wa) {
         __syncthreads();
         if constexpr (ROLE == 0) {
 #pragma unroll
-            for (int p2 = 0; p2 < 3; ++p2) tr_cols(tsrc, p2);
+            for (int p2 = 0; p2 < 3; ++p2) { tr_load(tsrc, p2); tr_cols(p2); }
 #pragma unroll
             for (int al = 0; al < 3; ++al) tr_row(tdst, al);
         }
@@ -332,14 +338,16 @@ __global__ __launch_bounds__(kThreads4, 2) void conv3x3_wino4(Wino4Args wa) {
                 // ---- this group's piece of the role's other work
                 if constexpr (ROLE == 0) {
                     if (do_tr) {
-                        if (k == 0 || k == 2 || k == 4) tr_cols(tin, k / 2);
-                        if (k == 7 || k == 10 || k == 13) tr_row(tout, (k - 7) / 3);
+                        if (k == 0) tr_load(tin, 0);
+                        if (k == 2 || k == 4 || k == 6) { tr_cols(k / 2 - 1); if (k < 6) tr_load(tin, k / 2); }
+                        if (k == 8 || k == 11 || k == 14) tr_row(tout, (k - 8) / 3);
                     }
                 }
                 // staging piece j: its two registers are stored (stream position c + 2, requested a chunk ago) and re-requested at once for
                 // position c + 3 (past the tile's end that is chunk c + 3 - T of the next tile)
-                if ((ROLE == 0 && (k == 6 || k == 11)) || (ROLE == 1 && (k == 2 || k == 5 || k == 8 || k == 11))) {
-                    const int i = ROLE == 0 ? (k - 6) / 5 : (k - 2) / 3;
+                constexpr int K0 = ROLE == 0 ? 9 : 2, KS = ROLE == 0 ? 4 : (NPC == 5 ? 2 : 3);   // groups that carry a staging piece: K0, K0 + KS, ...
+                if (k >= K0 && (k - K0) % KS == 0 && (k - K0) / KS < NPC) {
+                    const int i = (k - K0) / KS;
                     const int sb = PCS[i] / 3;
                     stage_store_piece(par, i);
 #ifndef TTC_W4_NOSTAGE

@@ -81,6 +81,7 @@ struct PackedConv {      // device copy of one layer's packed weights
     int nchunk = 0, ncb = 0;
     long set_stride = 0;
     int mode = 0;                 // ttc_config.precision: 0 = exact fp32 MFMA, 2 = fp16 / 3 = bf16 pairs on the 16-bit engine
+    int form = 0;                 // ttc_config.fp32_conv_form: 0 = F(4x4) where it applies, 1 = F(2x2) at most, 2 = direct only
     // 16-bit engine (precision 2 = fp16, 3 = bf16): LDS-image weights hi | lo per chunk, see conv3x3_h16.hip
     uint4* d_wh = nullptr;
     int nchunk_h = 0;             // 8-channel blocks (padded per input segment)

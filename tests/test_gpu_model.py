@@ -5,8 +5,17 @@ Tolerance (fp32 path): 5e-5 abs on probabilities.  The MFMA conv accumulates eac
 ONE k-ordered fp32 fmaf chain of up to K = 9*256 = 2304 terms, while the oracle's oneDNN conv
 uses blocked accumulation; both are valid fp32 evaluations and sit ~1e-5 apart on the deepest
 layers (measured: raw conv outputs 1e-6 .. 2e-5, probabilities <= 2e-5 at W = 172).  The
-contract of BASELINE.json is 1e-3."""
+contract of BASELINE.json is 1e-3.
+
+Round 5: the default fp32 engine (ttc_config.fp32_conv_form = 0) runs the 64-cout-multiple GroupNorm layers in the Winograd
+F(4x4, 3x3) form.  Its transforms cancel larger intermediates than F(2x2)'s (A^T holds 8, B^T 5, G 1/24): the RAW outputs of
+those layers carry ~4x the rounding error of the F(2x2) form, concentrated at output (3, 3) of a tile and at the corners of
+zero-padded planes (partial-conv ratio 2.25): measured <= 2.0e-4 on values of magnitude 6 (3e-5 relative).  The raw-output
+tolerance of THOSE layers is therefore 2.5e-4 with form 0 and the unchanged 5e-5 with form 1 (F(2x2) only, round 4's engine),
+both tested; the ConvGRU buffers (2e-5) and the probabilities (5e-5) keep their tolerances for both forms."""
 PROB_TOL = 5e-5
+RAW_TOL = {0: 2.5e-4, 1: 5e-5}          # raw conv outputs of the conv_swish_gn blocks per fp32_conv_form
+LATE_TOL = {0: 1e-3, 1: None}           # 'late' feature tap (values up to ~13): None = the unchanged size-dependent tolerance
 import numpy as np
 import pytest
 
@@ -15,7 +24,7 @@ from tests.helpers import synth
 pytestmark = pytest.mark.gpu
 
 
-def _setup(W, L, N, seed=0, precision=0):
+def _setup(W, L, N, seed=0, precision=0, form=0):
     import torch
     from oracle import restate_model as M
     from ttc import _lib, weights as Wt
@@ -23,7 +32,7 @@ def _setup(W, L, N, seed=0, precision=0):
     x = synth.synth_windows(seed=seed + 1, N=N, L=L, W=W)
     trace = {}
     ref = M.TreeCoverNet(w, dtype=torch.float32, trace=trace)(x)
-    ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=precision)
+    ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision=precision, fp32_conv_form=form)
     ctx.load_weights(w)
     return ctx, w, x, ref, trace
 
@@ -35,10 +44,11 @@ def _cmp(name, got, ref, atol):
     return err.max() <= atol, f"{name}: max|d| {err.max():.3e} > {atol} at {i} (got {got[i]}, ref {ref[i]})"
 
 
-def test_single_step_intermediates():
+@pytest.mark.parametrize("form", [0, 1])
+def test_single_step_intermediates(form):
     """L=1: every buffer of the first ConvGRU step and of the U-Net is comparable."""
     W, L, N = 44, 1, 3
-    ctx, w, x, ref, tr = _setup(W, L, N)
+    ctx, w, x, ref, tr = _setup(W, L, N, form=form)
     ctx.keep_intermediates(True)              # the update gate u is otherwise never written to HBM
     out = ctx.forward_windows(x).cpu().numpy()
     P = W * W
@@ -58,14 +68,14 @@ def test_single_step_intermediates():
     for buf, name, C, H in [("y_med", "conv_median", 64, W), ("y_cat", "conv_concat", 64, W), ("y_c1", "conv1", 128, c1),
                             ("y_c2", "conv2", 256, c2), ("y_u2", "up2", 128, u2), ("y_u2o", "up2_out", 128, u2),
                             ("y_u3", "up3", 64, u3), ("y_out", "out", 64, o)]:
-        ok, m = _cmp(buf, ctx.debug_fetch(buf, (N, C, H, H + 2))[..., :H], tr["raw_" + name], 5e-5); ok or fails.append(m)
+        ok, m = _cmp(buf, ctx.debug_fetch(buf, (N, C, H, H + 2))[..., :H], tr["raw_" + name], RAW_TOL[form]); ok or fails.append(m)
     ok, m = _cmp("prob", out, ref[..., 0], PROB_TOL); ok or fails.append(m)
     assert not fails, "\n".join(fails)
 
 
-@pytest.mark.parametrize("W,L,N", [(44, 4, 2), (60, 12, 1), (172, 4, 2), (168, 12, 1)])
-def test_forward_matches_oracle(W, L, N):
-    ctx, w, x, ref, tr = _setup(W, L, N, seed=W + L)
+@pytest.mark.parametrize("W,L,N,form", [(44, 4, 2, 0), (60, 12, 1, 0), (172, 4, 2, 0), (168, 12, 1, 0), (172, 4, 2, 1), (44, 4, 2, 2)])
+def test_forward_matches_oracle(W, L, N, form):
+    ctx, w, x, ref, tr = _setup(W, L, N, seed=W + L, form=form)
     out = ctx.forward_windows(x).cpu().numpy()
     assert out.shape == (N, W - 14, W - 14)
     ok, m = _cmp(f"prob W{W} L{L}", out, ref[..., 0], PROB_TOL)
@@ -74,7 +84,8 @@ def test_forward_matches_oracle(W, L, N):
     np.testing.assert_array_equal(out, out2)        # deterministic (no atomics in reductions)
 
 
-def test_feature_taps_match_oracle():
+@pytest.mark.parametrize("form", [0, 1])
+def test_feature_taps_match_oracle(form):
     """--gen_feats (job.py:1429-1445): early / late feature tensors, their Session.run names, the int16 packing"""
     import torch
     from oracle import restate_model as M, restate_numpy as R
@@ -84,11 +95,11 @@ def test_feature_taps_match_oracle():
     w = Wt.synth_weights(3)
     x = synth.synth_windows(seed=4, N=N, L=L, W=W)
     probs, early, late = M.TreeCoverNet(w, dtype=torch.float32).features(x)
-    sess = job.TTCSession(w, win_in=W, length=L, max_windows=N, dsen2_weights=None)
+    sess = job.TTCSession(w, win_in=W, length=L, max_windows=N, dsen2_weights=None, fp32_conv_form=form)
     gp, ge, gl = sess.ctx.forward_taps(x)
     fails = []
     for name, got, ref, tol in [("probs", gp.cpu().numpy(), probs[..., 0], PROB_TOL), ("early", ge.cpu().numpy(), early, 2e-5),
-                                ("late", gl.cpu().numpy(), late, 2e-4)]:      # values up to ~10; the conv epilogue evaluates swish with v_exp / v_rcp
+                                ("late", gl.cpu().numpy(), late, LATE_TOL[form] or 2e-4)]:      # values up to ~10; the conv epilogue evaluates swish with v_exp / v_rcp
         ok, m = _cmp(name, got, ref, tol); ok or fails.append(m)
     assert not fails, "\n".join(fails)
     via = sess.run([job.PREDICT_EARLYFEATS, job.PREDICT_LATEFEATS], feed_dict={job.PREDICT_INP: x})
@@ -107,8 +118,8 @@ def test_feature_taps_match_oracle():
     np.testing.assert_array_equal(p1, gp.cpu().numpy()[0])
 
 
-@pytest.mark.parametrize("H,W,L,N", [(44, 76, 2, 2), (60, 44, 1, 1), (220, 684, 4, 1)])
-def test_rectangular_windows_match_oracle(H, W, L, N):
+@pytest.mark.parametrize("H,W,L,N,form", [(44, 76, 2, 2, 0), (60, 44, 1, 1, 0), (220, 684, 4, 1, 0), (220, 684, 4, 1, 1)])
+def test_rectangular_windows_match_oracle(H, W, L, N, form):
     """the border graph of src/resegment_tiles_wide.py:478 is fed [L+1, SIZE_Y+14, SIZE+14, 17] = 220 x 684 windows"""
     import torch
     from oracle import restate_model as M
@@ -119,13 +130,13 @@ def test_rectangular_windows_match_oracle(H, W, L, N):
     # at 220 x 684 the float32 oracle is itself 7e-4 off the float64 one on `late` (GroupNorm sums over 150 k pixels):
     # the large case is checked against the float64 oracle
     probs, early, late = M.TreeCoverNet(w, dtype=torch.float64 if H * W > 100000 else torch.float32).features(x)
-    ctx = _lib.Context(win_in=W, win_rows=H, length=L, max_windows=N)
+    ctx = _lib.Context(win_in=W, win_rows=H, length=L, max_windows=N, fp32_conv_form=form)
     ctx.load_weights(w)
     gp, ge, gl = ctx.forward_taps(x)
     assert tuple(gp.shape) == (N, H - 14, W - 14) and tuple(ge.shape) == (N, H, W, 64) and tuple(gl.shape) == (N, H - 14, W - 14, 64)
     fails = []
     for name, got, ref, tol in [("probs", gp.cpu().numpy(), probs[..., 0], PROB_TOL), ("early", ge.cpu().numpy(), early, 2e-5),
-                                ("late", gl.cpu().numpy(), late, 3e-4 if H * W < 100000 else 5e-4)]:    # values up to ~10 there
+                                ("late", gl.cpu().numpy(), late, LATE_TOL[form] or (3e-4 if H * W < 100000 else 5e-4))]:    # values up to ~10 there
         ok, m = _cmp(name, got, ref, tol); ok or fails.append(m)
     assert not fails, "\n".join(fails)
     np.testing.assert_array_equal(ctx.forward_windows(x).cpu().numpy(), gp.cpu().numpy())
