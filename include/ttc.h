@@ -388,8 +388,6 @@ ttc_status ttc_write_geotiff_u8(const char* path, const uint8_t* h_raster, int32
  * Returns TTC_ERR_ARG for unknown names; *n_floats is the element count.  Test aid only. */
 /* on != 0: subsequent forwards also write intermediates that the fused kernels otherwise keep in registers ("u"). */
 ttc_status ttc_debug_keep(ttc_ctx* ctx, int32_t on);
-/* stage != 0: ttc_identify_clouds_shadows returns the flag planes after that stage of the detector (bisecting aid). */
-ttc_status ttc_debug_clouds_stage(ttc_ctx* ctx, int32_t stage);
 ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t cap_floats,
                            size_t* n_floats);
 /* average device time (ms) of the named kernel family over the launches since the last
@@ -397,12 +395,6 @@ ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t 
  * ttc_debug_timing(ctx, level): 0 = off, 1 = every kernel family, 2 = conv-engine launches only
  * (cheap enough to leave on inside a timed benchmark region). */
 ttc_status ttc_debug_timing(ttc_ctx* ctx, int32_t enable);
-/* PROBE ONLY -- not part of the drop-in surface.  Process-wide knobs of the 16-bit conv engine (tools/probes/h16_knobs.py, h16_trace.py):
- * which 0 = persistent grid size (-1 default = 2 per CU, 0 = one workgroup per tile), 1 = start offset of the odd wave slot in
- * s_sleep(127) units (-1 default), 2 | 3 = halves of a device pointer to a trace buffer, 4 = epilogue kind to trace.  They are plain
- * process globals read at launch time by every context and stream, so the call is REFUSED (TTC_ERR_STATE) unless the process was
- * started with TTC_ENABLE_PROBE_KNOBS=1 in its environment. */
-ttc_status ttc_debug_knob(int32_t which, int32_t value);
 ttc_status ttc_debug_kernel_ms(ttc_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
 
 #ifdef __cplusplus

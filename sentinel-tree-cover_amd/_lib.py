@@ -21,11 +21,14 @@ EXPORTS = [
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
     "ttc_debug_kernel_ms", "ttc_feather", "ttc_aligned_mosaic", "ttc_remove_cloud_and_shadows",
-    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows", "ttc_debug_clouds_stage",
+    "ttc_u16_to_float", "ttc_float_to_u16", "ttc_s1_to_db", "ttc_forward_taps", "ttc_float_to_int16", "ttc_mosaic_features", "ttc_debug_keep", "ttc_identify_clouds_shadows",
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
-    "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error", "ttc_debug_knob",
+    "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error",
 ]
+
+# exported for tools/probes and the detector-stage tests, declared in csrc/ttc_internal.h -- not part of the drop-in surface (include/ttc.h)
+INTERNAL_EXPORTS = ["ttc_debug_clouds_stage", "ttc_debug_knob"]
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
 
@@ -42,10 +45,6 @@ class TTCConfig(C.Structure):
 # operands keeps max |dprob| at 2e-4 (L = 4) .. 6.5e-4 (L = 12) on white-noise windows, but reaches 3.0e-3 on a real
 # (spatially smooth) 618^2 tile, outside the 1e-3 contract -- so no layer runs one product unless the caller asks for it.
 PRECISIONS = {"fp32": 0, "fp16": 2, "bf16": 3}     # 1 / 4 were the retired bf16x3 / fp32-blocked engines (csrc/experiments/)
-
-
-def default_one_term(precision, length):
-    return 0
 
 
 class TTCResegWindow(C.Structure):
@@ -201,7 +200,7 @@ class Context:
         self.torch = _torch()
         precision = PRECISIONS.get(precision, precision)
         if one_term_layers is None:
-            one_term_layers = default_one_term(precision, length)
+            one_term_layers = 0                  # every layer multiplies three split products (ttc.h)
         self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision, win_rows, one_term_layers, int(fp32_conv_form))
         self.device = device
         self._h = C.c_void_p()

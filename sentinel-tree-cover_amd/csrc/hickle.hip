@@ -18,6 +18,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <exception>
 #include <mutex>
 #include <thread>
 
@@ -44,10 +45,11 @@ struct Bytes {
 };
 struct File {
     Bytes b;
+    std::vector<uint8_t> owned;              // TTC_HKL_READ=1: the file's bytes, read() instead of mapped
     File() = default;
     File(const File&) = delete;
     File& operator=(const File&) = delete;
-    ~File() { if (b.p) munmap(const_cast<uint8_t*>(b.p), b.n); }
+    ~File() { if (b.p && owned.empty()) munmap(const_cast<uint8_t*>(b.p), b.n); }
     bool ok(uint64_t off, uint64_t n) const { return off <= b.size() && n <= b.size() - off; }
     uint64_t u(uint64_t off, int n) const {          // little-endian unsigned of n bytes
         uint64_t v = 0;
@@ -228,6 +230,9 @@ bool read_chunks(const File& f, const Dataset& d, uint8_t* out, std::string& err
     uint64_t chunk_elems = 1;
     for (int i = 0; i < R; ++i) chunk_elems *= d.chunk[i];
     const uint64_t chunk_bytes = chunk_elems * d.esize;
+    // a corrupt chunk shape must not become a multi-gigabyte allocation in every inflate thread: HDF5 itself caps a chunk at 4 GiB - 1,
+    // the job's chunks are < 1 MiB
+    if (chunk_elems == 0 || chunk_bytes > (1ull << 31)) { err = "implausible chunk size (corrupt dataset layout?)"; return false; }
     std::vector<ChunkRef> refs;
     std::vector<uint64_t> stack{d.data_addr};
     while (!stack.empty()) {
@@ -264,14 +269,19 @@ bool read_chunks(const File& f, const Dataset& d, uint8_t* out, std::string& err
     std::atomic<bool> failed{false};
     std::mutex mu;
     auto work = [&] {
-        std::vector<uint8_t> buf;
         std::string e;
-        for (size_t i = next.fetch_add(1); i < refs.size() && !failed.load(std::memory_order_relaxed); i = next.fetch_add(1))
-            if (!place_chunk(f, d, refs[i], chunk_bytes, buf, out, e)) {
-                std::lock_guard<std::mutex> g(mu);
-                if (!failed.exchange(true)) err = e;
-                return;
-            }
+        try {                                    // an exception that leaves a std::thread's function calls std::terminate
+            std::vector<uint8_t> buf;
+            for (size_t i = next.fetch_add(1); i < refs.size() && !failed.load(std::memory_order_relaxed); i = next.fetch_add(1))
+                if (!place_chunk(f, d, refs[i], chunk_bytes, buf, out, e)) {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!failed.exchange(true)) err = e;
+                    return;
+                }
+        } catch (const std::exception& ex) {
+            std::lock_guard<std::mutex> g(mu);
+            if (!failed.exchange(true)) err = std::string("inflate worker: ") + ex.what();
+        }
     };
     std::vector<std::thread> pool;
     for (int i = 1; i < nt; ++i) pool.emplace_back(work);
@@ -339,7 +349,20 @@ ttc_status ttc_read_hkl(const char* path, const char* name, void* h_out, size_t 
         if (fd < 0) return fail(TTC_ERR_IO, std::string("read_hkl: cannot open ") + path);
         struct stat sb;
         if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); return fail(TTC_ERR_IO, "read_hkl: cannot stat the file"); }
-        if (sb.st_size > 0) {
+        // Default: map the file (no copy of ~90 MB per tile).  A mapped file that is TRUNCATED or rewritten while it is being parsed (a download
+        // still in flight into temp/raw, some network filesystems) raises SIGBUS instead of an error return; TTC_HKL_READ=1 reads the bytes
+        // into memory first (+ ~15 ms per tile), after which nothing another process does to the file can reach this one.
+        static const bool use_read = [] { const char* e = getenv("TTC_HKL_READ"); return e && e[0] == '1'; }();
+        if (sb.st_size > 0 && use_read) {
+            try { f.owned.resize((size_t)sb.st_size); } catch (const std::exception&) { close(fd); return fail(TTC_ERR_NOMEM, "read_hkl: cannot allocate the file buffer"); }
+            size_t got = 0;
+            while (got < f.owned.size()) {
+                const ssize_t r = pread(fd, f.owned.data() + got, f.owned.size() - got, (off_t)got);
+                if (r <= 0) { close(fd); return fail(TTC_ERR_IO, "read_hkl: short read (file truncated while reading?)"); }
+                got += (size_t)r;
+            }
+            f.b.p = f.owned.data(); f.b.n = f.owned.size();
+        } else if (sb.st_size > 0) {
             void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m == MAP_FAILED) { close(fd); return fail(TTC_ERR_IO, "read_hkl: cannot map the file"); }
             f.b.p = static_cast<const uint8_t*>(m); f.b.n = (size_t)sb.st_size;

@@ -11,6 +11,19 @@
 
 #include "../../include/ttc.h"
 
+// ---- probe / bisecting entry points: exported (tools/probes/*.py and the cloud-detector stage tests bind them through ctypes) but NOT
+// part of the drop-in surface, hence declared here and not in include/ttc.h (sentinel-tree-cover_amd/_lib.py: INTERNAL_EXPORTS)
+extern "C" {
+/* stage != 0: ttc_identify_clouds_shadows returns the flag planes after that stage of the detector (bisecting aid). */
+ttc_status ttc_debug_clouds_stage(ttc_ctx* ctx, int32_t stage);
+/* PROBE ONLY -- not part of the drop-in surface.  Process-wide knobs of the 16-bit conv engine (tools/probes/h16_knobs.py, h16_trace.py):
+ * which 0 = persistent grid size (-1 default = 2 per CU, 0 = one workgroup per tile), 1 = start offset of the odd wave slot in
+ * s_sleep(127) units (-1 default), 2 | 3 = halves of a device pointer to a trace buffer, 4 = epilogue kind to trace.  They are plain
+ * process globals read at launch time by every context and stream, so the call is REFUSED (TTC_ERR_STATE) unless the process was
+ * started with TTC_ENABLE_PROBE_KNOBS=1 in its environment. */
+ttc_status ttc_debug_knob(int32_t which, int32_t value);
+}
+
 #define TTC_HIP(ctx, expr)                                                                   \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \

@@ -134,6 +134,31 @@ def predict_features(subtile, sess, size=SIZE):
     return probs[0].cpu().numpy(), feats.cpu().numpy()
 
 
+def superresolve_large_tile(arr, sess):
+    """src/download_and_predict_job.py:95-147, the call of :2001: `s2[..., :10] = superresolve_large_tile(s2[..., :10], sess)`.
+    arr: (T, X, Y, 10) float32 whose bands 4.. were bilinearly upsampled -- a numpy array (mutated in place AND returned, like
+    the reference's) or a cuda tensor (refined in place on the device, returned).  ONE ttc_superresolve_tile call: the 110-px
+    window tiling with its 4-px reflect pad, the x_end / y_end copies, the never-refined strip (:133-143) and the double pass
+    on the 110 x 42 patch all happen on the device; `sess` is the TTCSession that holds the DSen2 weights (TTCSession.run on
+    the superresolve tensor names stays available for callers that keep the reference's own Python loop)."""
+    ctx, t = sess.ctx, sess.ctx.torch
+    if isinstance(arr, t.Tensor):
+        if arr.dtype != t.float32 or not arr.is_contiguous():
+            raise ValueError("superresolve_large_tile: a cuda tensor must be contiguous float32 [T, X, Y, 10]")
+        ctx.superresolve_tile(arr, quirks=True)
+        return arr
+    a = np.asarray(arr)
+    if a.ndim != 4 or a.shape[-1] != 10:
+        raise ValueError(f"superresolve_large_tile: expected (T, X, Y, 10), got {a.shape}")
+    d = ctx._dev(np.ascontiguousarray(a, dtype=np.float32), t.float32)
+    ctx.superresolve_tile(d, quirks=True)
+    out = d.cpu().numpy()
+    if isinstance(arr, np.ndarray) and arr.dtype == np.float32:
+        arr[...] = out                                   # the reference writes into its argument (views included)
+        return arr
+    return out
+
+
 def sentinel1_to_db(s1_u16, sess):
     """The Sentinel-1 preparation of process_tile (src/download_and_predict_job.py:699-708) + convert_to_db
     (:74-89): uint16 [T, X, Y, 2] -> cuda float32."""
@@ -401,6 +426,8 @@ def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None):
     from concurrent.futures import ThreadPoolExecutor
     coords = list(coords)
     ahead = int(ahead) if ahead else 2 * int(workers)
+    if arena is not None:
+        arena.ahead = ahead                      # predict_tiles checks the arena's size against ahead + its own depth
 
     def load(xy, aset):
         raw = load_raw_tile(xy[0], xy[1], local_path, alloc=arena.allocator(aset) if arena is not None else None)
@@ -601,6 +628,9 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
     tiles: iterable of (raw, mask) as predict_tile_raw_checked takes them (may be a generator that loads files lazily:
     at most `depth` tiles are resident).  mask None = run the multi-temporal cloud / shadow DETECTION inside the call
     (TTC_TILE_DETECT; what the job does: job.py:839), a flagged tile then re-runs process_tile with its own detection.
+    A tile that comes with a Sen2Cor mask file (raw["clm"], job.py:685-697) and no given mask does NOT take the single call --
+    ttc_predict_tile has no input for it -- but the staged chain process_tile (which merges the cleaned mask into the detected
+    one, :841-846) -> superresolve -> predict_tile, and is reported as staged.
     on_result(k, result): called in input order as soon as tile k is finished (e.g. write_tif), while later tiles are in flight.
     timings: dict that receives host seconds spent staging uploads / waiting for results.  Raw arrays are staged through page-locked buffers and uploaded with non-blocking
     copies on the tile's stream (_PinnedStager), so the host never waits behind a stream's queued kernels while enqueueing; arrays that
@@ -617,6 +647,9 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         raise ValueError("predict_tiles: every session must live on the same device (shard tiles across ranks with shard.py)")
     streams = [t.cuda.Stream(device=dev) for _ in sessions]
     depth = int(depth) if depth else 2 * len(sessions)
+    if arena is not None and len(arena.sets) < getattr(arena, "ahead", 0) + depth + 2:
+        raise ValueError(f"predict_tiles: the PinnedArena has {len(arena.sets)} sets but the loop keeps up to "
+                         f"{getattr(arena, 'ahead', 0)} tiles read ahead + {depth} in flight: it needs >= {getattr(arena, 'ahead', 0) + depth + 2}")
     pending, results = deque(), []
     stager = _PinnedStager(t, dev, 2 * len(sessions))
     import time as _time
@@ -626,12 +659,17 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
         t0 = _time.perf_counter()
         with t.cuda.stream(st):
-            words = status.cpu().numpy()                                      # waits for this tile's stream only
-            staged = sess.ctx.tile_needs_staged(words)
-            if staged:
-                s2, dates, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None, clm=None), sess, sampler=sampler, cloudshad=mask)
-                sess.ctx.superresolve_tile(s2, quirks=True)
-                f32, u8 = predict_tile(s2, dates, interp, s1, dem, sess, size=size, to_host=False)
+            if status is None:                                                # went through the staged chain at enqueue time (Sen2Cor mask)
+                words, staged = np.zeros(4, dtype=np.int32), True
+            else:
+                words = status.cpu().numpy()                                  # waits for this tile's stream only
+                staged = sess.ctx.tile_needs_staged(words)
+                if staged:
+                    # a GIVEN mask replaces detection and Sen2Cor mask alike; without one the re-run detects and merges raw["clm"]
+                    s2, dates, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None, clm=None if mask is not None else raw.get("clm")),
+                                                                    sess, sampler=sampler, cloudshad=mask)
+                    sess.ctx.superresolve_tile(s2, quirks=True)
+                    f32, u8 = predict_tile(s2, dates, interp, s1, dem, sess, size=size, to_host=False)
             if to_host:
                 f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
             else:
@@ -646,40 +684,63 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
             on_result(k, results[-1])
 
     it = iter(tiles)
-    k = -1
-    while True:
-        t0 = _time.perf_counter()
-        try:
-            raw, mask = next(it)                                     # a lazy generator reads / waits for the tile's files here
-        except StopIteration:
-            break
-        k += 1
-        if timings is not None:
-            timings["next_tile_host_s"] = timings.get("next_tile_host_s", 0.0) + _time.perf_counter() - t0
-        sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
-        ctx = sess.ctx
-        t0 = _time.perf_counter()
-        arrays = {"s2_10": raw["s2_10"], "s2_20": raw["s2_20"], "s1": raw["s1"], "dem": np.asarray(raw["dem"], dtype=np.float32),
-                  "dates": np.asarray(raw["dates"], dtype=np.int32)}
-        if mask is not None:
-            arrays["mask"] = np.asarray(mask, dtype=np.float32)
-        d = stager.upload(k % (2 * len(sessions)), arrays, st)
-        if timings is not None:
-            timings["stage_h2d_host_s"] = timings.get("stage_h2d_host_s", 0.0) + _time.perf_counter() - t0
-        t0 = _time.perf_counter()
-        with t.cuda.stream(st):
-            dem_m = ctx.median5(d["dem"])                                                                # job.py:713 (metres: the detector's unit)
-            dem90 = ctx.divide(dem_m.clone(), 90.0)                                                      # :993
-            u8, f32, _, status = ctx.predict_tile_raw(d["s2_10"], d["s2_20"], d["s1"], dem90, d.get("mask"), d["dates"], min_all, max_all,
-                                                      size, dem_m=dem_m, flags=0 if mask is not None else ctx.TILE_DETECT, want_float=True)
-        if timings is not None:
-            timings["enqueue_host_s"] = timings.get("enqueue_host_s", 0.0) + _time.perf_counter() - t0
-        pending.append((k, raw, mask, u8, f32, status))
-        if len(pending) > depth:
+
+    def loop():
+        k = -1
+        while True:
+            t0 = _time.perf_counter()
+            try:
+                raw, mask = next(it)                                     # a lazy generator reads / waits for the tile's files here
+            except StopIteration:
+                break
+            k += 1
+            if timings is not None:
+                timings["next_tile_host_s"] = timings.get("next_tile_host_s", 0.0) + _time.perf_counter() - t0
+            sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
+            ctx = sess.ctx
+            if mask is None and isinstance(raw, dict) and raw.get("clm") is not None:
+                t0 = _time.perf_counter()
+                with t.cuda.stream(st):
+                    s2, dates_k, interp, s1, dem, _, _ = process_tile(dict(raw, clouds=None), sess, sampler=sampler)
+                    ctx.superresolve_tile(s2, quirks=True)
+                    f32, u8 = predict_tile(s2, dates_k, interp, s1, dem, sess, size=size, to_host=False)
+                if timings is not None:
+                    timings["enqueue_host_s"] = timings.get("enqueue_host_s", 0.0) + _time.perf_counter() - t0
+                pending.append((k, raw, mask, u8, f32, None))
+                if len(pending) > depth:
+                    finish()
+                continue
+            t0 = _time.perf_counter()
+            arrays = {"s2_10": raw["s2_10"], "s2_20": raw["s2_20"], "s1": raw["s1"], "dem": np.asarray(raw["dem"], dtype=np.float32),
+                      "dates": np.asarray(raw["dates"], dtype=np.int32)}
+            if mask is not None:
+                arrays["mask"] = np.asarray(mask, dtype=np.float32)
+            d = stager.upload(k % (2 * len(sessions)), arrays, st)
+            if timings is not None:
+                timings["stage_h2d_host_s"] = timings.get("stage_h2d_host_s", 0.0) + _time.perf_counter() - t0
+            t0 = _time.perf_counter()
+            with t.cuda.stream(st):
+                dem_m = ctx.median5(d["dem"])                                                                # job.py:713 (metres: the detector's unit)
+                dem90 = ctx.divide(dem_m.clone(), 90.0)                                                      # :993
+                u8, f32, _, status = ctx.predict_tile_raw(d["s2_10"], d["s2_20"], d["s1"], dem90, d.get("mask"), d["dates"], min_all, max_all,
+                                                          size, dem_m=dem_m, flags=0 if mask is not None else ctx.TILE_DETECT, want_float=True)
+            if timings is not None:
+                timings["enqueue_host_s"] = timings.get("enqueue_host_s", 0.0) + _time.perf_counter() - t0
+            pending.append((k, raw, mask, u8, f32, status))
+            if len(pending) > depth:
+                finish()
+        while pending:
             finish()
-    while pending:
-        finish()
-    return results
+        return results
+
+    try:
+        return loop()
+    except BaseException:
+        if arena is not None:                     # hand the sets of unfinished tiles back: an abandoned loop must not starve the next one
+            for rec in pending:
+                if isinstance(rec[1], dict) and rec[1].get("_arena_set") is not None:
+                    arena.release(rec[1]["_arena_set"])
+        raise
 
 
 def write_tif(arr, point, x, y, out_folder, suffix="_FINAL"):

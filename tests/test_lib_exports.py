@@ -27,6 +27,10 @@ def test_header_symbols_exported():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
+    # probe entry points live in csrc/ttc_internal.h, not in the public header
+    internal = open(os.path.join(ROOT, "sentinel-tree-cover_amd", "csrc", "ttc_internal.h")).read()
+    for name in _lib.INTERNAL_EXPORTS:
+        assert name not in hdr and re.search(r"\b" + name + r"\s*\(", internal) and hasattr(lib, name), name
     lib.ttc_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.ttc_version()
 
