@@ -57,7 +57,7 @@ constexpr int kIN = 2 * kSUB;            // floats of one staged chunk image (tw
 constexpr int kSE = kIR * (kIR / 2);     // float2 (two pixels of one channel) per channel of a sub-region image (162)
 constexpr int kVB = 36 * 256;            // floats of one V buffer: [xi 36][kq 4][tile 16][tb 2][s 2]
 #ifndef TTC_W4_RING
-#define TTC_W4_RING 9
+#define TTC_W4_RING 6
 #endif
 constexpr int kAR = TTC_W4_RING;         // A operands requested ahead (of the wave's 18 xi per chunk); 18 % kAR == 0
 constexpr int kXS = 64 * 24;             // floats of one exchange half-slot: 24 per lane (two couts x three rows a x four columns j)
