@@ -654,11 +654,11 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         size = args.win - 14
-        e2e_file = os.path.join(ROOT, "profiles", "r03_e2e_dprob.json")
+        e2e_file = os.path.join(ROOT, "profiles", "r05_e2e_dprob.json")
         sampler_effect = None
         if os.path.exists(e2e_file):
             with open(e2e_file) as f:
-                sampler_effect = dict(json.load(f), source="profiles/r03_e2e_dprob.json (tests/test_gpu_e2e.py, all 36 windows; not re-measured here)")
+                sampler_effect = dict(json.load(f), source="profiles/r05_e2e_dprob.json (tests/test_gpu_e2e.py, all 36 windows; not re-measured here)")
         r2r_file = os.path.join(ROOT, "profiles", "r05_reference_run_to_run.json")
         run_to_run = None
         if os.path.exists(r2r_file):

@@ -3,7 +3,7 @@
 # Kernel-stats runs use --inflight 1 --no-dprob --no-alt --no-cpu-baseline so that a kernel's average is not a mix of live
 # (two tiles in flight), isolated, warm-up and 3-window parity launches.  PMC passes are their own runs (--kernel-trace --pmc only).
 # ONLY=<section>[,<section>] restricts the run to stats | pmc_f32 | pmc_h16 | pmc_pre | bench.
-TAG=${1:-r04_g}
+TAG=${1:-r05_a}
 want() { [ -z "$ONLY" ] || [[ ",$ONLY," == *",$1,"* ]]; }
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -32,7 +32,7 @@ pmc() {  # out-file, kernel substring(s) separated by |, counters, command...
     rm -rf gpurun_out/pmc_$t
 }
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
-    want pmc_f32 && pmc $O/${TAG}_pmc_f32_gates.txt "conv3x3_wino<2, 0|conv3x3_wino<1, 1|conv3x3_f32<10, 2, 0" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
+    want pmc_f32 && pmc $O/${TAG}_pmc_f32_gates.txt "conv3x3_wino4<0|conv3x3_wino4<1|conv3x3_wino<2, 0|conv3x3_wino<1, 1" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
     want pmc_h16 && pmc $O/${TAG}_pmc_h16_gates.txt "conv3x3_h16<0, 3, 2, 0, 1|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
 done
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -26,13 +26,16 @@ def parse(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04_g"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05_a"
     rnd = tag.split("_")[0]
     algo = {"f32": {"read": 72 * 49 * 174 ** 2 * 4, "write": 72 * 64 * 172 * 174 * 4,
                     "what": "read 72 planes-sets x 49 ch x 174^2 x 4 B, write 72 x 64 x 172 x 174 x 4 B (input pitch)"},
             "h16": {"read": 72 * 56 * 174 ** 2 * 4, "write": 72 * 64 * 172 * 174 * 4,
                     "what": "read 72 x 56 ch (49 padded) x 174^2 x (hi + lo) 4 B, write 72 x 64 x 172 x 174 x (top + bottom halves) 4 B"}}
-    for eng, sub in (("f32", "conv3x3_wino<2, 0"), ("f32", "conv3x3_f32<10, 2, 0"), ("h16", "conv3x3_h16<0, 3, 2, 0, 1")):
+    done = set()
+    for eng, sub in (("f32", "conv3x3_wino4<0"), ("f32", "conv3x3_wino<2, 0"), ("f32", "conv3x3_f32<10, 2, 0"), ("h16", "conv3x3_h16<0, 3, 2, 0, 1")):
+        if eng in done:                                                                # the first kernel of an engine that ran is the product's
+            continue
         src = os.path.join(ROOT, "gpurun_out", "%s_pmc_%s_gates.txt" % (tag, eng))
         if not os.path.exists(src):
             continue
@@ -40,6 +43,7 @@ def main():
         if not k:
             continue
         k = k[0]
+        done.add(eng)
         traffic = int(k["FETCH_SIZE"]["avg"] * 1024 * 2 + k["WRITE_SIZE"]["avg"] * 1024)
         d = {"kernel": "%s...> (ConvGRU gates conv), W=172 L=4 36 windows, tools/gpu_probe.py 172 4 36 %s" % (sub, "fp32" if eng == "f32" else "fp16"),
              "method": "rocprofv3 --kernel-trace --pmc <one counter set per pass> (tools/gpu_pmc.sh via tools/gpu_profiles.sh %s); "
