@@ -531,6 +531,8 @@ def main():
                 for aset in range(len(arena.sets)):
                     arena.release(aset)
 
+            masks32 = [np.ascontiguousarray(p[0][2], dtype=np.float32) for p in pool]      # the given-mask loop's masks (a job would read them from clouds_*.hkl)
+
             def loop(n_loop, with_mask):
                 """the pipelined tile loop over n_loop tiles -> (seconds, results, host timings)"""
                 tmx, wr = {}, []
@@ -542,7 +544,7 @@ def main():
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 coords = [(k % n_tiles, 0) for k in range(n_loop)]
-                gen = ((raw_k, (pool[i % n_tiles % len(pool)][0][2].astype(np.float32) if with_mask else None))
+                gen = ((raw_k, (masks32[i % n_tiles % len(pool)] if with_mask else None))
                        for i, raw_k in enumerate(job.iter_raw_tiles(coords, root, workers=args.job_readers, arena=arena)))
                 rs = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tmx, on_result=on_res, arena=arena)
                 torch.cuda.synchronize()

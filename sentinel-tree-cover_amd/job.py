@@ -654,6 +654,24 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
     stager = _PinnedStager(t, dev, 2 * len(sessions))
     import time as _time
 
+    host_sets = {}                                # slot -> (status, u8, f32) page-locked result buffers, reused round-robin
+
+    def post_results(k, st, u8, f32, status):
+        """queue the tile's results into page-locked host buffers behind its kernels and record an EVENT: the loop later waits for that event,
+        not for the stream -- hipStreamSynchronize would also wait for the NEXT tile already queued on the same stream (measured: 19.4 vs 15.2 ms
+        per tile with three streams, tools/probes/job_overlap_probe.py modes H / I)"""
+        slot = k % (depth + 2)
+        hb = host_sets.get(slot)
+        if hb is None or hb[1].shape != u8.shape or hb[2].shape != f32.shape:
+            hb = host_sets[slot] = (t.empty(4, dtype=t.int32, pin_memory=True), t.empty(u8.shape, dtype=u8.dtype, pin_memory=True),
+                                    t.empty(f32.shape, dtype=f32.dtype, pin_memory=True))
+        with t.cuda.stream(st):
+            hb[0].copy_(status, non_blocking=True)
+            if to_host:
+                hb[1].copy_(u8, non_blocking=True)
+                hb[2].copy_(f32, non_blocking=True)
+            return hb, st.record_event()
+
     def finish():
         k, raw, mask, u8, f32, status = pending.popleft()
         sess, st = sessions[k % len(sessions)], streams[k % len(sessions)]
@@ -661,8 +679,14 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         with t.cuda.stream(st):
             if status is None:                                                # went through the staged chain at enqueue time (Sen2Cor mask)
                 words, staged = np.zeros(4, dtype=np.int32), True
+                if to_host:
+                    f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
+                else:
+                    st.synchronize()
             else:
-                words = status.cpu().numpy()                                  # waits for this tile's stream only
+                hb, ev = status
+                ev.synchronize()                                              # waits for THIS tile only (not for what is queued behind it)
+                words = hb[0].numpy().copy()
                 staged = sess.ctx.tile_needs_staged(words)
                 if staged:
                     # a GIVEN mask replaces detection and Sen2Cor mask alike; without one the re-run detects and merges raw["clm"]
@@ -670,10 +694,12 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
                                                                     sess, sampler=sampler, cloudshad=mask)
                     sess.ctx.superresolve_tile(s2, quirks=True)
                     f32, u8 = predict_tile(s2, dates, interp, s1, dem, sess, size=size, to_host=False)
-            if to_host:
-                f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
-            else:
-                st.synchronize()
+                    if to_host:
+                        f32, u8 = f32.cpu().numpy(), u8.cpu().numpy()
+                    else:
+                        st.synchronize()
+                elif to_host:
+                    f32, u8 = hb[2].numpy().copy(), hb[1].numpy().copy()      # the page-locked set is reused depth + 2 tiles later
         if timings is not None:
             timings["wait_d2h_host_s"] = timings.get("wait_d2h_host_s", 0.0) + _time.perf_counter() - t0
             timings["staged"] = timings.get("staged", 0) + int(staged)
@@ -724,6 +750,7 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
                 dem90 = ctx.divide(dem_m.clone(), 90.0)                                                      # :993
                 u8, f32, _, status = ctx.predict_tile_raw(d["s2_10"], d["s2_20"], d["s1"], dem90, d.get("mask"), d["dates"], min_all, max_all,
                                                           size, dem_m=dem_m, flags=0 if mask is not None else ctx.TILE_DETECT, want_float=True)
+            status = post_results(k, st, u8, f32, status)
             if timings is not None:
                 timings["enqueue_host_s"] = timings.get("enqueue_host_s", 0.0) + _time.perf_counter() - t0
             pending.append((k, raw, mask, u8, f32, status))
