@@ -74,6 +74,12 @@ typedef struct {
                             * 1 = F(2x2,3x3) only (rounds 4's engine): raw outputs <= 5e-5, probabilities <= 3e-5;
                             * 2 = direct implicit GEMM only (9 multiply-accumulates per tap: the slowest, <= 2e-5).
                             * The contract of the path is 1e-3 on probabilities (BASELINE.json).                          */
+    int32_t dsen2_precision; /* the DSen2 super-resolution convs (src/download_and_predict_job.py:95-147) only: 0 = the context's
+                            * `precision`; 2 / 3 = run them on the 16-bit engine with fp16 / bf16 hi + lo operand pairs and all THREE
+                            * split products (fp32 accumulate, fp32 bias / residual / tanh) even when `precision` is 0.  fp16 pairs
+                            * carry 22 significant bits: <= 1e-5 on reflectance against the fp64 graph (fp32 engine: 6e-7), end to
+                            * end on probabilities the same 3e-5 class as precision 0 (tests/test_gpu_tile.py, test_gpu_e2e.py);
+                            * 2.4 ms instead of 5.0 ms per 618^2 x 12-date tile.  Ignored when `precision` is 2 / 3.  Default 0. */
 } ttc_config;
 
 /* A named host tensor in TensorFlow layout (conv kernels HWIO). */

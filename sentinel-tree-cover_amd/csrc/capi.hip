@@ -83,6 +83,8 @@ ttc_status ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg) {
     if (cfg->max_windows < 1 || cfg->length < 1) return c->fail(TTC_ERR_ARG, "max_windows and length must be >= 1");
     if (cfg->fp32_conv_form < 0 || cfg->fp32_conv_form > 2)
         return c->fail(TTC_ERR_ARG, "fp32_conv_form: 0 (Winograd F(4x4,3x3) where it applies), 1 (F(2x2,3x3) at most), 2 (direct only)");
+    if (cfg->dsen2_precision != 0 && cfg->dsen2_precision != 2 && cfg->dsen2_precision != 3)
+        return c->fail(TTC_ERR_ARG, "dsen2_precision: 0 (the context's precision), 2 (fp16) / 3 (bf16) hi + lo pairs on the 16-bit engine");
     return model_alloc(c);
 }
 

@@ -446,11 +446,11 @@ long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, i
     return per_set;
 }
 
-ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN, int C0) {
+ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN, int C0, int mode) {
     pc.Cin = Cin; pc.Cout = Cout; pc.nsets = nsets;
     pc.CK = conv_pick_ck(Cin); pc.BN = BN;
     pc.nchunk = (Cin + pc.CK - 1) / pc.CK; pc.ncb = (Cout + pc.BN - 1) / pc.BN;
-    pc.mode = c->cfg.precision;
+    pc.mode = mode < 0 ? c->cfg.precision : mode;
     pc.form = c->cfg.fp32_conv_form;
     std::vector<float> packed;
     pc.set_stride = conv_pack(hwio, nsets, Cin, Cout, pc.CK, pc.BN, packed);

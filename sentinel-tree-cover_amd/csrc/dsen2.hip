@@ -272,8 +272,9 @@ ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n) {
         if (!k || !b) return c->fail(TTC_ERR_ARG, std::string("missing DSen2 tensor for ") + kDsNames[l]);
         PackedConv& pc = c->w_ds[l];
         const float* kk[1] = {k->data};
-        TTC_CHECK(conv_upload(c, pc, kk, 1, kDsCin[l], kDsCout[l], 32));
-        pc.terms = (c->cfg.one_term_layers >> (10 + l)) & 1u ? 1 : 3;
+        // ttc_config.dsen2_precision: an fp32 context may run these six convs on the 16-bit engine (hi + lo pairs, always three products there)
+        TTC_CHECK(conv_upload(c, pc, kk, 1, kDsCin[l], kDsCout[l], 32, -1, c->ds_half() && !c->half() ? c->cfg.dsen2_precision : -1));
+        pc.terms = (c->half() && ((c->cfg.one_term_layers >> (10 + l)) & 1u)) ? 1 : 3;
         std::vector<float> bb(32, 0.0f);
         for (int i = 0; i < pc.Cout; ++i) bb[i] = b->data[i];
         bias.insert(bias.end(), bb.begin(), bb.end());
@@ -382,12 +383,12 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
     hipLaunchKernelGGL(k_nhwc_to_planar, dim3((Hp * Wp + 255) / 256, n), dim3(256), 0, s, d_in, 10, 0, 10, H, W, 1, xin);
     hipLaunchKernelGGL(k_nhwc_to_planar, dim3((H * W + 255) / 256, n), dim3(256), 0, s, d_bil, 6, 0, 6, H, W, 0, bil);
     TTC_HIP(c, hipGetLastError());
-    if (c->half()) {
+    if (c->ds_half()) {
         const size_t ub = (size_t)n * 2 * Hp * Wp * 16;
         B16 x16{static_cast<uint4*>(c->scratch_buf("ds16_inh", ub)), static_cast<uint4*>(c->scratch_buf("ds16_inl", ub))};
         if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
         const dim3 g16((Hp * Wp + 255) / 256, n);
-        const int m = c->blk_mode();
+        const int m = c->ds_blk_mode();
         if (m == 1) hipLaunchKernelGGL((k_planar_to_b16<1>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
         else hipLaunchKernelGGL((k_planar_to_b16<0>), g16, dim3(256), 0, s, xin, 10, (long)Hp * Wp, 2, x16.hi, x16.lo);
         TTC_HIP(c, hipGetLastError());
@@ -441,18 +442,18 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
         float* bil = static_cast<float*>(c->scratch_buf("ds_bil", sizeof(float) * (size_t)n * 6 * E * E));
         float* res = static_cast<float*>(c->scratch_buf("ds_out", sizeof(float) * (size_t)n * 6 * E * E));
         if (!bil || !res) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
-        if (c->half()) {
+        if (c->ds_half()) {
             const size_t ub = (size_t)n * 2 * Ep * Ep * 16;
             B16 x16{static_cast<uint4*>(c->scratch_buf("ds16_inh", ub)), static_cast<uint4*>(c->scratch_buf("ds16_inl", ub))};
             if (!x16.hi || !x16.lo) return c->fail(TTC_ERR_NOMEM, "DSen2 scratch");
             { KTimer kt(c, "dsen2_gather", s);
               const dim3 gg((Ep * Ep + 255) / 256, sw.n, T);
-              const int m = c->blk_mode();
+              const int m = c->ds_blk_mode();
               if (m == 1) hipLaunchKernelGGL((k_sr_gather_b16<1>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
               else hipLaunchKernelGGL((k_sr_gather_b16<0>), gg, dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, x16.hi, x16.lo);
               hipLaunchKernelGGL(k_sr_bil_tile, dim3((E * E + 255) / 256, sw.n, T), dim3(256), 0, s, d_s2, X, Y, sw, ws, cs, bil);
               TTC_HIP(c, hipGetLastError()); }
-            { const int m = c->blk_mode();
+            { const int m = c->ds_blk_mode();
               TTC_CHECK(m == 1 ? dsen2_core_h16<1>(c, x16, bil, n, E, E, res, s) : dsen2_core_h16<0>(c, x16, bil, n, E, E, res, s)); }
         } else {
             float* xin = static_cast<float*>(c->scratch_buf("ds_in", sizeof(float) * (size_t)n * 10 * Ep * Ep));

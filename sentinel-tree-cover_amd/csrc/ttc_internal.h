@@ -185,7 +185,7 @@ float h16_to_float(uint16_t h, bool bf);
 struct ttc_ctx;
 // packs + uploads the weights of one layer for the engine selected by ctx->cfg.precision (both images when 1)
 // C0: real channels of the first of two concatenated input segments (-1: one segment); only the 16-bit engine needs it
-ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN, int C0 = -1);
+ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int nsets, int Cin, int Cout, int BN, int C0 = -1, int mode = -1);   // mode: engine the images are packed for (-1 = cfg.precision)
 
 // ----------------------------------------------------------------------------- context
 struct Timing {
@@ -246,6 +246,9 @@ struct ttc_ctx {
     bool alloc_b16(B16& b, size_t units);       // hi + lo tensors of `units` 16-byte K vectors each
     bool half() const { return cfg.precision >= 2; }      // 16-bit conv engine selected (channel-blocked hi / lo pairs)
     int blk_mode() const { return cfg.precision == 3 ? 1 : 0; }   // Elem<> mode: fp16 / bf16
+    // DSen2's convs may run on the 16-bit engine (hi + lo pairs, three products) inside an fp32 context: ttc_config.dsen2_precision
+    bool ds_half() const { return half() || cfg.dsen2_precision >= 2; }
+    int ds_blk_mode() const { return half() ? blk_mode() : (cfg.dsen2_precision == 3 ? 1 : 0); }
     void* scratch_buf(const std::string& key, size_t bytes);
     void* pinned_buf(const std::string& key, size_t bytes);
 };

@@ -19,8 +19,9 @@ from tests.helpers import ROOT, synth
 pytestmark = pytest.mark.gpu
 
 TILE, T, SIZE = 618, 12, 158
-TOL = {"fp32": 2e-4, "fp16": 2e-4, "bf16": 1e-3}          # measured max|dprob|: fp32 2.6e-5 / 4.8e-5, fp16 5.2e-5, bf16 3.3e-4
-FEED_TOL = {"fp32": 1e-4, "fp16": 1e-4, "bf16": 5e-4}
+TOL = {"fp32": 2e-4, "fp16": 2e-4, "bf16": 1e-3, "fp32+ds16": 2e-4}          # measured max|dprob|: fp32 2.6e-5 / 4.8e-5, fp16 5.2e-5, bf16 3.3e-4
+FEED_TOL = {"fp32": 1e-4, "fp16": 1e-4, "bf16": 5e-4, "fp32+ds16": 1e-4}
+# "fp32+ds16" = an fp32 session whose DSen2 convs run on the 16-bit engine (fp16 hi + lo pairs, three products): ttc_config.dsen2_precision
 
 
 def u16(a):
@@ -59,7 +60,8 @@ def oracle_for(seed, sampler="expected", size=SIZE, length=4):
 def hip_tile(seed, precision, size=SIZE, length=4):
     import torch
     from ttc import job, weights as Wt
-    sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=length, max_windows=36, precision=precision)
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=length, max_windows=36, precision=precision.split("+")[0],
+                          dsen2_precision="fp16" if precision.endswith("+ds16") else None)
     s2_10, s2_20, mask, dates, s1, dem = bench_tile(seed)
     u8, f32, frames, status = sess.ctx.predict_tile_raw(s2_10, s2_20, s1, dem, mask, dates, job.min_all, job.max_all, size,
                                                         want_float=True, want_inputs=True)
@@ -87,7 +89,8 @@ def window_stats(hip_raw, ref):
 # (seed, precision, window output size, steps): 158 / 4 = the geometry the reference's code runs (172-px inputs); 154 / 12 = the
 # geometry BASELINE.json's wording names (168-px inputs, 12 steps; job.py:1457-1472 applies no no-image mask at 154, :1274-1283)
 @pytest.mark.parametrize("seed,precision,size,length", [(1234, "fp32", SIZE, 4), (1234, "fp16", SIZE, 4), (1234, "bf16", SIZE, 4),
-                                                        (1235, "fp32", SIZE, 4), (1234, "fp32", 154, 12), (1234, "fp16", 154, 12)])
+                                                        (1235, "fp32", SIZE, 4), (1234, "fp32", 154, 12), (1234, "fp16", 154, 12),
+                                                        (1234, "fp32+ds16", SIZE, 4)])
 def test_single_call_tile_vs_chained_oracle(seed, precision, size, length):
     ref = oracle_for(seed, size=size, length=length)
     got = hip_tile(seed, precision, size, length)

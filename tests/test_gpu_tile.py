@@ -14,12 +14,14 @@ _SESS = {}
 
 
 def _session(W=172, L=4, seed=0, precision="fp32"):
-    """one session per geometry for the whole module (workspace is several GB)"""
+    """one session per geometry for the whole module (workspace is several GB); "fp32+ds16" = an fp32 session whose DSen2 convs run on
+    the 16-bit engine (ttc_config.dsen2_precision = fp16 pairs)"""
     from ttc import job, weights as Wt
     key = (W, L, seed, precision)
     if key not in _SESS:
         _SESS.clear()
-        _SESS[key] = (job.TTCSession(Wt.synth_weights(seed), win_in=W, length=L, precision=precision), Wt.synth_weights(seed))
+        _SESS[key] = (job.TTCSession(Wt.synth_weights(seed), win_in=W, length=L, precision=precision.split("+")[0],
+                                     dsen2_precision="fp16" if precision.endswith("+ds16") else None), Wt.synth_weights(seed))
     return _SESS[key]
 
 
@@ -253,7 +255,32 @@ def test_feature_mosaic_matches_reference():
     assert d.max() <= 1 and (d > 0).mean() < 1e-2
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("fp16", 5e-5), ("bf16", 1e-4)])
+def test_dsen2_precision_option_in_fp32_session():
+    """ttc_config.dsen2_precision: DSen2 on fp16 hi + lo pairs (three products) inside an fp32 session -- same oracle, the 16-bit engine's
+    tolerances; the model itself still runs the fp32 engine (probabilities identical to the plain fp32 session's on the same feeds)"""
+    import torch
+    from oracle import restate_model as M, restate_numpy as O
+    from ttc import weights as Wt
+    rng = np.random.default_rng(5)
+    x = rng.random((3, 118, 118, 10)).astype(np.float32)
+    arr = (rng.random((2, 618, 618, 10)) * 0.6).astype(np.float32)
+    wins = rng.random((2, 5, 172, 172, 17)).astype(np.float32)
+    sess32, _ = _session(172, 4)
+    plain = sess32.ctx.dsen2_forward(x, x[..., 4:]).cpu().numpy()
+    p32 = sess32.ctx.forward_windows(torch.from_numpy(wins).cuda()).cpu().numpy()
+    sess, _ = _session(172, 4, precision="fp32+ds16")
+    net = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    got = sess.ctx.dsen2_forward(x, x[..., 4:]).cpu().numpy()
+    _report("DSen2 window (fp32 session, fp16-pair DSen2)", got, net(x, x[..., 4:]), 5e-5)
+    assert not np.array_equal(got, plain)                                    # the option took effect
+    ref = O.superresolve_large_tile(arr.copy(), net)
+    d = torch.from_numpy(arr.copy()).cuda()
+    sess.ctx.superresolve_tile(d, quirks=True)
+    _report("superresolve tile (fp32 session, fp16-pair DSen2)", d.cpu().numpy(), ref, 1e-4)
+    np.testing.assert_array_equal(sess.ctx.forward_windows(torch.from_numpy(wins).cuda()).cpu().numpy(), p32)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("fp16", 5e-5), ("bf16", 1e-4), ("fp32+ds16", 5e-5)])
 def test_dsen2_ragged_windows(precision, tol):
     """odd / tiny window sizes: planes whose size is not a multiple of 4 take the conv engines' unaligned staging path"""
     import torch
