@@ -243,9 +243,9 @@ def main():
             os._exit(3)
     weights = Wt.synth_weights(0)
 
-    def make_sessions(precision, win=args.win, length=args.length, n=args.inflight, dsen2_precision=None):
+    def make_sessions(precision, win=args.win, length=args.length, n=args.inflight, dsen2_precision=None, two_term_layers=0):
         return [job.TTCSession(weights, win_in=win, length=length, max_windows=36, device=local, precision=precision,
-                               dsen2_precision=dsen2_precision) for _ in range(n)]
+                               dsen2_precision=dsen2_precision, two_term_layers=two_term_layers) for _ in range(n)]
 
     # ---- the tile pool: tile_id = k * world + rank, seed 1234 + tile_id; raw arrays as stored (uint16, tof_downloading.py:51-61)
     def u16(a):
@@ -640,6 +640,17 @@ def main():
                 r16 = roofline(other, args.win, 36, g2, 0, args.length)
                 extra["alt_" + other]["roofline"] = {k: r16[k] for k in ("kernel", "achieved", "peak", "frac", "mfma_issue_frac", "hbm_frac")}
             close(ss)
+        # the fp16 engine with the two ConvGRU convs on TWO products, x_hi * (w_hi + w_lo) (ttc_config.two_term_layers = 3):
+        # an accuracy option inside the 1e-3 contract, outside the 2e-4 the default engines keep
+        ss = make_sessions("fp16", two_term_layers=3)
+        dt2, g2, _, _ = measure(ss, alt_steps, 2)
+        extra["alt_fp16_two_term"] = {"precision": "fp16, two_term_layers = 3 (ConvGRU gates + candidate)", "dtype": DTYPES["fp16"] + "; ConvGRU convs: 2 products",
+                                      "value": args.inflight * TILE * TILE * alt_steps / dt2, "unit": "px/s", "ms_per_step": dt2 / alt_steps * 1e3,
+                                      "steps": alt_steps, "conv_gates_launch_ms": g2,
+                                      "max_dprob": None if args.no_dprob else max_dprob(ss[0]),
+                                      "max_dprob_e2e": None if args.no_dprob else dprob_e2e(ss[0], ref),
+                                      "note": "informational, not the headline value; default off (max_dprob_e2e above the 2e-4 of the default engines)"}
+        close(ss)
         if args.precision == "fp32":
             # the fp32 step with ONLY the DSen2 super-resolution convs on the 16-bit engine (fp16 hi + lo pairs, three products: <= 1e-5 on
             # reflectance; ttc_config.dsen2_precision).  An option, reported beside the headline -- never the headline.

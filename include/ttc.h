@@ -80,6 +80,14 @@ typedef struct {
                             * carry 22 significant bits: <= 1e-5 on reflectance against the fp64 graph (fp32 engine: 6e-7), end to
                             * end on probabilities the same 3e-5 class as precision 0 (tests/test_gpu_tile.py, test_gpu_e2e.py);
                             * 2.4 ms instead of 5.0 ms per 618^2 x 12-date tile.  Ignored when `precision` is 2 / 3.  Default 0. */
+    uint32_t two_term_layers; /* precision 2 (fp16 pairs) only: bit i set = conv layer i (bits 0..9 as in `one_term_layers`; the DSen2
+                            * bits are ignored) multiplies TWO products, x_hi * (w_hi + w_lo): 16-bit ACTIVATIONS, exact weights -- the lo
+                            * half of the layer's input is neither staged nor multiplied (2/3 of the matrix work, half the input bytes).
+                            * `one_term_layers` wins where both bits are set.  Default 0.  Costed per layer on the CPU
+                            * (profiles/r04_two_product_study.txt): gates 1.4e-4, candidate 5.0e-4, any U-Net block >= 1.6e-3 max |dprob|;
+                            * measured for bits 0 | 1 (both ConvGRU convs): white-noise windows 1.7e-4 .. 7.0e-4 (tests/test_gpu_h16.py),
+                            * but 3.9e-3 END TO END on bench.py's real tile (`alt_fp16_two_term`: 37.1 vs 35.3 Mpx/s) -- OUTSIDE the
+                            * 1e-3 contract, like every one-product form.  Only for workloads with a looser accuracy budget.       */
 } ttc_config;
 
 /* A named host tensor in TensorFlow layout (conv kernels HWIO). */

@@ -37,7 +37,7 @@ class TTCConfig(C.Structure):
     _fields_ = [("win_in", C.c_int32), ("length", C.c_int32), ("max_windows", C.c_int32),
                 ("n_bands", C.c_int32), ("hidden", C.c_int32), ("base_filters", C.c_int32),
                 ("zoneout", C.c_float), ("precision", C.c_int32), ("win_rows", C.c_int32),
-                ("one_term_layers", C.c_uint32), ("fp32_conv_form", C.c_int32), ("dsen2_precision", C.c_int32)]
+                ("one_term_layers", C.c_uint32), ("fp32_conv_form", C.c_int32), ("dsen2_precision", C.c_int32), ("two_term_layers", C.c_uint32)]
 
 
 # ttc_config.precision values.  The 16-bit engine multiplies three split products in every layer by default
@@ -195,7 +195,7 @@ class Context:
     """One libttc context: (device, window geometry, weights, workspace)."""
 
     def __init__(self, win_in=172, length=4, max_windows=36, device=0, zoneout=0.75, precision=0, win_rows=0,
-                 one_term_layers=None, fp32_conv_form=0, dsen2_precision=None):
+                 one_term_layers=None, fp32_conv_form=0, dsen2_precision=None, two_term_layers=0):
         self.lib = load()
         self.torch = _torch()
         precision = PRECISIONS.get(precision, precision)
@@ -204,7 +204,7 @@ class Context:
         if isinstance(dsen2_precision, str):
             dsen2_precision = PRECISIONS[dsen2_precision]
         self.cfg = TTCConfig(win_in, length, max_windows, 17, 32, 64, zoneout, precision, win_rows, one_term_layers, int(fp32_conv_form),
-                             int(dsen2_precision or 0))
+                             int(dsen2_precision or 0), int(two_term_layers or 0))
         self.device = device
         self._h = C.c_void_p()
         st = self.lib.ttc_create(C.byref(self._h), device, C.byref(self.cfg))

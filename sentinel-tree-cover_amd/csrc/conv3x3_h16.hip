@@ -516,12 +516,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
         // LDS: HI[0] HI[1] LO W[0] W[1], W = [hi plane | lo plane].  The chunk stream runs ACROSS tiles: buffer parity follows the
         // global chunk counter g, and the stage after the last chunk of a tile is chunk 0 of the workgroup's next tile -- `src`
         // always describes the tile whose chunks are being STAGED, `ep` the tile being multiplied.
-        const int LOU = 2 * INU, WU0 = 3 * INU;
+        // TERMS == 2 (ttc_config.two_term_layers): x_hi * (w_lo, w_hi) only -- 16-bit activations, exact weights.  No lo tile is staged
+        // (LDS: HI[0] HI[1] W[0] W[1]) and a chunk has ONE barrier.
+        const int LOU = 2 * INU, WU0 = TERMS == 3 ? 3 * INU : 2 * INU;
         Src src = src_of(wslot);
         Ep ep = ep_of(src);
         issue_in(src, in_plane(src, 0, false), 0);
         issue_w(src.wsrc, WU0, 2 * WPIECES, 0, kMaxW);
-        issue_in(src, in_plane(src, 0, true), LOU);
+        if constexpr (TERMS == 3) issue_in(src, in_plane(src, 0, true), LOU);
         // one chunk of the stream: multiply the chunk in buffer parity g & 1 while (cn, any) -- chunk cn of `src`, if any -- is staged.
         // mode 0: a chunk on its own (5 + 5 K blocks).  Chunks 2i and 2i + 1 of a tile form a PAIR whose hi-tile products skip the
         // half-empty fifth K block: mode 1 (first of the pair) ends with the straddle block over both chunks' tap 8 -- by then the
@@ -536,14 +538,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_h16(H16Args a, int nblk_q
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // hi, lo and weights of this chunk have landed (and, after an
             cbarrier();                                               // epilogue, its stores have retired) ... for every wave; every
                                                                       // wave is done with the previous chunk
-            mfma_chunk_s(LOU, WU0 + b * 2 * WUNITS, [&](int kb) {      // x_lo * w_hi; next hi tile after K block 0, weights after 1 and 2
+            auto stage_next = [&](int kb) {                           // next hi tile after K block 0, weights after 1 and 2
                 if (kb == 0) issue_in(src, nhi, (b ^ 1) * INU);
                 else if (kb == 1) issue_w(nws, nwu, 2 * WPIECES, 0, (kMaxW + 1) / 2);
                 else if (kb == 2) issue_w(nws, nwu, 2 * WPIECES, (kMaxW + 1) / 2, kMaxW);
-            });
-            cbarrier();                                               // the lo tile is free
-            mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, mode == 0 ? kKB : kKB - 1,
-                             [&](int kb) { if (kb == 0) issue_in(src, nlo, LOU); });   // x_hi * (w_lo, w_hi)
+            };
+            if constexpr (TERMS == 3) {
+                mfma_chunk_s(LOU, WU0 + b * 2 * WUNITS, stage_next);   // x_lo * w_hi
+                cbarrier();                                           // the lo tile is free
+                mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, mode == 0 ? kKB : kKB - 1,
+                                 [&](int kb) { if (kb == 0) issue_in(src, nlo, LOU); });   // x_hi * (w_lo, w_hi)
+            } else {
+                (void)nlo;
+                mfma_chunk_hi2_s(b * INU, WU0 + b * 2 * WUNITS, mode == 0 ? kKB : kKB - 1, stage_next);   // x_hi * (w_lo, w_hi)
+            }
             if (mode == 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pair chunk's tiles (issued during this chunk) have landed
                 cbarrier();
@@ -610,7 +618,7 @@ hipError_t launch_h16(const H16Args& a, const PackedConv& pw, int n, hipStream_t
     constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;
     const int TL = kBQ + 2 * a.c.Wp + 2;
     const int NIN = (TL + 63) >> 6;
-    const size_t lds = TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)(3 * NIN + 4 * WPIECES) * 1024;
+    const size_t lds = TERMS == 1 ? (size_t)3 * (NIN + WPIECES) * 1024 : (size_t)((TERMS == 3 ? 3 : 2) * NIN + 4 * WPIECES) * 1024;
     if (lds > 160 * 1024 || NIN > 16) return hipErrorInvalidValue;
     static LdsConfig lds_cfg;
     if (hipError_t e = lds_cfg.ensure(&conv3x3_h16<BF, TERMS, NCG, EPI, OUT>, lds); e != hipSuccess) return e;
@@ -724,7 +732,7 @@ long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cou
 
 hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s) {
     const bool bf = mode == 1;
-    const int terms = pw.terms == 1 ? 1 : 3;
+    const int terms = pw.terms == 1 ? 1 : (pw.terms == 2 ? 2 : 3);
 #define TTC_H16_CASE(BFV, T, ncg, e, o) \
     if ((int)bf == BFV && terms == T && pw.BN == ncg * 32 && epi == e && out_kind == o) return launch_h16<BFV, T, ncg, e, o>(a, pw, n, s);
 #define TTC_H16_LAYERS(BFV, T)                                                                                       \
@@ -737,6 +745,10 @@ hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, int mode, int
     TTC_H16_LAYERS(0, 3)
     TTC_H16_LAYERS(0, 1)
     TTC_H16_LAYERS(1, 3)
+    // two products (x_hi * w): the GroupNorm layers of the fp16 engine only (ttc_config.two_term_layers)
+    TTC_H16_CASE(0, 2, 2, EPI_RAW, OUT_B16)
+    TTC_H16_CASE(0, 2, 1, EPI_SSE, OUT_B16)
+    TTC_H16_CASE(0, 2, 2, EPI_SWISH, OUT_B16)
 #undef TTC_H16_LAYERS
 #undef TTC_H16_CASE
     return hipErrorInvalidValue;

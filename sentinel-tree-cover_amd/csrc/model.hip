@@ -732,10 +732,12 @@ ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
         }
     }
     const uint32_t one = c->cfg.one_term_layers;         // 16-bit engine: layers that multiply hi x hi only
+    const uint32_t two = c->cfg.precision == 2 ? c->cfg.two_term_layers : 0u;     // fp16 engine: layers that multiply x_hi x (w_hi + w_lo)
+    auto terms_of = [&](int bit) { return ((one >> bit) & 1u) ? 1 : (((two >> bit) & 1u) ? 2 : 3); };
     TTC_CHECK(upload_conv(c, c->w_gates, gk, 2, Cx + Hd, 2 * Hd, Cx));
     TTC_CHECK(upload_conv(c, c->w_cand, ck, 2, Cx + Hd, Hd, Cx));
-    c->w_gates.terms = (one & 1u) ? 1 : 3;
-    c->w_cand.terms = (one & 2u) ? 1 : 3;
+    c->w_gates.terms = terms_of(0);
+    c->w_cand.terms = terms_of(1);
     for (int b = 0; b < 8; ++b) {
         const std::string p = std::string(kBlockNames[b]) + "/";
         const int Ci = kBlockCin[b], Co = kBlockCout[b];
@@ -747,7 +749,7 @@ ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n) {
         if (!k || !ga || !be || !sw || !sb) return TTC_ERR_ARG;
         const float* kk[1] = {k->data};
         TTC_CHECK(upload_conv(c, c->w_block[b], kk, 1, Ci, Co));
-        c->w_block[b].terms = (one >> (2 + b)) & 1u ? 1 : 3;
+        c->w_block[b].terms = terms_of(2 + b);
         c->small_off[p] = (long)small.size();
         small.insert(small.end(), ga->data, ga->data + Co);
         small.insert(small.end(), be->data, be->data + Co);

@@ -59,19 +59,21 @@ class TTCSession:
     """
 
     def __init__(self, weights=None, win_in=SIZE + 14, length=LEN, max_windows=36, device=0, zoneout=0.75,
-                 dsen2_weights="package", precision="fp32", win_rows=0, one_term_layers=None, fp32_conv_form=0, dsen2_precision=None):
+                 dsen2_weights="package", precision="fp32", win_rows=0, one_term_layers=None, fp32_conv_form=0, dsen2_precision=None,
+                 two_term_layers=0):
         """precision: "fp32" = exact fp32 MFMA chains (default); "fp16" / "bf16" = the 16-bit engine (conv inputs stored
         as hi + lo 16-bit pairs, fp32 accumulate; per layer three split products or one, `one_term_layers` bit mask as in
         ttc.h -- default 0: EVERY layer multiplies three products; any single layer on one plain fp16 product measured
         3.0e-3 .. 2.7e-2 max |dprob| on a real tile, outside the 1e-3 contract).
         fp32_conv_form (precision fp32): 0 = fastest (Winograd F(4x4,3x3) / F(2x2,3x3)), 1 = F(2x2,3x3) at most, 2 = direct only: ttc.h.
         dsen2_precision: None = the session's precision; "fp16" / "bf16" = run the DSen2 super-resolution convs on the 16-bit engine (hi + lo
-        pairs, three products: <= 1e-5 on reflectance for fp16) inside an fp32 session -- 2.4 instead of 5.0 ms per tile (ttc.h)."""
+        pairs, three products: <= 1e-5 on reflectance for fp16) inside an fp32 session -- 2.4 instead of 5.0 ms per tile (ttc.h).
+        two_term_layers (precision fp16): bit mask of layers that multiply x_hi * (w_hi + w_lo) only (ttc.h; 3 = both ConvGRU convs)."""
         prec = _lib.PRECISIONS.get(precision, precision)
         # win_rows: rows of a non-square window (the 220 x 684 border graph of resegment_tiles_wide.py); 0 = square
         self.ctx = _lib.Context(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout,
                                 precision=prec, win_rows=win_rows, one_term_layers=one_term_layers, fp32_conv_form=fp32_conv_form,
-                                dsen2_precision=dsen2_precision)
+                                dsen2_precision=dsen2_precision, two_term_layers=two_term_layers)
         self.win_in, self.length = win_in, length
         if weights is not None:
             self.ctx.load_weights(_weights.validate(dict(weights)))

@@ -53,6 +53,31 @@ def test_forward_16bit_matches_oracle(W, L, N, precision, one_term, tol):
     np.testing.assert_array_equal(out, ctx.forward_windows(x).cpu().numpy())        # deterministic
 
 
+@pytest.mark.parametrize("W,L,N", [(44, 4, 2), (172, 4, 2), (168, 12, 1)])
+def test_two_term_convgru_layers(W, L, N):
+    """ttc_config.two_term_layers = 3: the ConvGRU gates and candidate convs multiply x_hi * (w_hi + w_lo) -- 16-bit activations, exact
+    weights (conv3x3_h16<TERMS = 2>).  An accuracy OPTION inside the 1e-3 contract (CPU study: 1.4e-4 / 5.0e-4 per layer); it must sit
+    between the three-product default and the one-product form, and the other layers must still run three products."""
+    import torch
+    from oracle import restate_model as M
+    from ttc import _lib, weights as Wt
+    w = Wt.synth_weights(W + L, stored_scale=True)
+    x = synth.synth_windows(seed=W + L + 1, N=N, L=L, W=W)
+    ref = M.TreeCoverNet({k: v.astype(np.float64) for k, v in w.items()}, dtype=torch.float64)(x.astype(np.float64))[..., 0]
+    errs = {}
+    for name, kw in (("three", {}), ("two", {"two_term_layers": 3}), ("one", {"one_term_layers": 3})):
+        ctx = _lib.Context(win_in=W, length=L, max_windows=N, precision="fp16", **kw)
+        ctx.load_weights(w)
+        out = ctx.forward_windows(x).cpu().numpy()
+        if name == "two":
+            np.testing.assert_array_equal(out, ctx.forward_windows(x).cpu().numpy())    # deterministic
+        errs[name] = float(np.abs(out.astype(np.float64) - ref).max())
+        ctx.close()
+    print(f"[parity] W{W} L{L} fp16 ConvGRU convs: three products {errs['three']:.2e}, two {errs['two']:.2e}, one {errs['one']:.2e}")
+    assert errs["three"] <= 4e-5 and errs["two"] <= 1e-3
+    assert errs["three"] < errs["two"] <= errs["one"] * 1.5 + 1e-5
+
+
 @pytest.mark.parametrize("precision", ["fp16", "bf16"])
 def test_single_step_intermediates_16bit(precision):
     """L = 1, three products everywhere: every raw conv output of the first ConvGRU step and of the U-Net against the
