@@ -1295,6 +1295,206 @@ __global__ void k_pick_last(SelState* __restrict__ st, unsigned* __restrict__ hi
         cs[q].up_key = up_key;
     }
 }
+// ---- medians from a SAMPLED BRACKET (round 5): one pass over the stack instead of four ---------------------------------------------
+// The four radix-select passes above read the 2 x 183 MB of (reference, date) columns four times for 240 medians.  Here: (1) a systematic
+// sample of kMedS pixels per date gives, per problem, two keys [lo, hi] that bracket the median's rank with 5 sigma of the sample quantile's
+// spread (k_med_sample / k_med_bracket: ~4 % of the rows fall inside); (2) ONE pass over the stack counts the keys below lo, collects the
+// keys inside the bracket (staged in LDS per workgroup, appended with one global atomic per workgroup and problem) and accumulates the
+// column moments exactly like k_hist_all<1>; (3) one workgroup per problem selects the order statistics k and k + 1 among the candidates in
+// LDS (k_med_final).  The result is the EXACT order statistic -- the same key the radix select finds -- because the rank bookkeeping
+// (below + position among the candidates) is exact; if the bracket misses (or a staging area overflows) that problem's workgroup falls
+// back to a radix select over the full column by itself.  TTC_MEDIAN_RADIX=1 runs the four-pass form, TTC_MEDIAN_FORCE_FALLBACK=1 empties
+// every bracket (tests: all three give identical keys).
+constexpr int kMedS = 16384;        // sample pixels per date
+constexpr int kMedCap = 24576;      // candidate keys per problem (k_med_final holds them in LDS: 96 KB)
+constexpr int kMedStage = 512;      // candidates one workgroup of the counting pass stages per problem
+struct MedBracket { unsigned lo, hi; };                 // lo > hi: no bracket
+struct MedCount { unsigned below, ncand, fail, fell_back; };
+
+__global__ __launch_bounds__(256) void k_med_sample(const float* __restrict__ ref_all, const float* __restrict__ tiles,
+                                                     const unsigned* __restrict__ vmask, int npix, unsigned* __restrict__ samp,
+                                                     int* __restrict__ nsamp) {
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int p = (int)((long long)j * npix / kMedS);
+    const bool valid = j < kMedS && ((vmask[p] >> i) & 1u);
+    const unsigned long long b = __ballot(valid);
+    if (!b) return;
+    int base = 0;
+    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&nsamp[i], __popcll(b));
+    base = __shfl(base, __ffsll((long long)b) - 1);
+    if (!valid) return;
+    const int slot = base + __popcll(b & ((1ull << lane) - 1ull));
+    const float* r = ref_all + ((long)i * npix + p) * 10;
+    const float* d = tiles + ((long)i * npix + p) * 10;
+#pragma unroll
+    for (int c2 = 0; c2 < 10; ++c2) {
+        samp[((long)(i * 20 + 2 * c2)) * kMedS + slot] = fkey(r[c2]);
+        samp[((long)(i * 20 + 2 * c2 + 1)) * kMedS + slot] = fkey(d[c2]);
+    }
+}
+// rank-th smallest (0-based) of the keys get(j), j < m, by a 256-thread workgroup: four 8-bit passes with an LDS histogram; h = 260 words
+template <class GET>
+__device__ unsigned block_select(GET get, int m, long long rank, unsigned* h) {
+    unsigned prefix = 0, mask = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        h[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < m; j += 256) {
+            unsigned k;
+            if (get(j, k) && (k & mask) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                  // lane l owns bins 4l .. 4l + 3 (k_sel_pick's scan)
+            unsigned c[4], mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = h[4 * lane + q]; mine += c[q]; }
+            unsigned incl = mine;
+            for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const long long excl = (long long)incl - mine;
+            const bool here = rank >= excl && rank < (long long)incl;
+            const unsigned long long mm = __ballot(here);
+            const int owner = mm ? __ffsll((long long)mm) - 1 : 63;
+            if (lane == owner) {
+                long long r = rank - excl;
+                int b = 0;
+                for (; b < 3; ++b) { if (r < (long long)c[b]) break; r -= c[b]; }
+                h[256] = (unsigned)(4 * lane + b);
+                h[257] = (unsigned)(mm ? r : 0);
+            }
+        }
+        __syncthreads();
+        prefix |= h[256] << shift; mask |= 255u << shift; rank = (long long)h[257];
+        __syncthreads();
+    }
+    return prefix;
+}
+__global__ __launch_bounds__(256) void k_med_bracket(const unsigned* __restrict__ samp, const int* __restrict__ nsamp,
+                                                      const int* __restrict__ count, MedBracket* __restrict__ br, int force_fail) {
+    __shared__ unsigned h[260];
+    const int q = blockIdx.x, i = q / 20;
+    const int m = min(nsamp[i], kMedS), n = count[i];
+    MedBracket out{0u, 0xffffffffu};                        // no usable sample: every key is a candidate (fits when n is small)
+    if (force_fail) { out.lo = 1u; out.hi = 0u; }
+    else if (m > 0 && n > 0) {
+        const unsigned* keys = samp + (long)q * kMedS;
+        auto get = [&](int j, unsigned& k) { k = keys[j]; return true; };
+        const double k0 = (double)((n - 1) / 2);
+        const double pos = (k0 + 0.5) * (double)m / (double)n, delta = 2.5 * sqrt((double)m) + 2.0;
+        const long long rlo = (long long)floor(pos - delta), rhi = (long long)ceil(pos + delta) + 1;
+        if (rlo >= 0) out.lo = block_select(get, m, rlo, h);
+        if (rhi < m) out.hi = block_select(get, m, rhi, h);
+    }
+    if (threadIdx.x == 0) br[q] = out;
+}
+__global__ __launch_bounds__(256) void k_med_count(const float* __restrict__ ref_all, const float* __restrict__ tiles,
+                                                    const unsigned* __restrict__ vmask, int npix, const MedBracket* __restrict__ br,
+                                                    MedCount* __restrict__ mc, unsigned* __restrict__ cand, ColStat* __restrict__ cs) {
+    __shared__ unsigned stage[20 * kMedStage];
+    __shared__ unsigned lo[20], hi[20], scnt[20], sbelow[20], sbase[20];
+    __shared__ double ssum[20], ssq[20];
+    const int i = blockIdx.y;
+    if (threadIdx.x < 20) {
+        const MedBracket b = br[i * 20 + threadIdx.x];
+        lo[threadIdx.x] = b.lo; hi[threadIdx.x] = b.hi; scnt[threadIdx.x] = 0; sbelow[threadIdx.x] = 0;
+        ssum[threadIdx.x] = 0.0; ssq[threadIdx.x] = 0.0;
+    }
+    __syncthreads();
+    unsigned below[20];
+    double a1[20], a2[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) { below[q] = 0; a1[q] = 0.0; a2[q] = 0.0; }
+    const int stride = gridDim.x * blockDim.x;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
+        if (!((vmask[p] >> i) & 1u)) continue;
+        const float2* r = reinterpret_cast<const float2*>(ref_all + ((long)i * npix + p) * 10);
+        const float2* sv = reinterpret_cast<const float2*>(tiles + ((long)i * npix + p) * 10);
+#pragma unroll
+        for (int c2 = 0; c2 < 5; ++c2) {
+            const float2 a = r[c2], b = sv[c2];
+            const float v[4] = {a.x, b.x, a.y, b.y};         // problems 4*c2 .. 4*c2 + 3, as in k_hist_all
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = 4 * c2 + j;
+                a1[q] += (double)v[j]; a2[q] += (double)v[j] * (double)v[j];
+                const unsigned k = fkey(v[j]);
+                if (k < lo[q]) { below[q]++; continue; }
+                if (k > hi[q]) continue;
+                const unsigned slot = atomicAdd(&scnt[q], 1u);
+                if (slot < (unsigned)kMedStage) stage[q * kMedStage + slot] = k;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 20; ++q) {
+        for (int k = 32; k >= 1; k >>= 1) {
+            a1[q] += __shfl_xor(a1[q], k); a2[q] += __shfl_xor(a2[q], k);
+            below[q] += (unsigned)__shfl_xor((int)below[q], k);
+        }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&ssum[q], a1[q]); atomicAdd(&ssq[q], a2[q]); if (below[q]) atomicAdd(&sbelow[q], below[q]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 20) {
+        const int q = threadIdx.x;
+        MedCount* m = mc + i * 20 + q;
+        atomicAdd(&cs[i * 20 + q].sum, ssum[q]); atomicAdd(&cs[i * 20 + q].sq, ssq[q]);
+        if (sbelow[q]) atomicAdd(&m->below, sbelow[q]);
+        unsigned c = scnt[q];
+        if (c > (unsigned)kMedStage) { atomicOr(&m->fail, 1u); c = kMedStage; }
+        sbase[q] = c ? atomicAdd(&m->ncand, c) : 0u;
+        if (c && sbase[q] + c > (unsigned)kMedCap) atomicOr(&m->fail, 1u);
+        scnt[q] = c;
+    }
+    __syncthreads();
+    for (int q = 0; q < 20; ++q) {
+        const unsigned c = scnt[q], base = sbase[q];
+        unsigned* dst = cand + (long)(i * 20 + q) * kMedCap;
+        for (unsigned j = threadIdx.x; j < c; j += blockDim.x)
+            if (base + j < (unsigned)kMedCap) dst[base + j] = stage[q * kMedStage + j];
+    }
+}
+__global__ __launch_bounds__(256) void k_med_final(const unsigned* __restrict__ cand, MedCount* __restrict__ mc, const MedBracket* __restrict__ br,
+                                                    const int* __restrict__ count, const float* __restrict__ ref_all,
+                                                    const float* __restrict__ tiles, const unsigned* __restrict__ vmask, int npix,
+                                                    SelState* __restrict__ st, ColStat* __restrict__ cs) {
+    extern __shared__ unsigned med_lds[];                  // [kMedCap] candidates + 260 words of histogram
+    unsigned* keys = med_lds;
+    unsigned* h = med_lds + kMedCap;
+    const int q = blockIdx.x, i = q / 20;
+    const int n = count[i];
+    const MedCount m = mc[q];
+    const MedBracket b = br[q];
+    const long long k = n > 0 ? (n - 1) / 2 : 0;
+    const bool need_up = n > 0 && (n & 1) == 0;            // k_params_all reads the successor only for an even count
+    const long long r = k - (long long)m.below;
+    const int c = (int)min(m.ncand, (unsigned)kMedCap);
+    const bool ok = n > 0 && !m.fail && b.lo <= b.hi && m.ncand <= (unsigned)kMedCap && r >= 0 && r + (need_up ? 1 : 0) < (long long)c;
+    unsigned med = 0, up = 0;
+    if (ok) {
+        for (int j = threadIdx.x; j < c; j += blockDim.x) keys[j] = cand[(long)q * kMedCap + j];
+        __syncthreads();
+        auto get = [&](int j, unsigned& kk) { kk = keys[j]; return true; };
+        med = block_select(get, c, r, h);
+        up = need_up ? block_select(get, c, r + 1, h) : med;
+    } else if (n > 0) {                                    // the bracket missed (or overflowed): radix select over the full column
+        const int which = q & 1, band = (q % 20) >> 1;
+        const float* col = (which ? tiles : ref_all) + (long)i * npix * 10 + band;
+        auto get = [&](int p, unsigned& kk) {
+            if (!((vmask[p] >> i) & 1u)) return false;
+            kk = fkey(col[(long)p * 10]);
+            return true;
+        };
+        // ranks count VALID rows only: block_select skips the rows get() rejects
+        med = block_select(get, npix, k, h);
+        up = need_up ? block_select(get, npix, k + 1, h) : med;
+        if (threadIdx.x == 0) mc[q].fell_back = 1u;
+    }
+    if (threadIdx.x == 0) {
+        SelState ss; ss.prefix = med; ss.mask = 0xffffffffu; ss.k = 0;
+        st[q] = ss;
+        cs[q].up_key = up;
+    }
+}
 __global__ void k_params_all(const SelState* __restrict__ st, const ColStat* __restrict__ cs, const int* __restrict__ count,
                              const int* __restrict__ n_land, int T, AlignPar* __restrict__ out) {
     const int i = threadIdx.x;
@@ -1388,7 +1588,7 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     unsigned* vmask = static_cast<unsigned*>(c->scratch_buf("gf_vmask", sizeof(unsigned) * (size_t)npix));
     float* divisor = static_cast<float*>(c->scratch_buf("gf_div", sizeof(float) * (size_t)npix));
     const size_t ctl_bytes = 8192 + sizeof(SelState) * kMaxT * 20 + sizeof(ColStat) * kMaxT * 20 + sizeof(AlignPar) * kMaxT +
-                             sizeof(unsigned) * kMaxT * 20 * 256;
+                             sizeof(unsigned) * kMaxT * 20 * 256 + sizeof(int) * kMaxT + (sizeof(MedBracket) + sizeof(MedCount)) * kMaxT * 20;
     char* ctl = static_cast<char*>(c->scratch_buf("gf_ctl_all", ctl_bytes));
     if (!water || !ref_all || !vmask || !divisor || !ctl) return c->fail(TTC_ERR_NOMEM, "aligned_mosaic scratch");
     int* count = reinterpret_cast<int*>(ctl);                              // [kMaxT] valid rows per date, [kMaxT] = n_land
@@ -1396,6 +1596,12 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     ColStat* cs = reinterpret_cast<ColStat*>(st + kMaxT * 20);
     AlignPar* ap = reinterpret_cast<AlignPar*>(cs + kMaxT * 20);
     unsigned* hist = reinterpret_cast<unsigned*>(ap + kMaxT);
+    int* nsamp = reinterpret_cast<int*>(hist + kMaxT * 20 * 256);
+    MedBracket* br = reinterpret_cast<MedBracket*>(nsamp + kMaxT);
+    MedCount* mc = reinterpret_cast<MedCount*>(br + kMaxT * 20);
+    // read per call (two getenv's per tile): the parity tests switch the three forms inside one process
+    const bool med_radix = [] { const char* e = getenv("TTC_MEDIAN_RADIX"); return e && atoi(e) != 0; }();
+    const int med_force = [] { const char* e = getenv("TTC_MEDIAN_FORCE_FALLBACK"); return e ? atoi(e) : 0; }();
     {
         KTimer kt(c, "aligned_mosaic", s);
         TTC_CHECK(water_mask(c, d_tiles, T, X, Y, false, true, water, s));
@@ -1406,6 +1612,21 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
         GF_T(k_ref_all, T, dim3(2048), blk, 0, s, d_tiles, d_w, water, T, npix, ref_all, vmask, count);
         hipLaunchKernelGGL(k_sel_init_dates, dim3((T * 20 + 63) / 64), dim3(64), 0, s, st, count, T);
         hipLaunchKernelGGL(k_stat_init, dim3(1), dim3(kMaxT * 20), 0, s, cs);
+        if (!med_radix) {
+            // medians from a sampled bracket: one pass over the stack (see k_med_sample .. k_med_final)
+            unsigned* samp = static_cast<unsigned*>(c->scratch_buf("gf_med_samp", sizeof(unsigned) * (size_t)T * 20 * kMedS));
+            unsigned* cand = static_cast<unsigned*>(c->scratch_buf("gf_med_cand", sizeof(unsigned) * (size_t)T * 20 * kMedCap));
+            if (!samp || !cand) return c->fail(TTC_ERR_NOMEM, "aligned_mosaic scratch");
+            const size_t lds = sizeof(unsigned) * (kMedCap + 260);
+            TTC_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_med_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_med_sample, dim3(kMedS / 256, T), blk, 0, s, ref_all, d_tiles, vmask, npix, samp, nsamp);
+            hipLaunchKernelGGL(k_med_bracket, dim3(T * 20), blk, 0, s, samp, nsamp, count, br, med_force);
+            hipLaunchKernelGGL(k_med_count, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, br, mc, cand, cs);
+            hipLaunchKernelGGL(k_med_final, dim3(T * 20), blk, lds, s, cand, mc, br, count, ref_all, d_tiles, vmask, npix, st, cs);
+            hipLaunchKernelGGL(k_params_all, dim3(1), dim3(64), 0, s, st, cs, count, count + kMaxT, T, ap);
+            TTC_HIP(c, hipGetLastError());
+            c->named["gf_med_counts"] = {reinterpret_cast<float*>(mc), (size_t)T * 20 * 4};      // tests: candidates / fallbacks per problem
+        } else {
         // 128 x T workgroups: measured 64 / 128 / 256 / 512 -> 3.58 / 3.47 / 3.51 / 3.66 ms per tile for the whole preprocessing chain
         hipLaunchKernelGGL(k_hist_all<1>, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, st, 24, hist, cs);      // + the moments
         hipLaunchKernelGGL(k_sel_pick, dim3(T * 20), dim3(64), 0, s, st, 24, hist);
@@ -1417,6 +1638,7 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
         hipLaunchKernelGGL(k_pick_last, dim3(T * 20), dim3(64), 0, s, st, hist, cs);
         hipLaunchKernelGGL(k_params_all, dim3(1), dim3(64), 0, s, st, cs, count, count + kMaxT, T, ap);
         TTC_HIP(c, hipGetLastError());
+        }
     }
     // the one host decision: a date with <= 1000 usable rows on a tile that has land marks itself fully interpolated
     // and thereby changes every later date (CR.py:679-680) -> redo date by date.  T small ints, one stream wait.

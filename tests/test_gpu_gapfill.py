@@ -65,6 +65,32 @@ def test_aligned_mosaic_matches_reference(sess):
     assert np.abs(mos2 - ref).max() < 2e-6
 
 
+@pytest.mark.parametrize("seed,T,H,W", [(3, 5, 120, 112), (1234, 12, 618, 618), (77, 3, 64, 70)])
+def test_sampled_bracket_medians_equal_radix_select(sess, monkeypatch, seed, T, H, W):
+    """The aligned mosaic's 20 x T medians come from a sampled bracket + ONE counting pass (gapfill.hip: k_med_*); the four-pass radix select
+    (TTC_MEDIAN_RADIX=1) and the per-problem fallback (TTC_MEDIAN_FORCE_FALLBACK=1: every bracket empty) must give the SAME mosaic bit for
+    bit -- the selected order statistics are identical keys, everything downstream is the same code."""
+    import torch
+    tiles, dates, probs, pf = synth.synth_gapfill_scene(seed, T, H, W)
+    td = torch.from_numpy(tiles).cuda()
+    out = {}
+    for name, env in (("bracket", {}), ("radix", {"TTC_MEDIAN_RADIX": "1"}), ("fallback", {"TTC_MEDIAN_FORCE_FALLBACK": "1"})):
+        for k in ("TTC_MEDIAN_RADIX", "TTC_MEDIAN_FORCE_FALLBACK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        w = sess.ctx.feather(probs, closing=20)
+        out[name] = sess.ctx.aligned_mosaic(td, w).cpu().numpy()
+        if name != "radix":
+            mc = sess.ctx.debug_fetch("gf_med_counts", (T * 20, 4)).view(np.uint32)
+            print(f"[parity] medians {name} {T}x{H}x{W}: candidates per problem max {mc[:, 1].max()}, below max {mc[:, 0].max()}, "
+                  f"staging overflows {int(mc[:, 2].sum())}, problems that fell back {int(mc[:, 3].sum())} of {T * 20}")
+            # forced: every problem with valid rows selects over the full column; default: no miss, no staging overflow on these scenes
+            assert (mc[:, 3].sum() >= 0.5 * T * 20) if name == "fallback" else (mc[:, 3].sum() == 0 and mc[:, 2].sum() == 0)
+    np.testing.assert_array_equal(out["bracket"], out["radix"])
+    np.testing.assert_array_equal(out["fallback"], out["radix"])
+
+
 def test_remove_cloud_and_shadows_reference_replay(sess):
     """stdlib RNG replayed on the host through the sampler callback: same sample as the reference."""
     from ttc import job
