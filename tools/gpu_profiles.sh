@@ -3,7 +3,7 @@
 # Kernel-stats runs use --inflight 1 --no-dprob --no-alt --no-cpu-baseline so that a kernel's average is not a mix of live
 # (two tiles in flight), isolated, warm-up and 3-window parity launches.  PMC passes are their own runs (--kernel-trace --pmc only).
 # ONLY=<section>[,<section>] restricts the run to stats | pmc_f32 | pmc_h16 | pmc_pre | bench.
-TAG=${1:-r05_a}
+TAG=${1:-r05_d}
 want() { [ -z "$ONLY" ] || [[ ",$ONLY," == *",$1,"* ]]; }
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -36,7 +36,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
     want pmc_h16 && pmc $O/${TAG}_pmc_h16_gates.txt "conv3x3_h16<0, 3, 2, 0, 1|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-    want pmc_pre && pmc $O/${TAG}_pmc_preprocess.txt "k_hist_all|k_tile_temporal|k_stat_all|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
+    want pmc_pre && pmc $O/${TAG}_pmc_preprocess.txt "k_med_count|k_med_final|k_med_bracket|k_med_sample|k_tile_temporal|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all|k_decode_upsample" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
 done
 want bench || exit 0
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
