@@ -1301,12 +1301,12 @@ __global__ void k_pick_last(SelState* __restrict__ st, unsigned* __restrict__ hi
 // spread (k_med_sample / k_med_bracket: ~4 % of the rows fall inside); (2) ONE pass over the stack counts the keys below lo, collects the
 // keys inside the bracket (staged in LDS per workgroup, appended with one global atomic per workgroup and problem) and accumulates the
 // column moments exactly like k_hist_all<1>; (3) one workgroup per problem selects the order statistics k and k + 1 among the candidates in
-// LDS (k_med_final).  The result is the EXACT order statistic -- the same key the radix select finds -- because the rank bookkeeping
+// registers (k_med_final).  The result is the EXACT order statistic -- the same key the radix select finds -- because the rank bookkeeping
 // (below + position among the candidates) is exact; if the bracket misses (or a staging area overflows) that problem's workgroup falls
 // back to a radix select over the full column by itself.  TTC_MEDIAN_RADIX=1 runs the four-pass form, TTC_MEDIAN_FORCE_FALLBACK=1 empties
 // every bracket (tests: all three give identical keys).
 constexpr int kMedS = 16384;        // sample pixels per date
-constexpr int kMedCap = 24576;      // candidate keys per problem (k_med_final holds them in LDS: 96 KB)
+constexpr int kMedCap = 24576;      // candidate keys per problem (k_med_final holds them in registers: 96 per thread)
 constexpr int kMedStage = 512;      // candidates one workgroup of the counting pass stages per problem
 struct MedBracket { unsigned lo, hi; };                 // lo > hi: no bracket
 struct MedCount { unsigned below, ncand, fail, fell_back; };
@@ -1314,22 +1314,31 @@ struct MedCount { unsigned below, ncand, fail, fell_back; };
 __global__ __launch_bounds__(256) void k_med_sample(const float* __restrict__ ref_all, const float* __restrict__ tiles,
                                                      const unsigned* __restrict__ vmask, int npix, unsigned* __restrict__ samp,
                                                      int* __restrict__ nsamp) {
+    __shared__ int spix[256];
+    __shared__ int sbase, scount;
     const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) scount = 0;
+    __syncthreads();
     const int p = (int)((long long)j * npix / kMedS);
     const bool valid = j < kMedS && ((vmask[p] >> i) & 1u);
     const unsigned long long b = __ballot(valid);
-    if (!b) return;
     int base = 0;
-    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&nsamp[i], __popcll(b));
-    base = __shfl(base, __ffsll((long long)b) - 1);
-    if (!valid) return;
-    const int slot = base + __popcll(b & ((1ull << lane) - 1ull));
-    const float* r = ref_all + ((long)i * npix + p) * 10;
-    const float* d = tiles + ((long)i * npix + p) * 10;
-#pragma unroll
-    for (int c2 = 0; c2 < 10; ++c2) {
-        samp[((long)(i * 20 + 2 * c2)) * kMedS + slot] = fkey(r[c2]);
-        samp[((long)(i * 20 + 2 * c2 + 1)) * kMedS + slot] = fkey(d[c2]);
+    if (b && lane == __ffsll((long long)b) - 1) base = atomicAdd(&scount, __popcll(b));      // order inside the sample does not matter
+    base = __shfl(base, b ? __ffsll((long long)b) - 1 : 0);
+    if (valid) spix[base + __popcll(b & ((1ull << lane) - 1ull))] = p;
+    __syncthreads();
+    const int n = scount;
+    if (threadIdx.x == 0 && n) sbase = atomicAdd(&nsamp[i], n);
+    __syncthreads();
+    // five lanes per sampled pixel: lane c2 reads the float2 of bands (2 c2, 2 c2 + 1) of the reference and of the date (40 contiguous
+    // bytes per pixel and array), and writes four keys
+    for (int w = threadIdx.x; w < n * 5; w += blockDim.x) {
+        const int e = w / 5, c2 = w - e * 5;
+        const int slot = sbase + e, pp = spix[e];
+        const float2 r = reinterpret_cast<const float2*>(ref_all + ((long)i * npix + pp) * 10)[c2];
+        const float2 d = reinterpret_cast<const float2*>(tiles + ((long)i * npix + pp) * 10)[c2];
+        unsigned* o = samp + ((long)(i * 20 + 4 * c2)) * kMedS + slot;
+        o[0] = fkey(r.x); o[kMedS] = fkey(d.x); o[2 * kMedS] = fkey(r.y); o[3 * kMedS] = fkey(d.y);
     }
 }
 // rank-th smallest (0-based) of the keys get(j), j < m, by a 256-thread workgroup: four 8-bit passes with an LDS histogram; h = 260 words
@@ -1340,12 +1349,67 @@ __device__ unsigned block_select(GET get, int m, long long rank, unsigned* h) {
     for (int shift = 24; shift >= 0; shift -= 8) {
         h[tid] = 0;
         __syncthreads();
+        // a lane aggregates its own consecutive hits of one bin (k_hist_all's device): keys of one column share their high bytes, so on the
+        // high passes every hit lands in a handful of bins (one LDS address per wave instruction otherwise), on the low ones few keys match
+        int cur = -1;
+        unsigned cnt = 0;
         for (int j = tid; j < m; j += 256) {
             unsigned k;
-            if (get(j, k) && (k & mask) == prefix) atomicAdd(&h[(k >> shift) & 255u], 1u);
+            if (!get(j, k) || (k & mask) != prefix) continue;
+            const int bin = (int)((k >> shift) & 255u);
+            if (bin == cur) { ++cnt; continue; }
+            if (cnt) atomicAdd(&h[cur], cnt);
+            cur = bin; cnt = 1;
         }
+        if (cnt) atomicAdd(&h[cur], cnt);
         __syncthreads();
         if (tid < 64) {                                  // lane l owns bins 4l .. 4l + 3 (k_sel_pick's scan)
+            unsigned c[4], mine = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = h[4 * lane + q]; mine += c[q]; }
+            unsigned incl = mine;
+            for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const long long excl = (long long)incl - mine;
+            const bool here = rank >= excl && rank < (long long)incl;
+            const unsigned long long mm = __ballot(here);
+            const int owner = mm ? __ffsll((long long)mm) - 1 : 63;
+            if (lane == owner) {
+                long long r = rank - excl;
+                int b = 0;
+                for (; b < 3; ++b) { if (r < (long long)c[b]) break; r -= c[b]; }
+                h[256] = (unsigned)(4 * lane + b);
+                h[257] = (unsigned)(mm ? r : 0);
+            }
+        }
+        __syncthreads();
+        prefix |= h[256] << shift; mask |= 255u << shift; rank = (long long)h[257];
+        __syncthreads();
+    }
+    return prefix;
+}
+// the same select over keys the workgroup holds in REGISTERS (thread t owns keys t, t + 256, ...: NPER per thread, m in total): the eight
+// passes of two selects then touch no memory but the LDS histogram (from L2 / LDS each pass re-waited the load latency: 83-96 us per launch)
+template <int NPER>
+__device__ unsigned block_select_reg(const unsigned (&key)[NPER], int m, long long rank, unsigned* h) {
+    unsigned prefix = 0, mask = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        h[tid] = 0;
+        __syncthreads();
+        int cur = -1;
+        unsigned cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) {
+            const unsigned k = key[u];
+            if (u * 256 + tid >= m || (k & mask) != prefix) continue;
+            const int bin = (int)((k >> shift) & 255u);
+            if (bin == cur) { ++cnt; continue; }
+            if (cnt) atomicAdd(&h[cur], cnt);
+            cur = bin; cnt = 1;
+        }
+        if (cnt) atomicAdd(&h[cur], cnt);
+        __syncthreads();
+        if (tid < 64) {
             unsigned c[4], mine = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { c[q] = h[4 * lane + q]; mine += c[q]; }
@@ -1378,12 +1442,14 @@ __global__ __launch_bounds__(256) void k_med_bracket(const unsigned* __restrict_
     if (force_fail) { out.lo = 1u; out.hi = 0u; }
     else if (m > 0 && n > 0) {
         const unsigned* keys = samp + (long)q * kMedS;
-        auto get = [&](int j, unsigned& k) { k = keys[j]; return true; };
+        unsigned key[kMedS / 256];
+#pragma unroll
+        for (int u = 0; u < kMedS / 256; ++u) key[u] = (u * 256 + (int)threadIdx.x < m) ? keys[u * 256 + threadIdx.x] : 0u;
         const double k0 = (double)((n - 1) / 2);
         const double pos = (k0 + 0.5) * (double)m / (double)n, delta = 2.5 * sqrt((double)m) + 2.0;
         const long long rlo = (long long)floor(pos - delta), rhi = (long long)ceil(pos + delta) + 1;
-        if (rlo >= 0) out.lo = block_select(get, m, rlo, h);
-        if (rhi < m) out.hi = block_select(get, m, rhi, h);
+        if (rlo >= 0) out.lo = block_select_reg(key, m, rlo, h);
+        if (rhi < m) out.hi = block_select_reg(key, m, rhi, h);
     }
     if (threadIdx.x == 0) br[q] = out;
 }
@@ -1404,6 +1470,8 @@ __global__ __launch_bounds__(256) void k_med_count(const float* __restrict__ ref
     double a1[20], a2[20];
 #pragma unroll
     for (int q = 0; q < 20; ++q) { below[q] = 0; a1[q] = 0.0; a2[q] = 0.0; }
+    // (an LDS-staged loader -- the workgroup copies its 256 consecutive 40-byte records with coalesced loads, lanes read them from LDS --
+    // measured SLOWER here: 282 vs 196 us; 60 KB of LDS per workgroup leaves two workgroups per CU and nothing to hide the copy's latency)
     const int stride = gridDim.x * blockDim.x;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
         if (!((vmask[p] >> i) & 1u)) continue;
@@ -1457,9 +1525,7 @@ __global__ __launch_bounds__(256) void k_med_final(const unsigned* __restrict__ 
                                                     const int* __restrict__ count, const float* __restrict__ ref_all,
                                                     const float* __restrict__ tiles, const unsigned* __restrict__ vmask, int npix,
                                                     SelState* __restrict__ st, ColStat* __restrict__ cs) {
-    extern __shared__ unsigned med_lds[];                  // [kMedCap] candidates + 260 words of histogram
-    unsigned* keys = med_lds;
-    unsigned* h = med_lds + kMedCap;
+    __shared__ unsigned h[260];
     const int q = blockIdx.x, i = q / 20;
     const int n = count[i];
     const MedCount m = mc[q];
@@ -1471,11 +1537,11 @@ __global__ __launch_bounds__(256) void k_med_final(const unsigned* __restrict__ 
     const bool ok = n > 0 && !m.fail && b.lo <= b.hi && m.ncand <= (unsigned)kMedCap && r >= 0 && r + (need_up ? 1 : 0) < (long long)c;
     unsigned med = 0, up = 0;
     if (ok) {
-        for (int j = threadIdx.x; j < c; j += blockDim.x) keys[j] = cand[(long)q * kMedCap + j];
-        __syncthreads();
-        auto get = [&](int j, unsigned& kk) { kk = keys[j]; return true; };
-        med = block_select(get, c, r, h);
-        up = need_up ? block_select(get, c, r + 1, h) : med;
+        unsigned key[kMedCap / 256];                        // 96 candidates per thread, in registers
+#pragma unroll
+        for (int u = 0; u < kMedCap / 256; ++u) key[u] = (u * 256 + (int)threadIdx.x < c) ? cand[(long)q * kMedCap + u * 256 + threadIdx.x] : 0u;
+        med = block_select_reg(key, c, r, h);
+        up = need_up ? block_select_reg(key, c, r + 1, h) : med;
     } else if (n > 0) {                                    // the bracket missed (or overflowed): radix select over the full column
         const int which = q & 1, band = (q % 20) >> 1;
         const float* col = (which ? tiles : ref_all) + (long)i * npix * 10 + band;
@@ -1617,12 +1683,10 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
             unsigned* samp = static_cast<unsigned*>(c->scratch_buf("gf_med_samp", sizeof(unsigned) * (size_t)T * 20 * kMedS));
             unsigned* cand = static_cast<unsigned*>(c->scratch_buf("gf_med_cand", sizeof(unsigned) * (size_t)T * 20 * kMedCap));
             if (!samp || !cand) return c->fail(TTC_ERR_NOMEM, "aligned_mosaic scratch");
-            const size_t lds = sizeof(unsigned) * (kMedCap + 260);
-            TTC_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_med_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_med_sample, dim3(kMedS / 256, T), blk, 0, s, ref_all, d_tiles, vmask, npix, samp, nsamp);
             hipLaunchKernelGGL(k_med_bracket, dim3(T * 20), blk, 0, s, samp, nsamp, count, br, med_force);
             hipLaunchKernelGGL(k_med_count, dim3(128, T), blk, 0, s, ref_all, d_tiles, vmask, npix, br, mc, cand, cs);
-            hipLaunchKernelGGL(k_med_final, dim3(T * 20), blk, lds, s, cand, mc, br, count, ref_all, d_tiles, vmask, npix, st, cs);
+            hipLaunchKernelGGL(k_med_final, dim3(T * 20), blk, 0, s, cand, mc, br, count, ref_all, d_tiles, vmask, npix, st, cs);
             hipLaunchKernelGGL(k_params_all, dim3(1), dim3(64), 0, s, st, cs, count, count + kMaxT, T, ap);
             TTC_HIP(c, hipGetLastError());
             c->named["gf_med_counts"] = {reinterpret_cast<float*>(mc), (size_t)T * 20 * 4};      // tests: candidates / fallbacks per problem
