@@ -1117,39 +1117,41 @@ template <int TM>
 __global__ void k_ref_all(const float* __restrict__ tiles, const float* __restrict__ w, const unsigned char* __restrict__ water,
                           int T, int npix, float* __restrict__ ref_all, unsigned* __restrict__ vmask, int* __restrict__ count) {
 #pragma clang fp contract(off)
+    // thread = the float2 of two neighbouring bands of one pixel (round 5; one float per thread before: twice the load / store instructions)
     __shared__ int cnt[TM];
     if (threadIdx.x < TM) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const long total = (long)npix * 10;
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id - threadIdx.x < total; id += (long)gridDim.x * blockDim.x) {
+    const long total2 = (long)npix * 5;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id - threadIdx.x < total2; id += (long)gridDim.x * blockDim.x) {
         unsigned mask = 0;
-        const bool live = id < total;
-        const int p = live ? (int)(id / 10) : 0;
-        const int ch = (int)(id - (long)p * 10);
+        const bool live = id < total2;
+        const int p = live ? (int)(id / 5) : 0;
+        const int c2 = (int)(id - (long)p * 5);
         if (live) {
-            float wv[TM], v[TM];
+            float wv[TM];
+            float2 v[TM];
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 wv[t] = t < T ? w[(long)t * npix + p] : 1.0f;
-                v[t] = t < T ? tiles[(long)t * total + id] : 0.0f;
+                v[t] = t < T ? reinterpret_cast<const float2*>(tiles + (long)t * npix * 10)[id] : float2{0.0f, 0.0f};
             }
             if (!water[p]) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     if (i < T && wv[i] < 0.25f) {
-                        float sum = 0.f;
+                        float2 sum = {0.f, 0.f};
                         int n = 0;
 #pragma unroll
                         for (int b = 0; b < TM; ++b)
-                            if (b < T && b != i && wv[b] < 1.0f) { sum += v[b]; ++n; }
-                        if (n > 0) { mask |= 1u << i; ref_all[(long)i * total + id] = sum / (float)n; }
+                            if (b < T && b != i && wv[b] < 1.0f) { sum.x += v[b].x; sum.y += v[b].y; ++n; }
+                        if (n > 0) { mask |= 1u << i; reinterpret_cast<float2*>(ref_all + (long)i * npix * 10)[id] = float2{sum.x / (float)n, sum.y / (float)n}; }
                     }
                 }
             }
-            if (ch == 0) vmask[p] = mask;
+            if (c2 == 0) vmask[p] = mask;
         }
         for (int i = 0; i < T; ++i) {
-            const int k = __popcll(__ballot(live && ch == 0 && ((mask >> i) & 1u)));
+            const int k = __popcll(__ballot(live && c2 == 0 && ((mask >> i) & 1u)));
             if ((threadIdx.x & 63) == 0 && k) atomicAdd(&cnt[i], k);
         }
     }
@@ -1472,6 +1474,10 @@ __global__ __launch_bounds__(256) void k_med_count(const float* __restrict__ ref
     for (int q = 0; q < 20; ++q) { below[q] = 0; a1[q] = 0.0; a2[q] = 0.0; }
     // (an LDS-staged loader -- the workgroup copies its 256 consecutive 40-byte records with coalesced loads, lanes read them from LDS --
     // measured SLOWER here: 282 vs 196 us; 60 KB of LDS per workgroup leaves two workgroups per CU and nothing to hide the copy's latency)
+    // the 20 brackets are workgroup-uniform: read through a uniform pointer they live in SGPRs (from LDS: 40 ds_reads per pixel)
+    MedBracket bq[20];
+#pragma unroll
+    for (int q = 0; q < 20; ++q) bq[q] = br[i * 20 + q];
     const int stride = gridDim.x * blockDim.x;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += stride) {
         if (!((vmask[p] >> i) & 1u)) continue;
@@ -1486,8 +1492,8 @@ __global__ __launch_bounds__(256) void k_med_count(const float* __restrict__ ref
                 const int q = 4 * c2 + j;
                 a1[q] += (double)v[j]; a2[q] += (double)v[j] * (double)v[j];
                 const unsigned k = fkey(v[j]);
-                if (k < lo[q]) { below[q]++; continue; }
-                if (k > hi[q]) continue;
+                if (k < bq[q].lo) { below[q]++; continue; }
+                if (k > bq[q].hi) continue;
                 const unsigned slot = atomicAdd(&scnt[q], 1u);
                 if (slot < (unsigned)kMedStage) stage[q * kMedStage + slot] = k;
             }
@@ -1594,42 +1600,62 @@ __global__ void k_accum_final_all(const float* __restrict__ tiles, const float* 
                                   const AlignPar* __restrict__ ap, const float* __restrict__ divisor, int T, int npix,
                                   float* __restrict__ mosaic) {
 #pragma clang fp contract(off)
-    const long total = (long)npix * 10;
-    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= total) return;
-    const int p = (int)(id / 10), ch = (int)(id - (long)p * 10);
+    // thread = the float2 of two neighbouring bands of one pixel (10 bands: a pair never straddles pixels): 8-byte loads and stores.
+    // The per-date alignment parameters come from LDS: read straight from `ap` they were four more vector loads per date and thread.
+    __shared__ float2 sk[TM * 5], sadd[TM * 5];
+    __shared__ int sok[TM];
+    for (int e = threadIdx.x; e < T * 5; e += blockDim.x) {
+        const int t = e / 5, c = 2 * (e - t * 5);
+        sk[e] = float2{ap[t].k[c], ap[t].k[c + 1]}; sadd[e] = float2{ap[t].add[c], ap[t].add[c + 1]};
+        if (c == 0) sok[t] = ap[t].ok ? 1 : 0;
+    }
+    __syncthreads();
+    const long total2 = (long)npix * 5;
+    const long id2 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id2 >= total2) return;
+    const int p = (int)(id2 / 5), ch = 2 * (int)(id2 - (long)p * 5);
     const bool land = !water[p];
-    float v[TM];
-    float m = 0.f, mn = INFINITY, mx = -INFINITY;
+    float2 v[TM];
+    float2 m = {0.f, 0.f}, mn = {INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        v[t] = INFINITY;
+        v[t] = float2{INFINITY, INFINITY};
         if (t < T) {
-            v[t] = tiles[(long)t * total + id];
-            mn = fminf(mn, v[t]); mx = fmaxf(mx, v[t]);
-            if (ap[t].ok) {
+            v[t] = reinterpret_cast<const float2*>(tiles + (long)t * npix * 10)[id2];
+            mn.x = fminf(mn.x, v[t].x); mx.x = fmaxf(mx.x, v[t].x);
+            mn.y = fminf(mn.y, v[t].y); mx.y = fmaxf(mx.y, v[t].y);
+            if (sok[t]) {
                 const float wi = 1.0f - w[(long)t * npix + p];
-                const float a = land ? v[t] * ap[t].k[ch] + ap[t].add[ch] : v[t];
-                m = m + wi * a;
+                const float2 kk = sk[t * 5 + (ch >> 1)], ad = sadd[t * 5 + (ch >> 1)];
+                const float a0 = land ? v[t].x * kk.x + ad.x : v[t].x;
+                const float a1 = land ? v[t].y * kk.y + ad.y : v[t].y;
+                m.x = m.x + wi * a0;
+                m.y = m.y + wi * a1;
             }
         }
     }
     float d = divisor[p];
     if (d < 0.f) d = 0.f;
-    m = m / d;
-    if (isnan(m)) {
-        bitonic_sort<TM>(v);
-        const double pos = 0.1 * (T - 1);
-        const int lo = (int)floor(pos);
-        float a = 0.f, b = 0.f;
+    float mm[2] = {m.x / d, m.y / d};
 #pragma unroll
-        for (int t = 0; t < TM; ++t) { if (t == lo) a = v[t]; if (t == lo + 1 && lo + 1 < T) b = v[t]; }
-        if (lo + 1 >= T) b = a;
-        m = (float)((double)a + ((double)b - (double)a) * (pos - lo));
+    for (int e = 0; e < 2; ++e) {
+        if (isnan(mm[e])) {
+            float vv[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) vv[t] = e ? v[t].y : v[t].x;
+            bitonic_sort<TM>(vv);
+            const double pos = 0.1 * (T - 1);
+            const int lo = (int)floor(pos);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) { if (t == lo) a = vv[t]; if (t == lo + 1 && lo + 1 < T) b = vv[t]; }
+            if (lo + 1 >= T) b = a;
+            mm[e] = (float)((double)a + ((double)b - (double)a) * (pos - lo));
+        }
     }
-    m = fmaxf(m, mn);
-    m = fminf(m, mx);
-    mosaic[id] = m;
+    mm[0] = fminf(fmaxf(mm[0], mn.x), mx.x);
+    mm[1] = fminf(fmaxf(mm[1], mn.y), mx.y);
+    reinterpret_cast<float2*>(mosaic)[id2] = float2{mm[0], mm[1]};
 }
 
 __global__ void k_count_flags(const int* __restrict__ flags, int T, int* __restrict__ out) {
@@ -1711,7 +1737,7 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     if (c->spec_status) {
         hipLaunchKernelGGL(k_redo_flag, dim3(1), dim3(64), 0, s, ap, T, c->spec_status);
         KTimer kt(c, "aligned_mosaic", s);
-        GF_T(k_accum_final_all, T, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_tiles, d_w, water, ap, divisor, T, npix, d_mosaic);
+        GF_T(k_accum_final_all, T, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, s, d_tiles, d_w, water, ap, divisor, T, npix, d_mosaic);
         TTC_HIP(c, hipGetLastError());
         return TTC_OK;
     }
@@ -1722,7 +1748,7 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     for (int i = 0; i < T; ++i) redo |= (!h_ap[i].ok && h_ap[i].any_land);
     if (redo) return aligned_mosaic_sequential(c, d_tiles, d_w, T, X, Y, d_mosaic, s);
     KTimer kt(c, "aligned_mosaic", s);
-    GF_T(k_accum_final_all, T, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_tiles, d_w, water, ap, divisor, T, npix, d_mosaic);
+    GF_T(k_accum_final_all, T, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, s, d_tiles, d_w, water, ap, divisor, T, npix, d_mosaic);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }
