@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rocprofv3 --kernel-trace --stats -d $O/prof_m -o m -- python $R/bench.py --preprocess-only --tiles 30 --inflight 1 --no-cpu-baseline > /dev/null 2>&1
 f=$(find $O/prof_m -name "*results.db" | head -1)
-cd $R && python tools/rocpd_stats.py $f | grep -E "minmax|edt|dil|mask_positive|feather" | cut -c1-70,100-175
+cd $R && python tools/rocpd_stats.py $f | grep -E "fix_missing|missing_counts" | cut -c1-70,100-175
 rm -rf $O/prof_m
