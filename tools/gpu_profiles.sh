@@ -3,7 +3,7 @@
 # Kernel-stats runs use --inflight 1 --no-dprob --no-alt --no-cpu-baseline so that a kernel's average is not a mix of live
 # (two tiles in flight), isolated, warm-up and 3-window parity launches.  PMC passes are their own runs (--kernel-trace --pmc only).
 # ONLY=<section>[,<section>] restricts the run to stats | pmc_f32 | pmc_h16 | pmc_pre | bench.
-TAG=${1:-r05_d}
+TAG=${1:-r05_e}
 want() { [ -z "$ONLY" ] || [[ ",$ONLY," == *",$1,"* ]]; }
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
