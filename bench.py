@@ -546,7 +546,8 @@ def main():
                 t0 = time.perf_counter()
                 coords = [(k % n_tiles, 0) for k in range(n_loop)]
                 gen = ((raw_k, (masks32[i % n_tiles % len(pool)] if with_mask else None))
-                       for i, raw_k in enumerate(job.iter_raw_tiles(coords, root, workers=args.job_readers, arena=arena)))
+                       for i, raw_k in enumerate(job.iter_raw_tiles(coords, root, workers=args.job_readers, arena=arena,
+                                                                     want_clouds=with_mask)))      # the detecting loop never reads the s2cloudless file
                 rs = job.predict_tiles(gen, sessions, size=size, want_status=True, timings=tmx, on_result=on_res, arena=arena)
                 torch.cuda.synchronize()
                 for w in wr:
@@ -562,6 +563,15 @@ def main():
             writer.shutdown()
         finally:
             shutil.rmtree(root, ignore_errors=True)
+        def host_cores():
+            """cores this process may use: the cgroup CPU quota when there is one (the GPU box's container: 16), else the affinity mask"""
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    return round(int(q) / int(per), 1)
+            except Exception:
+                pass
+            return len(os.sched_getaffinity(0))
         gpu_ms = stages["gpu_detect+predict_tile"] * 1e3
         host_ms = {k: v * 1e3 for k, v in stages.items() if k != "gpu_detect+predict_tile"}
         slowest = max(host_ms, key=host_ms.get)
@@ -573,10 +583,13 @@ def main():
                 "ms_per_stage_serial": {k: round(v * 1e3, 2) for k, v in stages.items()},
                 "host_seconds_in_loop": {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()},
                 "raw_bytes_on_disk_per_tile": disk // n_tiles, "pinned_arena_sets": 0 if arena is None else len(arena.sets), "read_threads": args.job_readers, "inflate_threads_per_read": int(os.environ.get("TTC_IO_THREADS", "8")), "sessions": len(sessions),
+                "host_cores_available": host_cores(),
                 "tiles_rerun_staged": int(sum(1 for r in res if r[3])),
                 "slowest_host_stage": {"name": slowest, "ms": round(host_ms[slowest], 2), "x_gpu_stage": round(host_ms[slowest] / gpu_ms, 2)},
                 "note": "job-level: files -> ttc_read_hkl -> pinned H2D -> detection + ttc_predict_tile -> D2H -> ttc_write_geotiff_u8; "
-                        "serial stage times are of tile 0 alone, the rate is the pipelined loop (job.iter_raw_tiles + job.predict_tiles)"}
+                        "serial stage times are of tile 0 alone, the rate is the pipelined loop (job.iter_raw_tiles + job.predict_tiles).  The reader side "
+                        "(inflating ~90 MB of deflate per tile, ~0.27 core-seconds) is bound by host_cores_available: 17 ms per tile on a 16-core quota "
+                        "whatever the thread counts (tools/probes/reader_probe.py); the detecting loop does not read the s2cloudless file it never uses"}
 
     sessions = make_sessions(args.precision)
     if args.job_level_only:

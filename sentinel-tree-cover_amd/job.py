@@ -353,12 +353,14 @@ def adjust_shape(arr, width, height):
     return arr.squeeze()
 
 
-def load_raw_tile(x, y, local_path, alloc=None):
+def load_raw_tile(x, y, local_path, alloc=None, want_clouds=True):
     """The file loads at the top of process_tile (job.py:669-714): the arrays of `{local_path}{x}/{y}/raw/` as the `raw` dict
     that process_tile (below) takes.  hkl.load is replaced by the library's own HDF5 reader (ttc_read_hkl, host code);
     the Sen2Cor mask is returned at its stored 20 m resolution, the clean-up of :687-694 happens on the device.
     alloc(name) -> allocator for _lib.read_hkl (PinnedArena.allocator): the arrays the tile call uploads are then read straight
-    into page-locked memory."""
+    into page-locked memory.  want_clouds=False skips the s2cloudless probabilities (18 MB inflated per T = 12 tile): the reference loads
+    them (:684) but only carries them along the date steps -- the mask the gap-fill uses comes from identify_clouds_shadows (:839), so a
+    tile loop that detects (predict_tiles with mask None) never reads them and the host saves a sixth of its inflate work."""
     x, y = str(int(x)), str(int(y))
     folder = f"{local_path}{x}/{y}/"
     idx = f"{x}X{y}Y"
@@ -366,7 +368,7 @@ def load_raw_tile(x, y, local_path, alloc=None):
     def rd(path, name=None):
         return _lib.read_hkl(path, alloc=alloc(name) if (alloc is not None and name is not None) else None)
     clm_file = f"{folder}raw/clouds/cloudmask_{idx}.hkl"
-    return {"clouds": rd(f"{folder}raw/clouds/clouds_{idx}.hkl"),
+    return {"clouds": rd(f"{folder}raw/clouds/clouds_{idx}.hkl") if want_clouds else None,
             "clm": rd(clm_file) if os.path.exists(clm_file) else None,
             "s1": rd(f"{folder}raw/s1/{idx}.hkl", "s1"), "s2_10": rd(f"{folder}raw/s2_10/{idx}.hkl", "s2_10"),
             "s2_20": rd(f"{folder}raw/s2_20/{idx}.hkl", "s2_20"), "dem": rd(f"{folder}raw/misc/dem_{idx}.hkl", "dem"),
@@ -420,7 +422,7 @@ class PinnedArena:
         return for_name
 
 
-def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None):
+def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None, want_clouds=True):
     """Generator over load_raw_tile(x, y, local_path) for (x, y) in coords, read AHEAD by a small thread pool: the HDF5 reader is
     host C++ behind ctypes (the GIL is released for the duration of the call), so `workers` tiles are parsed / inflated in
     parallel while the GPU works on earlier ones -- feed it to predict_tiles.  At most `ahead` (default 2 x workers) tiles are
@@ -435,7 +437,7 @@ def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None):
         arena.ahead = ahead                      # predict_tiles checks the arena's size against ahead + its own depth
 
     def load(xy, aset):
-        raw = load_raw_tile(xy[0], xy[1], local_path, alloc=arena.allocator(aset) if arena is not None else None)
+        raw = load_raw_tile(xy[0], xy[1], local_path, alloc=arena.allocator(aset) if arena is not None else None, want_clouds=want_clouds)
         if arena is not None:
             raw["_arena_set"] = aset
         return raw
