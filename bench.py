@@ -396,6 +396,8 @@ def main():
                 "clock_ghz": (sum(tail_clk) / len(tail_clk) / 1e3) if tail_clk else None, "clock_source": "rocm-smi --showclocks (sclk), sampled every 0.7 s over the tail",
                 "whole_run_value": args.inflight * TILE * TILE * marks[-1][1] / (t_end - t0)}
 
+    iso_extra = {}
+
     def isolated_gates(sess):
         """the gates launch without a second tile competing for the CUs (informational)"""
         c0 = sess.ctx
@@ -406,7 +408,9 @@ def main():
                                 sess.win_in - 14, dem_m=tile["dem_m"], flags=base_flags)
         torch.cuda.synchronize()
         ms, _ = c0.kernel_ms("conv_gates")
+        ds_ms, ds_n = c0.kernel_ms("dsen2_conv")
         c0.timing(0)
+        iso_extra["dsen2_conv"] = (ds_ms, ds_n // 3)          # mean launch, launches per tile (three tiles were run)
         return ms
 
     def hip_tile0(sess):
@@ -749,6 +753,17 @@ def main():
                 out["roofline"]["isolated_algorithmic_frac"] = out["roofline"]["algorithmic_frac"] * gates_ms / iso_ms
             out["roofline"]["note"] = ("launch_ms / frac are live values with %d tiles in flight (kernels of the other tile share the CUs); "
                                        "isolated_* = the same launch with one tile in flight" % args.inflight)
+            if iso_extra.get("dsen2_conv") and iso_extra["dsen2_conv"][1] > 0 and args.precision == "fp32":
+                # the largest kernel FAMILY of the fp32 tile by time: DSen2's six convs on the direct fp32 kernel (31 windows x T dates of 118 x 118)
+                ds_ms, ds_n = iso_extra["dsen2_conv"]
+                ds_flops = 2.0 * 9 * (10 * 32 + 4 * 32 * 32 + 32 * 6) * 118 * 118 * 31 * args.dates
+                ds_tf = ds_flops / (ds_ms * ds_n * 1e-3) / 1e12
+                out["roofline"]["other_families"] = {"dsen2_conv": {
+                    "kernel": "conv3x3_f32<CK,1,EPI_BIAS_*> direct implicit GEMM on v_mfma_f32_32x32x2_f32 (+ the 32 -> 6 head), one tile in flight",
+                    "ms_per_tile": ds_ms * ds_n, "launches_per_tile": ds_n, "flops_per_tile": ds_flops, "achieved": ds_tf,
+                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ds_tf / FP32_MFMA_PEAK_TF,
+                    "note": "direct form: issued = algorithmic flops; power-bound (1.84 GHz with the matrix pipe 83 % busy, DESIGN.md 7); "
+                            "ttc_config.dsen2_precision = fp16 runs these convs on the 16-bit engine (alt_fp32_dsen2_fp16)"}}
         out.update(extra)
         sus = extra.get("sustained") or {}
         if sus.get("value") and sus["value"] < 0.97 * out["value"]:
