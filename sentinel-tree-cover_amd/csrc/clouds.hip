@@ -66,6 +66,125 @@ __global__ void k_coldist(const unsigned char* __restrict__ hd, int H, int W, in
     }
     out[p] = any;
 }
+// (round 5) the two passes with FOUR outputs per thread along the scan axis: (2 r + 4) byte loads per four outputs instead of up to 2 r + 1
+// each -- these kernels are bound by their load instructions.  Same sets (gapfill.hip: k_dil_rows4 / k_dil_cols4 are the single-plane twins).
+constexpr int kDilR4 = 10;                // largest radius of the four-output forms
+__global__ void k_rowdist4(const unsigned char* __restrict__ in, int H, int W, int r, int invert, unsigned char* __restrict__ hd) {
+    const int nb = (W + 3) / 4;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= H * nb) return;
+    in += (long)blockIdx.y * H * W; hd += (long)blockIdx.y * H * W;
+    const int y = id / nb, x0 = 4 * (id % nb);
+    unsigned hit = 0;                                       // bit j: pixel x0 - r + j is set
+#pragma unroll
+    for (int j = 0; j < 2 * kDilR4 + 4; ++j) {
+        const int xx = x0 - r + j;
+        if (j < 2 * r + 4 && xx >= 0 && xx < W && ((in[y * W + xx] != 0) != (invert != 0))) hit |= 1u << j;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (x0 + q >= W) break;
+        int best = r + 1;
+        for (int d = r; d >= 0; --d)
+            if (((hit >> (r + q - d)) | (hit >> (r + q + d))) & 1u) best = d;
+        hd[y * W + x0 + q] = (unsigned char)best;
+    }
+}
+__global__ void k_coldist4(const unsigned char* __restrict__ hd, int H, int W, int r, unsigned char* __restrict__ out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= ((H + 3) / 4) * W) return;
+    hd += (long)blockIdx.y * H * W; out += (long)blockIdx.y * H * W;
+    const int y0 = 4 * (id / W), x = id % W;
+    int gv[2 * kDilR4 + 4];
+#pragma unroll
+    for (int j = 0; j < 2 * kDilR4 + 4; ++j) {
+        const int yy = y0 - r + j;
+        gv[j] = (j < 2 * r + 4 && yy >= 0 && yy < H) ? (int)hd[yy * W + x] : 255;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (y0 + q >= H) break;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 2 * kDilR4 + 1; ++j) {         // dy = j - r
+            const int dy = j - r;
+            if (j <= 2 * r) any |= gv[q + j] <= r - (dy < 0 ? -dy : dy);
+        }
+        out[(y0 + q) * W + x] = any;
+    }
+}
+// the 3-D cross (k_dil_l1_3d below: up to 63 probes for r = 3) in three separable passes: k_rowdist4, then the L1 distance inside the plane
+// (k_coldist_d4: min over dy of |dy| + row distance, r + 1 = none within r), then a date offset dt with |dt| + that distance <= r (k_tdist)
+__global__ void k_coldist_d4(const unsigned char* __restrict__ hd, int H, int W, int r, unsigned char* __restrict__ d2) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= ((H + 3) / 4) * W) return;
+    hd += (long)blockIdx.y * H * W; d2 += (long)blockIdx.y * H * W;
+    const int y0 = 4 * (id / W), x = id % W;
+    int gv[2 * kDilR4 + 4];
+#pragma unroll
+    for (int j = 0; j < 2 * kDilR4 + 4; ++j) {
+        const int yy = y0 - r + j;
+        gv[j] = (j < 2 * r + 4 && yy >= 0 && yy < H) ? (int)hd[yy * W + x] : 255;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (y0 + q >= H) break;
+        int best = r + 1;
+#pragma unroll
+        for (int j = 0; j < 2 * kDilR4 + 1; ++j) {
+            const int dy = j - r;
+            if (j <= 2 * r) best = min(best, gv[q + j] + (dy < 0 ? -dy : dy));
+        }
+        d2[(y0 + q) * W + x] = (unsigned char)best;
+    }
+}
+__global__ void k_tdist(const unsigned char* __restrict__ d2, int T, int npix, int r, unsigned char* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    int v[kMaxT];
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) v[t] = t < T ? (int)d2[(long)t * npix + p] : 255;
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) {
+        bool any = false;
+#pragma unroll
+        for (int dt = -3; dt <= 3; ++dt) {
+            const int tt = t + dt;                              // constant after unrolling: v[] stays in registers
+            if (tt >= 0 && tt < kMaxT) any |= ((dt < 0 ? -dt : dt) <= r) && tt < T && (v[tt] + (dt < 0 ? -dt : dt) <= r);
+        }
+        if (t < T) out[(long)t * npix + p] = any;
+    }
+}
+// column pass of k_near_euclid's separable form: k_rowdist4 gives the distance along the row (R + 1 = none within R); a pixel is within the
+// Euclidean radius iff some row dy away has dy^2 + distance^2 <= r2.  (The direct form probes (2 R + 1)^2 pixels.)
+__global__ void k_coleuclid4(const unsigned char* __restrict__ hd, const int* __restrict__ counts, int H, int W, int R, int r2,
+                             unsigned char* __restrict__ out) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (id >= ((H + 3) / 4) * W) return;
+    hd += (long)t * H * W; out += (long)t * H * W;
+    const int y0 = 4 * (id / W), x = id % W;
+    if (counts[t] == 0) {                                   // scipy's transform of a plane without background: measured from (-1, 0)
+        for (int q = 0; q < 4 && y0 + q < H; ++q) out[(y0 + q) * W + x] = ((y0 + q + 1) * (y0 + q + 1) + x * x) <= r2;
+        return;
+    }
+    int gv[2 * kDilR4 + 4];
+#pragma unroll
+    for (int j = 0; j < 2 * kDilR4 + 4; ++j) {
+        const int yy = y0 - R + j;
+        gv[j] = (j < 2 * R + 4 && yy >= 0 && yy < H) ? (int)hd[yy * W + x] : 255;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (y0 + q >= H) break;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 2 * kDilR4 + 1; ++j) {
+            const int dy = j - R;
+            if (j <= 2 * R) any |= gv[q + j] <= R && dy * dy + gv[q + j] * gv[q + j] <= r2;
+        }
+        out[(y0 + q) * W + x] = any;
+    }
+}
 // 8-connected structure, r iterations = square of radius r
 __global__ void k_dil_sq(const unsigned char* __restrict__ in, int H, int W, int r, unsigned char* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,6 +311,24 @@ __global__ void k_allref(const float* __restrict__ img, const unsigned char* __r
         all_min[(long)p * 4 + k] = mn;
     }
 }
+// ascending order of eight values in registers (Batcher's 19-comparator network): the window of k_shadow_cand holds at most eight dates, missing
+// ones are +inf and end up behind the valid ones -- the same order the insertion sort of the first version produced in scratch memory
+__device__ __forceinline__ void sort8(float (&v)[8]) {
+#define TTC_CE(i, j) { const float lo_ = fminf(v[i], v[j]), hi_ = fmaxf(v[i], v[j]); v[i] = lo_; v[j] = hi_; }
+    TTC_CE(0, 1) TTC_CE(2, 3) TTC_CE(4, 5) TTC_CE(6, 7)
+    TTC_CE(0, 2) TTC_CE(1, 3) TTC_CE(4, 6) TTC_CE(5, 7)
+    TTC_CE(1, 2) TTC_CE(5, 6)
+    TTC_CE(0, 4) TTC_CE(1, 5) TTC_CE(2, 6) TTC_CE(3, 7)
+    TTC_CE(2, 4) TTC_CE(3, 5)
+    TTC_CE(1, 2) TTC_CE(3, 4) TTC_CE(5, 6)
+#undef TTC_CE
+}
+__device__ __forceinline__ float pick8(const float (&v)[8], int i) {          // v[i] without dynamic register indexing
+    float r = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = i == k ? v[k] : r;
+    return r;
+}
 __global__ void k_shadow_cand(const float* __restrict__ img, const unsigned char* __restrict__ clm, const float* __restrict__ water,
                               const float* __restrict__ dem, const DateWin* __restrict__ wins, const float* __restrict__ all_med,
                               const float* __restrict__ all_min, int T, int npix, unsigned char* __restrict__ out) {
@@ -201,14 +338,29 @@ __global__ void k_shadow_cand(const float* __restrict__ img, const unsigned char
     const DateWin& w = wins[t];
     const int bands[4] = {0, 1, 7, 8};
     float lmax[4], lmed[4];
+    // (round 5) the window's values live in registers: eight predicated slots, a sorting network, selects -- the first version filled a
+    // local array of runtime length and insertion-sorted it (scratch memory, data-dependent loops: 0.56 ms per tile)
+    bool ok[8];
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int tt = w.sh_lo + j;
+        ok[j] = tt < w.sh_hi && !clm[(long)(tt < w.sh_hi ? tt : w.sh_lo) * npix + p];
+        n += ok[j] ? 1 : 0;
+    }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         float v[8];
-        int n = 0;
-        float mx = -INFINITY;
-        for (int tt = w.sh_lo; tt < w.sh_hi; ++tt)
-            if (!clm[(long)tt * npix + p]) { const float x = IMG(tt, p, bands[k]); v[n++] = x; mx = fmaxf(mx, x); }
-        if (n > 0) { isort(v, n); lmed[k] = median_sorted(v, n); lmax[k] = mx; }
-        else { lmed[k] = all_min[(long)p * 4 + k]; lmax[k] = NAN; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tt = w.sh_lo + j;
+            v[j] = ok[j] ? IMG(tt, p, bands[k]) : INFINITY;
+        }
+        if (n > 0) {
+            sort8(v);
+            lmed[k] = (n & 1) ? pick8(v, n >> 1) : (pick8(v, (n >> 1) - 1) + pick8(v, n >> 1)) * 0.5f;
+            lmax[k] = pick8(v, n - 1);
+        } else { lmed[k] = all_min[(long)p * 4 + k]; lmax[k] = NAN; }
     }
     const float b = IMG(t, p, 0), g = IMG(t, p, 1), r = IMG(t, p, 2), a8 = IMG(t, p, 7), s11 = IMG(t, p, 8);
     const bool wet_px = water[p] > 0.f;
@@ -835,8 +987,24 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     unsigned char* hd = static_cast<unsigned char*>(c->scratch_buf("cd_rowdist", (size_t)N));
     if (!hd) return c->fail(TTC_ERR_NOMEM, "cloud detection scratch");
     auto dil_l1 = [&](const unsigned char* in, int r, int invert, unsigned char* out) {        // out may alias in
-        hipLaunchKernelGGL(k_rowdist, gpt, b256, 0, s, in, H, W, r, invert, hd);
-        hipLaunchKernelGGL(k_coldist, gpt, b256, 0, s, hd, H, W, r, out);
+        if (r <= kDilR4) {
+            hipLaunchKernelGGL(k_rowdist4, dim3((unsigned)(((long)H * ((W + 3) / 4) + 255) / 256), T), b256, 0, s, in, H, W, r, invert, hd);
+            hipLaunchKernelGGL(k_coldist4, dim3((unsigned)(((long)((H + 3) / 4) * W + 255) / 256), T), b256, 0, s, hd, H, W, r, out);
+        } else {
+            hipLaunchKernelGGL(k_rowdist, gpt, b256, 0, s, in, H, W, r, invert, hd);
+            hipLaunchKernelGGL(k_coldist, gpt, b256, 0, s, hd, H, W, r, out);
+        }
+    };
+    unsigned char* hd2 = static_cast<unsigned char*>(c->scratch_buf("cd_coldist", (size_t)N));
+    if (!hd2) return c->fail(TTC_ERR_NOMEM, "cloud detection scratch");
+    auto dil_l1_3d = [&](const unsigned char* in, int r, unsigned char* out) {                // r <= 3; in and out distinct
+        hipLaunchKernelGGL(k_rowdist4, dim3((unsigned)(((long)H * ((W + 3) / 4) + 255) / 256), T), b256, 0, s, in, H, W, r, 0, hd);
+        hipLaunchKernelGGL(k_coldist_d4, dim3((unsigned)(((long)((H + 3) / 4) * W + 255) / 256), T), b256, 0, s, hd, H, W, r, hd2);
+        hipLaunchKernelGGL(k_tdist, gp, b256, 0, s, hd2, T, npix, r, out);
+    };
+    auto near_euclid = [&](const unsigned char* in, const int* counts, int R, int r2, unsigned char* out) {     // R <= kDilR4; out may alias in
+        hipLaunchKernelGGL(k_rowdist4, dim3((unsigned)(((long)H * ((W + 3) / 4) + 255) / 256), T), b256, 0, s, in, H, W, R, 0, hd);
+        hipLaunchKernelGGL(k_coleuclid4, dim3((unsigned)(((long)((H + 3) / 4) * W + 255) / 256), T), b256, 0, s, hd, counts, H, W, R, r2, out);
     };
     // opening idiom of the reference: dilate(1 - dilate(x == 0, a), b)
     auto open_planes = [&](const unsigned char* in, int a, int b, unsigned char* tmp, unsigned char* out) {
@@ -856,7 +1024,7 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     open_planes(t1, 2, 3, t2, t3);
     TTC_HIP(c, zero_counts(cnt_a));
     hipLaunchKernelGGL(k_plane_count, gred, b256, 0, s, t3, npix, cnt_a);
-    hipLaunchKernelGGL(k_near_euclid, gpt, b256, 0, s, t3, cnt_a, H, W, 5, 25, shadows);
+    near_euclid(t3, cnt_a, 5, 25, shadows);
     if (debug_stage == 3) return finish(shadows);
     // ---- 4: cloud candidates
     hipLaunchKernelGGL(k_extra_table, dim3(1), dim3(64), 0, s, extra);
@@ -908,7 +1076,7 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     // ---- 8: false-positive rules
     hipLaunchKernelGGL(k_fp_urban, gpt, b256, 0, s, img, fcps, T, npix, clouds, shadows);
     hipLaunchKernelGGL(k_nsr, gpt, b256, 0, s, img, npix, t1);
-    hipLaunchKernelGGL(k_dil_l1_3d, gpt, b256, 0, s, t1, T, H, W, 3, nsr);
+    dil_l1_3d(t1, 3, nsr);
     hipLaunchKernelGGL(k_fp_nsr, gpt, b256, 0, s, img, water, T, npix, nsr, clouds);
     hipLaunchKernelGGL(k_water_dark, gpt, b256, 0, s, img, water, npix, t1);
     dil_l1(t1, 10, 0, t2);
@@ -937,7 +1105,7 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, t2, t3, N, far);
     TTC_HIP(c, zero_counts(cnt_a));
     hipLaunchKernelGGL(k_plane_count, gred, b256, 0, s, far, npix, cnt_a);
-    hipLaunchKernelGGL(k_near_euclid, gpt, b256, 0, s, far, cnt_a, H, W, 3, 9, t2);  // non-urban clouds
+    near_euclid(far, cnt_a, 3, 9, t2);  // non-urban clouds
     hipLaunchKernelGGL(k_and_planes, gn, b256, 0, s, t2, t1, N, twos);                // value 2 in the reference's sum
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, t2, t1, N, clouds);
     if (debug_stage == 9) return finish(clouds);
@@ -950,7 +1118,7 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     if (debug_stage == 10) return finish(shadows);
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, clouds, shadows, N, clouds);
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, fcps, nsr, N, t1);
-    hipLaunchKernelGGL(k_dil_l1_3d, gpt, b256, 0, s, t1, T, H, W, 2, d_fcps);
+    dil_l1_3d(t1, 2, d_fcps);
     // ---- 11: false-negative shadows from the per-image blue statistics
     TTC_HIP(c, zero_counts(cnt_b));
     hipLaunchKernelGGL(k_mean_flags, gred, b256, 0, s, clouds, npix, cnt_b);
