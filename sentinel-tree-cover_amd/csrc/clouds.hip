@@ -113,7 +113,7 @@ __global__ void k_coldist4(const unsigned char* __restrict__ hd, int H, int W, i
         out[(y0 + q) * W + x] = any;
     }
 }
-// the 3-D cross (k_dil_l1_3d below: up to 63 probes for r = 3) in three separable passes: k_rowdist4, then the L1 distance inside the plane
+// the 3-D cross (binary_dilation with the 3-D cross, r iterations: up to 63 probes for r = 3 in the direct form) in three separable passes: k_rowdist4, then the L1 distance inside the plane
 // (k_coldist_d4: min over dy of |dy| + row distance, r + 1 = none within r), then a date offset dt with |dt| + that distance <= r (k_tdist)
 __global__ void k_coldist_d4(const unsigned char* __restrict__ hd, int H, int W, int r, unsigned char* __restrict__ d2) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,7 +155,7 @@ __global__ void k_tdist(const unsigned char* __restrict__ d2, int T, int npix, i
         if (t < T) out[(long)t * npix + p] = any;
     }
 }
-// column pass of k_near_euclid's separable form: k_rowdist4 gives the distance along the row (R + 1 = none within R); a pixel is within the
+// column pass of the Euclidean-radius dilation (distance_transform_edt(1 - in) <= R): k_rowdist4 gives the distance along the row (R + 1 = none within R); a pixel is within the
 // Euclidean radius iff some row dy away has dy^2 + distance^2 <= r2.  (The direct form probes (2 R + 1)^2 pixels.)
 __global__ void k_coleuclid4(const unsigned char* __restrict__ hd, const int* __restrict__ counts, int H, int W, int R, int r2,
                              unsigned char* __restrict__ out) {
@@ -197,29 +197,6 @@ __global__ void k_dil_sq(const unsigned char* __restrict__ in, int H, int W, int
             if (in[yy * W + xx]) { any = true; break; }
     out[p] = any;
 }
-// 3-D cross, r iterations, on [T][H][W]
-__global__ void k_dil_l1_3d(const unsigned char* __restrict__ in, int T, int H, int W, int r, unsigned char* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-    if (p >= H * W) return;
-    const int y = p / W, x = p % W;
-    bool any = false;
-    for (int dt = -r; dt <= r && !any; ++dt) {
-        const int tt = t + dt;
-        if (tt < 0 || tt >= T) continue;
-        const int r1 = r - abs(dt);
-        for (int dy = -r1; dy <= r1 && !any; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
-            const int r2 = r1 - abs(dy);
-            for (int dx = -r2; dx <= r2; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                if (in[((long)tt * H + yy) * W + xx]) { any = true; break; }
-            }
-        }
-    }
-    out[(long)t * H * W + p] = any;
-}
 __global__ void k_plane_count(const unsigned char* __restrict__ in, int npix, int* __restrict__ counts) {
     const int t = blockIdx.y;
     int c = 0;
@@ -227,27 +204,8 @@ __global__ void k_plane_count(const unsigned char* __restrict__ in, int npix, in
     for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[t], c);
 }
-// out = (distance_transform_edt(1 - in) <= R), r2 = R*R.  A plane without any set pixel has no background for scipy's
-// transform, which then measures from the virtual point (-1, 0).
-__global__ void k_near_euclid(const unsigned char* __restrict__ in, const int* __restrict__ counts, int H, int W, int R, int r2,
-                              unsigned char* __restrict__ out) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-    if (p >= H * W) return;
-    in += (long)t * H * W; out += (long)t * H * W;
-    const int y = p / W, x = p % W;
-    if (counts[t] == 0) { out[p] = ((y + 1) * (y + 1) + x * x) <= r2; return; }
-    bool any = false;
-    for (int dy = -R; dy <= R && !any; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -R; dx <= R; ++dx) {
-            const int xx = x + dx;
-            if (xx < 0 || xx >= W || dy * dy + dx * dx > r2) continue;
-            if (in[yy * W + xx]) { any = true; break; }
-        }
-    }
-    out[p] = any;
-}
+// (distance_transform_edt(1 - in) <= R), r2 = R*R: k_rowdist4 + k_coleuclid4 above.  A plane without any set pixel has no background for
+// scipy's transform, which then measures from the virtual point (-1, 0).
 __global__ void k_u8_not(const unsigned char* __restrict__ in, long n, unsigned char* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i] == 0;
