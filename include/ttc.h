@@ -100,6 +100,9 @@ typedef struct {
 
 /* ---- lifecycle --------------------------------------------------------------------- */
 const char* ttc_version(void);
+/* sizeof(ttc_config) as THIS library was built: a binding (cgo / ctypes / JNI) compares it with its own struct before ttc_create -- the struct
+ * grows at its end from round to round, and a stale binding would otherwise hand over a short struct silently */
+size_t      ttc_config_size(void);
 ttc_status  ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg);
 void        ttc_destroy(ttc_ctx* ctx);
 const char* ttc_last_error(const ttc_ctx* ctx);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTC_LIB", os.path.join(_HERE, "libttc_hip.so"))      # TTC_LIB: experiment builds only
 
 EXPORTS = [
-    "ttc_version", "ttc_create", "ttc_destroy", "ttc_last_error", "ttc_device_bytes",
+    "ttc_version", "ttc_config_size", "ttc_create", "ttc_destroy", "ttc_last_error", "ttc_device_bytes",
     "ttc_load_weights", "ttc_load_dsen2_weights", "ttc_forward_windows", "ttc_process_subtiles",
     "ttc_tile_missing_counts", "ttc_tile_fix_missing", "ttc_mosaic", "ttc_dsen2_forward",
     "ttc_superresolve_tile", "ttc_upsample_20m", "ttc_debug_fetch", "ttc_debug_timing",
@@ -72,6 +72,10 @@ def load():
     lib = C.CDLL(LIB_PATH)
     P, I32, F32P, VP = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p
     lib.ttc_version.restype = C.c_char_p
+    lib.ttc_config_size.restype = C.c_size_t
+    if lib.ttc_config_size() != C.sizeof(TTCConfig):       # a stale .so (or binding): fail loudly instead of handing over a short struct
+        raise RuntimeError(f"{LIB_PATH}: ttc_config is {lib.ttc_config_size()} bytes in the library, {C.sizeof(TTCConfig)} in this binding -- "
+                           "rebuild the library (`make -C sentinel-tree-cover_amd/csrc`)")
     lib.ttc_create.argtypes = [C.POINTER(P), I32, C.POINTER(TTCConfig)]
     lib.ttc_destroy.argtypes = [P]
     lib.ttc_destroy.restype = None

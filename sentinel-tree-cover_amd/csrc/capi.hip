@@ -67,6 +67,8 @@ extern "C" {
 
 const char* ttc_version(void) { return "ttc-hip 0.1 (gfx950)"; }
 
+size_t ttc_config_size(void) { return sizeof(ttc_config); }
+
 ttc_status ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg) {
     if (!out || !cfg) return TTC_ERR_ARG;
     *out = nullptr;

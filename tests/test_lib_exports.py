@@ -39,6 +39,12 @@ def test_loader_prototypes():
     _ensure_built()
     lib = _lib.load()
     assert lib.ttc_create.argtypes is not None
+    # the binding's struct and the library's agree (ttc_config grows at its end: _lib.load() refuses a stale library)
+    assert lib.ttc_config_size() == ctypes.sizeof(_lib.TTCConfig) == 13 * 4
+    hdr = open(os.path.join(ROOT, "include", "ttc.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("Model / workspace configuration") if "Model / workspace configuration" in hdr else 0):hdr.index("} ttc_config;")]
+    fields = re.findall(r"^\s*(?:u?int32_t|float)\s+(\w+);", body, flags=re.M)
+    assert fields == [f[0] for f in _lib.TTCConfig._fields_], fields
 
 
 def test_no_cpu_fallback_without_gpu():
