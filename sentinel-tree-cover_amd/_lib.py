@@ -69,6 +69,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C sentinel-tree-cover_amd/csrc`).  There is no CPU fallback.")
+    try:
+        # PyTorch-ROCm wheels bundle their own HIP runtime: it has to be in the process BEFORE this library is dlopen'ed, or the library binds
+        # to the system's libamdhip64 and the process ends up with two runtimes (ttc_create then fails with TTC_ERR_HIP: no device) --
+        # measured with __graft_entry__.build() followed by smoke() in one process
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     P, I32, F32P, VP = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_void_p
     lib.ttc_version.restype = C.c_char_p
