@@ -955,10 +955,12 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     };
     unsigned char* hd2 = static_cast<unsigned char*>(c->scratch_buf("cd_coldist", (size_t)N));
     if (!hd2) return c->fail(TTC_ERR_NOMEM, "cloud detection scratch");
-    auto dil_l1_3d = [&](const unsigned char* in, int r, unsigned char* out) {                // r <= 3; in and out distinct
+    auto dil_l1_3d = [&](const unsigned char* in, int r, unsigned char* out) -> ttc_status {   // r <= 3 (k_tdist's date window); in and out distinct
+        if (r > 3) return c->fail(TTC_ERR_ARG, "cloud detection: the 3-D cross dilation is built for r <= 3");
         hipLaunchKernelGGL(k_rowdist4, dim3((unsigned)(((long)H * ((W + 3) / 4) + 255) / 256), T), b256, 0, s, in, H, W, r, 0, hd);
         hipLaunchKernelGGL(k_coldist_d4, dim3((unsigned)(((long)((H + 3) / 4) * W + 255) / 256), T), b256, 0, s, hd, H, W, r, hd2);
         hipLaunchKernelGGL(k_tdist, gp, b256, 0, s, hd2, T, npix, r, out);
+        return TTC_OK;
     };
     auto near_euclid = [&](const unsigned char* in, const int* counts, int R, int r2, unsigned char* out) {     // R <= kDilR4; out may alias in
         hipLaunchKernelGGL(k_rowdist4, dim3((unsigned)(((long)H * ((W + 3) / 4) + 255) / 256), T), b256, 0, s, in, H, W, R, 0, hd);
@@ -1034,7 +1036,7 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     // ---- 8: false-positive rules
     hipLaunchKernelGGL(k_fp_urban, gpt, b256, 0, s, img, fcps, T, npix, clouds, shadows);
     hipLaunchKernelGGL(k_nsr, gpt, b256, 0, s, img, npix, t1);
-    dil_l1_3d(t1, 3, nsr);
+    TTC_CHECK(dil_l1_3d(t1, 3, nsr));
     hipLaunchKernelGGL(k_fp_nsr, gpt, b256, 0, s, img, water, T, npix, nsr, clouds);
     hipLaunchKernelGGL(k_water_dark, gpt, b256, 0, s, img, water, npix, t1);
     dil_l1(t1, 10, 0, t2);
@@ -1076,7 +1078,7 @@ ttc_status clouds_identify(ttc_ctx* c, const float* img, int T, int X, int Y, co
     if (debug_stage == 10) return finish(shadows);
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, clouds, shadows, N, clouds);
     hipLaunchKernelGGL(k_or_planes, gn, b256, 0, s, fcps, nsr, N, t1);
-    dil_l1_3d(t1, 2, d_fcps);
+    TTC_CHECK(dil_l1_3d(t1, 2, d_fcps));
     // ---- 11: false-negative shadows from the per-image blue statistics
     TTC_HIP(c, zero_counts(cnt_b));
     hipLaunchKernelGGL(k_mean_flags, gred, b256, 0, s, clouds, npix, cnt_b);
