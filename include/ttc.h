@@ -20,6 +20,10 @@
  *  - A context is bound to one device and is not re-entrant.
  *  - Array layouts are the reference's numpy layouts ([T, X, Y, C], C-contiguous float32)
  *    unless a parameter says "planar".
+ *  - Non-finite inputs.  The model entry points expect FINITE window inputs (the reference feeds np.clip'ed, normalised values:
+ *    job.py:316-325).  A NaN / Inf in one window makes that window's probabilities NaN -- in the reference too, its GroupNorm
+ *    statistics span the whole window (model.py:100-121) -- and never touches another window of the batch; WHICH raw conv outputs
+ *    inside the poisoned window are non-finite depends on `fp32_conv_form` (the Winograd forms transform 6 x 6 input patches).
  */
 #ifndef TTC_H
 #define TTC_H
@@ -104,6 +108,10 @@ const char* ttc_version(void);
  * grows at its end from round to round, and a stale binding would otherwise hand over a short struct silently */
 size_t      ttc_config_size(void);
 ttc_status  ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg);
+/* The same with the CALLER's sizeof(ttc_config): a binding built against an older header passes its shorter struct and the fields it does
+ * not know read as zero (every field added after `win_rows` defaults to 0); a struct LONGER than this library's is refused with
+ * TTC_ERR_ARG.  Bindings in other languages should call this one; ttc_create(cfg) == ttc_create_v2(cfg, ttc_config_size()). */
+ttc_status  ttc_create_v2(ttc_ctx** out, int32_t device, const ttc_config* cfg, size_t cfg_size);
 void        ttc_destroy(ttc_ctx* ctx);
 const char* ttc_last_error(const ttc_ctx* ctx);
 /* bytes of device memory the context holds (weights + workspace) */
@@ -276,6 +284,30 @@ ttc_status ttc_predict_tile(ttc_ctx* ctx, const uint16_t* d_s2_10, const uint16_
                             int32_t T, int32_t X, int32_t Y, const double* h_min, const double* h_max, int32_t size,
                             int32_t flags, uint8_t* d_out_u8, float* d_out_f32, float* d_model_in, int32_t* d_status,
                             void* stream);
+
+/* The same call for raw arrays that are NOT all on one grid -- the case adjust_shape exists for.  process_tile keys the tile's size on the
+ * 20 m stack (width, height = 2 x s2_20.shape[1:3], job.py:716-717) and crops / edge-pads Sentinel-1 (after its dB conversion, :699-718), the
+ * 10 m bands (:720) and the median-filtered DEM (:713, :721) to it with adjust_shape (:260-310): an array one pixel short gains its first row /
+ * column once more, one pixel long loses it, an even difference is split between both ends.  Here that is an index map inside the decode
+ * passes (no copy of the big arrays); only the DEM planes are re-gridded into scratch.  Every array comes with ITS OWN rows x cols:
+ *   shapes->s2_20  [h, w]     X = 2 h, Y = 2 w are the tile's grid and the shape of every output (d_out_u8 [Y, X] ...)
+ *   shapes->s2_10, ->s1, ->dem   as stored; d_dem / d_dem_m share ->dem
+ *   shapes->mask   must equal [X, Y] (the mask is produced on the tile's grid, :839; ignored with TTC_TILE_DETECT)
+ * Differences adjust_shape does not reconcile (an odd difference of 3 or more: the reference's own result has the wrong length there and
+ * process_tile raises on the next statement) and a mask of another shape return TTC_ERR_ARG with the offending array named in
+ * ttc_last_error.  Everything else as ttc_predict_tile, which is this call with every shape equal to [X, Y]. */
+typedef struct {
+    int32_t s2_10[2], s2_20[2], s1[2], dem[2], mask[2];
+} ttc_tile_shapes;
+ttc_status ttc_predict_tile_shaped(ttc_ctx* ctx, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1,
+                                   const float* d_dem, const float* d_dem_m, const float* d_mask, const int32_t* d_dates, int32_t T,
+                                   const ttc_tile_shapes* shapes, const double* h_min, const double* h_max, int32_t size,
+                                   int32_t flags, uint8_t* d_out_u8, float* d_out_f32, float* d_model_in, int32_t* d_status,
+                                   void* stream);
+/* adjust_shape (job.py:260-310) on its own: d_in [T, n1, n2, channels] float32 -> d_out [T, width, height, channels] (not in place).
+ * TTC_ERR_ARG where the reference's rule does not produce width x height (see above). */
+ttc_status ttc_adjust_shape(ttc_ctx* ctx, const float* d_in, int32_t T, int32_t n1, int32_t n2, int32_t channels, int32_t width,
+                            int32_t height, float* d_out, void* stream);
 
 /* ---- Gaussian overlap mosaic --------------------------------------------------------
  * == load_mosaic_predictions(out_folder, depth=1), job.py:1515-1641, from the 36 window

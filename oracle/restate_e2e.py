@@ -74,7 +74,8 @@ def single_call_chain(s2_10, s2_20, s1, dem90, mask, dates, net, dsen2, size=158
     """What ttc_predict_tile computes for a tile on which none of process_tile's date-dropping rules fire (its status words
     stay zero): to_float32 + convert_to_db, bilinear 20 m -> 10 m, remove_cloud_and_shadows with the GIVEN mask and the
     deterministic expected-multiplicity sampler, process_tile's final clip, then the rest of the chain.
-    dem90: the elevation as process_tile returns it (median-filtered, / 90).
+    dem90: the elevation as process_tile returns it (median-filtered, / 90), on the DEM file's own grid.  The 10 m bands, Sentinel-1 and
+    the DEM may be a pixel (or an even number of pixels) off the grid of the 20 m stack: adjust_shape reconciles them (job.py:716-721).
     cache: a dict shared by passes over the SAME tile and sampler at different window geometries (size / length): the stages up
     to and including DSen2 do not depend on the geometry and are computed by the first pass only."""
     clk = _Clock(timings)
@@ -82,6 +83,9 @@ def single_call_chain(s2_10, s2_20, s1, dem90, mask, dates, net, dsen2, size=158
         s2, interp, to_remove, s1db = (np.array(v, copy=True) if isinstance(v, np.ndarray) else list(v) for v in cache["gapfilled"])
     else:
         s2_10f, s2_20f, s1db = R.to_float32(s2_10), R.to_float32(s2_20), R.s1_to_db(s1)
+        width, height = s2_20f.shape[1] * 2, s2_20f.shape[2] * 2                   # job.py:716-721 (ttc_predict_tile_shaped)
+        s2_10f, s1db = R.adjust_shape(s2_10f, width, height), R.adjust_shape(s1db, width, height)
+        dem90 = R.adjust_shape(np.asarray(dem90, dtype=np.float32), width, height)
         clk.lap("codecs")
         s2 = R.upsample_20m(s2_10f, s2_20f)
         clk.lap("bilinear")

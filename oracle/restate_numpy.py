@@ -28,6 +28,28 @@ MAX_ALL = np.array([0.2691233691920348, 0.3740291447318227, 0.5171435111009385,
                     0.7602693339366691])
 
 
+# --------------------------------------------------------------------------- shape reconciliation
+def adjust_shape(arr, width, height):
+    """job.py:260-310: bring axes 1 / 2 of [T, X, Y, C] (3-D: [T, X, Y]; 2-D: [X, Y]) to width x height.  One pixel short: the first
+    row / column once more (np.pad 'edge' with (1, 0)); an even shortfall: half at either end; one pixel long: the first row / column
+    goes; an even excess: half at either end.  Written per axis as a gather -- index i of the result reads clip(i + off, 0, n - 1).
+    The reference's remaining branches (odd differences of 3 or more) leave the axis at the WRONG length (pads 2*(d//2), crops only
+    (d//2) in total) and process_tile raises on its next assignment: here that is a ValueError.  Squeezes like the reference."""
+    arr = np.asarray(arr)
+    arr = arr[:, :, :, np.newaxis] if arr.ndim == 3 else arr
+    arr = arr[np.newaxis, :, :, np.newaxis] if arr.ndim == 2 else arr
+    for ax, want in ((1, int(width)), (2, int(height))):
+        n = arr.shape[ax]
+        if n == want:
+            continue
+        d = abs(want - n)
+        if d // 2 != 0 and d % 2 != 0:
+            raise ValueError(f"adjust_shape: axis {ax} is {n}, wanted {want}: the reference does not reconcile an odd difference of {d}")
+        off = (1 if n > want else -1) * max(d // 2, 1)
+        arr = np.take(arr, np.clip(np.arange(want) + off, 0, n - 1), axis=ax)
+    return arr.squeeze()
+
+
 # --------------------------------------------------------------------------- codecs
 def to_float32(a):
     """src/tof/tof_downloading.py:64-72."""

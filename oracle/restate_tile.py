@@ -51,6 +51,11 @@ def process_tile_arrays(raw, forest=None, urban=None, sampler=G.reference_sample
     s2_10, s2_20 = R.to_float32(raw["s2_10"]), R.to_float32(raw["s2_20"])
     dem = ndi.median_filter(np.array(raw["dem"], copy=True), size=5)
     dates = np.array(raw["dates"], copy=True)
+    # job.py:716-721: the 20 m stack decides the tile's grid; S1 (already dB-scaled), the 10 m bands and the filtered DEM are brought onto it
+    width, height = s2_20.shape[1] * 2, s2_20.shape[2] * 2
+    s1, s2_10, dem = (R.adjust_shape(a, width, height) for a in (s1, s2_10, dem))
+    if s2_10.ndim == 3:                                                # :724-727, a single image
+        s2_10, s2_20 = s2_10[np.newaxis], (s2_20[np.newaxis] if s2_20.ndim == 3 else s2_20)
     clouds = np.array(raw["clouds"], copy=True) if raw.get("clouds") is not None else np.zeros((len(dates), 1, 1), np.float32)
     s2 = R.upsample_20m(s2_10, s2_20)
 

@@ -25,6 +25,7 @@ EXPORTS = [
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
     "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error",
+    "ttc_create_v2", "ttc_predict_tile_shaped", "ttc_adjust_shape",
 ]
 
 # exported for tools/probes and the detector-stage tests, declared in csrc/ttc_internal.h -- not part of the drop-in surface (include/ttc.h)
@@ -45,6 +46,11 @@ class TTCConfig(C.Structure):
 # operands keeps max |dprob| at 2e-4 (L = 4) .. 6.5e-4 (L = 12) on white-noise windows, but reaches 3.0e-3 on a real
 # (spatially smooth) 618^2 tile, outside the 1e-3 contract -- so no layer runs one product unless the caller asks for it.
 PRECISIONS = {"fp32": 0, "fp16": 2, "bf16": 3}     # 1 / 4 were the retired bf16x3 / fp32-blocked engines (csrc/experiments/)
+
+
+class TTCTileShapes(C.Structure):
+    """ttc_tile_shapes: rows x cols of each raw array as stored (ttc_predict_tile_shaped)"""
+    _fields_ = [("s2_10", C.c_int32 * 2), ("s2_20", C.c_int32 * 2), ("s1", C.c_int32 * 2), ("dem", C.c_int32 * 2), ("mask", C.c_int32 * 2)]
 
 
 class TTCResegWindow(C.Structure):
@@ -84,6 +90,7 @@ def load():
         raise RuntimeError(f"{LIB_PATH}: ttc_config is {lib.ttc_config_size()} bytes in the library, {C.sizeof(TTCConfig)} in this binding -- "
                            "rebuild the library (`make -C sentinel-tree-cover_amd/csrc`)")
     lib.ttc_create.argtypes = [C.POINTER(P), I32, C.POINTER(TTCConfig)]
+    lib.ttc_create_v2.argtypes = [C.POINTER(P), I32, C.POINTER(TTCConfig), C.c_size_t]
     lib.ttc_destroy.argtypes = [P]
     lib.ttc_destroy.restype = None
     lib.ttc_last_error.argtypes = [P]
@@ -123,6 +130,8 @@ def load():
     lib.ttc_s1_to_db.argtypes = [P, VP, I32, I32, I32, VP, VP]
     F64P, I32P = C.POINTER(C.c_double), C.POINTER(C.c_int32)
     lib.ttc_predict_tile.argtypes = [P, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, F64P, F64P, I32, I32, VP, VP, VP, VP, VP]
+    lib.ttc_predict_tile_shaped.argtypes = [P, VP, VP, VP, VP, VP, VP, VP, I32, C.POINTER(TTCTileShapes), F64P, F64P, I32, I32, VP, VP, VP, VP, VP]
+    lib.ttc_adjust_shape.argtypes = [P, VP, I32, I32, I32, I32, I32, I32, VP, VP]
     lib.ttc_border_subtiles.argtypes = [P, VP, VP, VP, I32, I32P, I32, F32P, F32P, I32, I32, VP, F32P, I32P, VP]
     lib.ttc_smooth_strip.argtypes = [P, VP, I32, I32, I32, F32P, VP, VP]
     lib.ttc_superresolve_windows.argtypes = [P, VP, I32, I32, I32, I32, I32, I32, VP]
@@ -218,7 +227,7 @@ class Context:
                              int(dsen2_precision or 0), int(two_term_layers or 0))
         self.device = device
         self._h = C.c_void_p()
-        st = self.lib.ttc_create(C.byref(self._h), device, C.byref(self.cfg))
+        st = self.lib.ttc_create_v2(C.byref(self._h), device, C.byref(self.cfg), C.sizeof(self.cfg))
         if st != 0:
             msg = self.lib.ttc_last_error(self._h).decode() if self._h else "ttc_create failed"
             if self._h:
@@ -334,9 +343,12 @@ class Context:
 
     def predict_tile_raw(self, s2_10, s2_20, s1, dem, mask, dates, min_all, max_all, size, dem_m=None, flags=0,
                          want_float=False, want_inputs=False, out=None, status=None):
-        """ttc_predict_tile: the whole per-tile chain in ONE enqueue, no host round trip.  s2_10 [T, X, Y, 4] / s2_20
-        [T, X/2, Y/2, 6] / s1 [12, X, Y, 2] uint16 as stored (cuda int16 / uint16 views or numpy), dem [X, Y] (/90), mask
-        [T, X, Y] float32 cloud + shadow mask (None with TILE_DETECT), dates [T] (cuda int32 tensor or sequence).
+        """ttc_predict_tile_shaped: the whole per-tile chain in ONE enqueue, no host round trip.  s2_20 [T, h, w, 6] uint16 decides the
+        tile's grid X, Y = 2h, 2w like process_tile (job.py:716-717); s2_10 [T, ~X, ~Y, 4] / s1 [12, ~X, ~Y, 2] uint16 as stored (cuda
+        int16 / uint16 views or numpy) and dem [~X, ~Y] (median-filtered, /90) may be a pixel or an even number of pixels off that grid:
+        they are reconciled by adjust_shape (:260-310) as an index map on the device; every array's shape is CHECKED here (dates per
+        array, channel counts, the mask's [T, X, Y]) -- a raw device pointer carries none.  mask: float32 cloud + shadow mask (None with
+        TILE_DETECT), dates [T] (cuda int32 tensor or sequence).
         -> (u8 cuda [Y, X] | None, f32 | None, model inputs | None, status cuda int32[4]); read `status` after a stream
         synchronisation and hand it to Context.tile_needs_staged: status[0] (a date the mosaic cannot align), status[2] (dates
         the gap-fill marks fully interpolated) or status[3] (bit 1 a date with > 10 % missing pixels, bit 2 more than 10 snowy
@@ -345,20 +357,53 @@ class Context:
         t = self.torch
         dev = f"cuda:{self.device}"
 
-        def u16(a):
+        def u16(a, what, last):
             if isinstance(a, t.Tensor):
-                return a.to(dev).contiguous()
-            a = np.ascontiguousarray(a)
-            return t.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev)
-        d10, d20, ds1 = u16(s2_10), u16(s2_20), u16(s1)
-        T, X, Y = int(d10.shape[0]), int(d10.shape[1]), int(d10.shape[2])
+                if a.dtype not in (t.int16, t.uint16):
+                    raise ValueError(f"predict_tile_raw: {what} must hold the uint16 values as stored (int16 / uint16 tensor), got {a.dtype}")
+                a = a.to(dev).contiguous()
+            else:
+                a = np.ascontiguousarray(a)
+                if a.dtype not in (np.uint16, np.int16):
+                    raise ValueError(f"predict_tile_raw: {what} must be the uint16 array as stored, got {a.dtype}")
+                a = t.from_numpy(a.view(np.int16)).to(dev)
+            if a.dim() == 3 and what != "s1":          # a single image: hkl stores [X, Y, C] (job.py:724-727)
+                a = a[None]
+            if a.dim() != 4 or int(a.shape[3]) != last:
+                raise ValueError(f"predict_tile_raw: {what} must be [T, rows, cols, {last}], got {tuple(a.shape)}")
+            return a
+        d10, d20, ds1 = u16(s2_10, "s2_10", 4), u16(s2_20, "s2_20", 6), u16(s1, "s1", 2)
+        T = int(d20.shape[0])
+        # the 20 m stack decides the tile's grid (job.py:716-717); the other arrays are reconciled to it by adjust_shape on the device
+        X, Y = 2 * int(d20.shape[1]), 2 * int(d20.shape[2])
+        if int(d10.shape[0]) != T:
+            raise ValueError(f"predict_tile_raw: s2_10 holds {int(d10.shape[0])} dates, s2_20 {T}")
+        if int(ds1.shape[0]) != 12:
+            raise ValueError(f"predict_tile_raw: s1 must hold the 12 monthly composites, got {tuple(ds1.shape)}")
         ddem = self._dev(dem, t.float32)
         dmask = self._dev(mask, t.float32) if mask is not None else None
         ddem_m = self._dev(dem_m, t.float32) if dem_m is not None else None
-        ddates = dates if isinstance(dates, t.Tensor) else t.tensor([int(d) for d in dates], dtype=t.int32)
+        if ddem.dim() != 2 or (ddem_m is not None and tuple(ddem_m.shape) != tuple(ddem.shape)):
+            raise ValueError(f"predict_tile_raw: dem / dem_m must be [rows, cols] arrays of one shape, got {tuple(ddem.shape)}"
+                             + (f" and {tuple(ddem_m.shape)}" if ddem_m is not None else ""))
+        detect = bool(flags & self.TILE_DETECT)
+        if dmask is not None and not detect and tuple(dmask.shape) != (T, X, Y):
+            raise ValueError(f"predict_tile_raw: the cloud / shadow mask is {tuple(dmask.shape)}, the tile is {(T, X, Y)} "
+                             "(T dates on the grid of 2 x the 20 m stack, job.py:716-717)")
+        ddates = dates if isinstance(dates, t.Tensor) else t.tensor([int(d) for d in np.asarray(dates).ravel()], dtype=t.int32)
         ddates = ddates.to(dev, t.int32).contiguous()
+        if int(ddates.numel()) != T:
+            raise ValueError(f"predict_tile_raw: {int(ddates.numel())} dates for {T} images")
+        shp = TTCTileShapes()
+        for name, a in (("s2_10", d10), ("s2_20", d20), ("s1", ds1)):
+            getattr(shp, name)[0], getattr(shp, name)[1] = int(a.shape[1]), int(a.shape[2])
+        shp.dem[0], shp.dem[1] = int(ddem.shape[0]), int(ddem.shape[1])
+        if dmask is not None:
+            shp.mask[0], shp.mask[1] = int(dmask.shape[1]), int(dmask.shape[2])
         inputs_only = bool(flags & self.TILE_INPUTS_ONLY)
         # rasters are [Y, X]: transposed like load_mosaic_predictions' (job.py:1578)
+        if out is not None and (tuple(out.shape) != (Y, X) or out.dtype != t.uint8 or not out.is_cuda or not out.is_contiguous()):
+            raise ValueError(f"predict_tile_raw: out must be a contiguous cuda uint8 tensor [{Y}, {X}]")
         u8 = out if out is not None else (None if inputs_only else t.empty((Y, X), dtype=t.uint8, device=dev))
         f32 = t.empty((Y, X), dtype=t.float32, device=dev) if (want_float and not inputs_only) else None
         W = self.cfg.win_in
@@ -367,11 +412,25 @@ class Context:
         mn = (C.c_double * 17)(*[float(v) for v in min_all])
         mx = (C.c_double * 17)(*[float(v) for v in max_all])
         ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None      # noqa: E731
-        self._check(self.lib.ttc_predict_tile(self._h, ptr(d10), ptr(d20), ptr(ds1), ptr(ddem), ptr(ddem_m), ptr(dmask), ptr(ddates),
-                                              T, X, Y, mn, mx, int(size), int(flags), ptr(u8), ptr(f32), ptr(frames), ptr(status),
-                                              self._stream()), "ttc_predict_tile")
+        self._check(self.lib.ttc_predict_tile_shaped(self._h, ptr(d10), ptr(d20), ptr(ds1), ptr(ddem), ptr(ddem_m), ptr(dmask), ptr(ddates),
+                                                     T, C.byref(shp), mn, mx, int(size), int(flags), ptr(u8), ptr(f32), ptr(frames),
+                                                     ptr(status), self._stream()), "ttc_predict_tile_shaped")
         self._keep = (d10, d20, ds1, ddem, dmask, ddem_m, ddates)      # inputs must outlive the enqueued work
         return u8, f32, frames, status
+
+    def adjust_shape(self, a, width, height):
+        """adjust_shape (job.py:260-310) on the device: float32 [T, n1, n2, C] / [T, n1, n2] / [n1, n2] -> the same rank at width x height"""
+        t = self.torch
+        x = self._dev(a, t.float32)
+        nd = x.dim()
+        x4 = x[None, :, :, None] if nd == 2 else (x[..., None] if nd == 3 else x)
+        T, n1, n2, ch = (int(v) for v in x4.shape)
+        if (n1, n2) == (int(width), int(height)):
+            return x
+        out = t.empty((T, int(width), int(height), ch), dtype=t.float32, device=x.device)
+        self._check(self.lib.ttc_adjust_shape(self._h, C.c_void_p(x4.contiguous().data_ptr()), T, n1, n2, ch, int(width), int(height),
+                                              C.c_void_p(out.data_ptr()), self._stream()), "ttc_adjust_shape")
+        return out[0, :, :, 0] if nd == 2 else (out[..., 0] if nd == 3 else out)
 
     def mosaic(self, windows, xy, size, rows, cols, want_float=False):
         """windows [n, size, size] (numpy / cuda), xy [n, 2] int32 (folder_x, folder_y) -> (u8 [rows, cols], f32 | None)"""

@@ -1,5 +1,6 @@
 // extern "C" entry points of libttc_hip.so (see include/ttc.h for the contract).
 #include <algorithm>
+#include <cstddef>
 
 #include "ttc_internal.h"
 
@@ -20,7 +21,8 @@ ttc_status dsen2_forward(ttc_ctx* c, const float* d_in, const float* d_bil, int 
 ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, int ws, int cs, hipStream_t s);
 ttc_status tile_smooth_strip(ttc_ctx* c, const float* d_s2, int T, int X, int Y, const float* h_wmat, float* d_out, hipStream_t s);
 ttc_status upsample_20m(ttc_ctx* c, const float* d10, const float* d20, int T, int h, int w, float* d_out, hipStream_t s);
-ttc_status decode_upsample_u16(ttc_ctx* c, const uint16_t* d10, const uint16_t* d20, int T, int h, int w, float* d_out, hipStream_t s);
+ttc_status decode_upsample_u16(ttc_ctx* c, const uint16_t* d10, const uint16_t* d20, int T, int h, int w, const AdjustMap* am10, float* d_out,
+                               hipStream_t s);
 
 ttc_status gapfill_feather(ttc_ctx* c, const float* d_mask, int T, int X, int Y, int closing, int clip, float* d_w, hipStream_t s);
 ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic, hipStream_t s);
@@ -30,7 +32,8 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
 
 ttc_status codec_u16_to_f32(ttc_ctx* c, const uint16_t* d_in, int64_t n, float* d_out, hipStream_t s);
 ttc_status codec_f32_to_u16(ttc_ctx* c, const float* d_in, int64_t n, uint16_t* d_out, hipStream_t s);
-ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s);
+ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s, const AdjustMap* am = nullptr);
+ttc_status codec_adjust_shape(ttc_ctx* c, const float* d_in, int T, int n1, int n2, int C, int width, int height, float* d_out, hipStream_t s);
 ttc_status codec_f32_to_i16(ttc_ctx* c, const float* d_in, int64_t n, float precision, int16_t* d_out, hipStream_t s);
 
 ttc_status mosaic_features(ttc_ctx* c, const int16_t* d_feats, int n, const int32_t* h_xy, int size, int depth, int rows, int cols,
@@ -68,6 +71,20 @@ extern "C" {
 const char* ttc_version(void) { return "ttc-hip 0.1 (gfx950)"; }
 
 size_t ttc_config_size(void) { return sizeof(ttc_config); }
+
+// ttc_config grows at its END from release to release: a caller built against an older header hands over a shorter struct.  _v2 takes the
+// caller's sizeof(ttc_config): missing trailing fields read as zero (every field added so far defaults to 0), a LONGER struct than this
+// library knows is refused (it may carry a request the library would silently ignore).
+ttc_status ttc_create_v2(ttc_ctx** out, int32_t device, const ttc_config* cfg, size_t cfg_size) {
+    if (!out || !cfg) return TTC_ERR_ARG;
+    *out = nullptr;
+    // the first nine fields (up to win_rows) are the round-1 struct: nothing shorter was ever shipped
+    if (cfg_size < offsetof(ttc_config, one_term_layers) || cfg_size > sizeof(ttc_config)) return TTC_ERR_ARG;
+    ttc_config full;
+    memset(&full, 0, sizeof(full));
+    memcpy(&full, cfg, cfg_size);
+    return ttc_create(out, device, &full);
+}
 
 ttc_status ttc_create(ttc_ctx** out, int32_t device, const ttc_config* cfg) {
     if (!out || !cfg) return TTC_ERR_ARG;
@@ -217,12 +234,13 @@ ttc_status ttc_remove_cloud_and_shadows(ttc_ctx* c, float* d_tiles, const float*
                                  n_to_remove, static_cast<hipStream_t>(stream));
 }
 
-ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1, const float* d_dem,
-                            const float* d_dem_m, const float* d_mask, const int32_t* d_dates, int32_t T, int32_t X, int32_t Y,
-                            const double* h_min, const double* h_max, int32_t size, int32_t flags, uint8_t* d_out_u8,
-                            float* d_out_f32, float* d_model_in, int32_t* d_status, void* stream) {
-    if (!c) return TTC_ERR_ARG;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+// the body of ttc_predict_tile / ttc_predict_tile_shaped: X, Y = the tile's grid (2 x the 20 m stack's, job.py:716-717); am10 / am_s1 map it
+// onto the 10 m and Sentinel-1 arrays as stored (null = same shape); d_dem / d_dem_m / d_mask already have the tile's shape
+static ttc_status predict_tile_impl(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1, const float* d_dem,
+                                    const float* d_dem_m, const float* d_mask, const int32_t* d_dates, int32_t T, int32_t X, int32_t Y,
+                                    const AdjustMap* am10, const AdjustMap* am_s1, const double* h_min, const double* h_max, int32_t size,
+                                    int32_t flags, uint8_t* d_out_u8, float* d_out_f32, float* d_model_in, int32_t* d_status,
+                                    hipStream_t s) {
     const bool detect = (flags & TTC_TILE_DETECT) != 0, inputs_only = (flags & TTC_TILE_INPUTS_ONLY) != 0;
     if (!d_s2_10 || !d_s2_20 || !d_s1 || !d_dem || !d_dates || !h_min || !h_max || !d_status) return c->fail(TTC_ERR_ARG, "predict_tile: null argument");
     if (!detect && !d_mask) return c->fail(TTC_ERR_ARG, "predict_tile: a cloud / shadow mask is needed unless TTC_TILE_DETECT is set");
@@ -254,8 +272,8 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
     c->named["pt_windows"] = {windows, (size_t)n_win * size * size};           // what the reference np.save()s per window
     c->named["pt_windows_raw"] = {windows_raw, (size_t)n_win * size * size};   // before np.around / the bright-surface product
     TTC_HIP(c, hipMemsetAsync(d_status, 0, sizeof(int32_t) * 4, s));
-    TTC_CHECK(codec_s1_to_db(c, d_s1, 12, X, Y, s1db, s));                              // job.py:699-708
-    TTC_CHECK(decode_upsample_u16(c, d_s2_10, d_s2_20, T, h, w, s2, s));                // tof_downloading.py:64-72 + job.py:734-782, one pass
+    TTC_CHECK(codec_s1_to_db(c, d_s1, 12, X, Y, s1db, s, am_s1));                       // job.py:699-708 (+ adjust_shape :718)
+    TTC_CHECK(decode_upsample_u16(c, d_s2_10, d_s2_20, T, h, w, am10, s2, s));          // tof_downloading.py:64-72 + job.py:720, :734-782, one pass
     const float* mask = d_mask;
     const uint8_t* pf = nullptr;
     if (detect) {                                                                       // cloud_removal.py:1215-1677
@@ -283,6 +301,60 @@ ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t*
     int rows = 0, cols = 0;
     for (int i = 0; i < n_win; ++i) { rows = std::max(rows, xy[2 * i + 1] + size); cols = std::max(cols, xy[2 * i] + size); }
     return mosaic_run(c, windows, n_win, xy.data(), size, rows, cols, d_out_u8, d_out_f32, s);                                 // job.py:1515-1641
+}
+
+ttc_status ttc_predict_tile(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1, const float* d_dem,
+                            const float* d_dem_m, const float* d_mask, const int32_t* d_dates, int32_t T, int32_t X, int32_t Y,
+                            const double* h_min, const double* h_max, int32_t size, int32_t flags, uint8_t* d_out_u8,
+                            float* d_out_f32, float* d_model_in, int32_t* d_status, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return predict_tile_impl(c, d_s2_10, d_s2_20, d_s1, d_dem, d_dem_m, d_mask, d_dates, T, X, Y, nullptr, nullptr, h_min, h_max, size, flags,
+                             d_out_u8, d_out_f32, d_model_in, d_status, static_cast<hipStream_t>(stream));
+}
+
+ttc_status ttc_predict_tile_shaped(ttc_ctx* c, const uint16_t* d_s2_10, const uint16_t* d_s2_20, const uint16_t* d_s1, const float* d_dem,
+                                   const float* d_dem_m, const float* d_mask, const int32_t* d_dates, int32_t T,
+                                   const ttc_tile_shapes* shp, const double* h_min, const double* h_max, int32_t size, int32_t flags,
+                                   uint8_t* d_out_u8, float* d_out_f32, float* d_model_in, int32_t* d_status, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    if (!shp) return c->fail(TTC_ERR_ARG, "predict_tile_shaped: null shapes");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (shp->s2_20[0] < 1 || shp->s2_20[1] < 1) return c->fail(TTC_ERR_ARG, "predict_tile_shaped: empty 20 m stack");
+    const int X = 2 * shp->s2_20[0], Y = 2 * shp->s2_20[1];                  // job.py:716-717: the 20 m stack decides
+    AdjustMap am10, am_s1, am_dem;
+    auto bad = [&](const char* what, const int32_t* got) {
+        char m[256];
+        snprintf(m, sizeof m, "predict_tile_shaped: %s is %d x %d for a %d x %d tile -- adjust_shape (job.py:260-310) reconciles differences of 1 "
+                 "or of an even number of pixels only (the reference raises on the rest)", what, got[0], got[1], X, Y);
+        return c->fail(TTC_ERR_ARG, m);
+    };
+    if (!adjust_map(shp->s2_10[0], shp->s2_10[1], X, Y, &am10)) return bad("s2_10", shp->s2_10);
+    if (!adjust_map(shp->s1[0], shp->s1[1], X, Y, &am_s1)) return bad("s1", shp->s1);
+    if (!adjust_map(shp->dem[0], shp->dem[1], X, Y, &am_dem)) return bad("dem", shp->dem);
+    // the cloud / shadow mask is not one of process_tile's files: it is made ON the tile's grid (identify_clouds_shadows, :839), so a mask of
+    // another shape is a caller error, not something adjust_shape covers
+    if (d_mask && !(flags & TTC_TILE_DETECT) && (shp->mask[0] != X || shp->mask[1] != Y)) {
+        char m[200];
+        snprintf(m, sizeof m, "predict_tile_shaped: the mask is %d x %d, the tile (2 x the 20 m stack) is %d x %d", shp->mask[0], shp->mask[1], X, Y);
+        return c->fail(TTC_ERR_ARG, m);
+    }
+    const float *dem = d_dem, *dem_m = d_dem_m;
+    if (am_dem.n1 != X || am_dem.n2 != Y) {                                  // dem = adjust_shape(median_filter(dem, 5), ...), :713, :721
+        if (!d_dem) return c->fail(TTC_ERR_ARG, "predict_tile: null argument");
+        float* a = static_cast<float*>(c->scratch_buf("pt_dem_adj", sizeof(float) * 2 * (size_t)X * Y));
+        if (!a) return c->fail(TTC_ERR_NOMEM, "predict_tile scratch");
+        TTC_CHECK(codec_adjust_shape(c, d_dem, 1, am_dem.n1, am_dem.n2, 1, X, Y, a, s));
+        dem = a;
+        if (d_dem_m) { TTC_CHECK(codec_adjust_shape(c, d_dem_m, 1, am_dem.n1, am_dem.n2, 1, X, Y, a + (size_t)X * Y, s)); dem_m = a + (size_t)X * Y; }
+    }
+    return predict_tile_impl(c, d_s2_10, d_s2_20, d_s1, dem, dem_m, d_mask, d_dates, T, X, Y, &am10, &am_s1, h_min, h_max, size, flags, d_out_u8,
+                             d_out_f32, d_model_in, d_status, s);
+}
+
+ttc_status ttc_adjust_shape(ttc_ctx* c, const float* d_in, int32_t T, int32_t n1, int32_t n2, int32_t channels, int32_t width, int32_t height,
+                            float* d_out, void* stream) {
+    if (!c) return TTC_ERR_ARG;
+    return codec_adjust_shape(c, d_in, T, n1, n2, channels, width, height, d_out, static_cast<hipStream_t>(stream));
 }
 
 ttc_status ttc_mosaic(ttc_ctx* c, const float* d_windows, int32_t n, const int32_t* h_xy, int32_t size,

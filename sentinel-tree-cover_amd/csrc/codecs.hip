@@ -85,18 +85,34 @@ __global__ void k_s1_clear(unsigned* __restrict__ hist, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) hist[i] = 0;
 }
-__global__ void k_s1_finish(const uint16_t* __restrict__ u16, const S1Sel* __restrict__ sel, int per_image, float* __restrict__ s1) {
+// am / X / Y: the result is written on the [X, Y] grid of the 20 m stack; adjust_shape (job.py:260-310) runs AFTER the dB conversion in the
+// reference (:699-718), so the median above is the one of the image AS STORED and only this pass re-indexes
+__global__ void k_s1_finish(const uint16_t* __restrict__ u16, const S1Sel* __restrict__ sel, int per_image, AdjustMap am, int X, int Y,
+                            float* __restrict__ s1) {
 #pragma clang fp contract(off)
     const int t = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= per_image) return;
+    if (p >= X * Y * 2) return;
     const float med = ((float)sel[t].prefix[0] / 65535.0f + (float)sel[t].prefix[1] / 65535.0f) * 0.5f;   // np.median of the float32 image
-    float x = (float)u16[(long)t * per_image + p] / 65535.0f;   // to_float32, tof_downloading.py:64-72
+    const int pix = p >> 1, i = pix / Y, j = pix - i * Y;
+    const int is = min(max(i + am.o1, 0), am.n1 - 1), js = min(max(j + am.o2, 0), am.n2 - 1);
+    float x = (float)u16[(long)t * per_image + ((long)is * am.n2 + js) * 2 + (p & 1)] / 65535.0f;   // to_float32, tof_downloading.py:64-72
     if (x == 1.0f) x = med;                                  // job.py:703
     x = 10.0f * log10f(x + (float)(1.0 / 65535.0));          // convert_to_db, job.py:86-89 (min_db = 22)
     if (x < -22.0f) x = -22.0f;
     x = (x + 22.0f) / 22.0f;
-    s1[(long)t * per_image + p] = fminf(fmaxf(x, 0.f), 1.f);
+    s1[(long)t * X * Y * 2 + p] = fminf(fmaxf(x, 0.f), 1.f);
+}
+
+// adjust_shape (job.py:260-310) on a float32 array [T, n1, n2, C] -> [T, X, Y, C]
+__global__ void k_adjust_shape(const float* __restrict__ in, AdjustMap am, int X, int Y, int C, float* __restrict__ out) {
+    const int t = blockIdx.y;
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)X * Y * C) return;
+    const int ch = (int)(p % C);
+    const int pix = (int)(p / C), i = pix / Y, j = pix - i * Y;
+    const int is = min(max(i + am.o1, 0), am.n1 - 1), js = min(max(j + am.o2, 0), am.n2 - 1);
+    out[(long)t * X * Y * C + p] = in[(((long)t * am.n1 + is) * am.n2 + js) * C + ch];
 }
 
 }  // namespace
@@ -125,9 +141,23 @@ ttc_status codec_f32_to_i16(ttc_ctx* c, const float* d_in, int64_t n, float prec
     return TTC_OK;
 }
 
-ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s) {
+ttc_status codec_adjust_shape(ttc_ctx* c, const float* d_in, int T, int n1, int n2, int C, int width, int height, float* d_out, hipStream_t s) {
+    AdjustMap am;
+    if (!d_in || !d_out || T < 1 || C < 1 || d_in == d_out) return c->fail(TTC_ERR_ARG, "adjust_shape: bad argument");
+    if (!adjust_map(n1, n2, width, height, &am))
+        return c->fail(TTC_ERR_ARG, "adjust_shape: an axis is off by an odd amount of 3 or more -- the reference's adjust_shape (job.py:260-310) does "
+                                    "not produce the requested size there and process_tile raises");
+    const long per = (long)width * height * C;
+    hipLaunchKernelGGL(k_adjust_shape, dim3((unsigned)((per + 255) / 256), T), dim3(256), 0, s, d_in, am, width, height, C, d_out);
+    TTC_HIP(c, hipGetLastError());
+    return TTC_OK;
+}
+
+// X, Y: shape of the result; am (may be null = the array has that shape) maps it onto the array as stored [T, am->n1, am->n2, 2]
+ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y, float* d_out, hipStream_t s, const AdjustMap* amp) {
     if (!d_u16 || !d_out || T < 1 || T > 64) return c->fail(TTC_ERR_ARG, "s1_to_db: bad argument (T in [1, 64])");
-    const int per = X * Y * 2;
+    const AdjustMap am = amp ? *amp : AdjustMap{X, Y, 0, 0};
+    const int per = am.n1 * am.n2 * 2;
     char* ctl = static_cast<char*>(c->scratch_buf("s1_ctl", 4096 + 128 * 256 * 4));
     if (!ctl) return c->fail(TTC_ERR_NOMEM, "s1 scratch");
     S1Sel* sel = reinterpret_cast<S1Sel*>(ctl);                 // 64 x 24 B
@@ -138,7 +168,7 @@ ttc_status codec_s1_to_db(ttc_ctx* c, const uint16_t* d_u16, int T, int X, int Y
         hipLaunchKernelGGL(k_s1_hist, dim3(96, T), dim3(256), 0, s, d_u16, per, sel, pass, hist);
         hipLaunchKernelGGL(k_s1_pick, dim3(T, 2), dim3(64), 0, s, sel, per, pass, hist);
     }
-    hipLaunchKernelGGL(k_s1_finish, dim3((per + 255) / 256, T), dim3(256), 0, s, d_u16, sel, per, d_out);
+    hipLaunchKernelGGL(k_s1_finish, dim3((X * Y * 2 + 255) / 256, T), dim3(256), 0, s, d_u16, sel, per, am, X, Y, d_out);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }

@@ -192,7 +192,13 @@ __global__ __launch_bounds__(kThreads4, 2) void conv3x3_wino4(Wino4Args wa) {
         int spo_cur[NPC], spo_nxt[NPC];
         float2 g[2 * NPC];                       // [h 2][piece]
         // positions past the plane's end (the 18 x 18 image of an edge sub-region) only feed outputs that are never stored: any finite
-        // in-plane value will do, so the offset is clamped into the plane
+        // in-plane value will do, so the offset is clamped into the plane.  PRECONDITION (include/ttc.h, "Non-finite inputs"): the planes hold
+        // finite values.  The transforms mix a patch's 36 inputs into every V, so a NaN / Inf picked up by a clamped read reaches STORED
+        // outputs of a partly valid patch where the direct kernel would not read it -- but every in-plane position of a padded plane (and
+        // every plane of the real channel Cin - 1 the pad channels alias below) is an input of some valid output of the SAME window, and
+        // the layer's GroupNorm statistics span the whole window: the direct kernel turns that window into NaN as well.  What differs is
+        // only WHICH raw outputs are non-finite before the statistics are taken, never which windows are (tested:
+        // tests/test_gpu_model.py::test_non_finite_window_stays_in_its_window)
         auto lane_offsets = [&](const TileS& t, int (&spo)[NPC]) {
 #pragma unroll
             for (int i = 0; i < NPC; ++i) spo[i] = min(t.base[PCS[i] / 3] + loff[PCS[i] % 3], plane - 2);

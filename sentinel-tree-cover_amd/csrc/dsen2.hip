@@ -213,14 +213,16 @@ __device__ __forceinline__ float mean4_u16(const unsigned short* __restrict__ b,
     const float v00 = dec16(b[0]), v01 = dec16(b[6]), v10 = dec16(b[w6]), v11 = dec16(b[w6 + 6]);
     return (((v00 + v01) + v10) + v11) / 4.0f;
 }
+// am: the 10 m array as stored may be a pixel or two off the 20 m grid; adjust_shape (job.py:260-310, applied at :720) is its index map
 __global__ void k_decode_upsample(const unsigned short* __restrict__ s10, const unsigned short* __restrict__ s20, int h, int w, int oy, int ox,
-                                  float* __restrict__ out) {
+                                  AdjustMap am, float* __restrict__ out) {
     const int t = blockIdx.y, H = 2 * h, W = 2 * w, hh = (h - oy) / 2, ww = (w - ox) / 2;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W) return;
     const int y = p / W, x = p % W;
     float v[10];
-    const ushort4 a = *reinterpret_cast<const ushort4*>(s10 + ((long)t * H * W + p) * 4);
+    const int ys = min(max(y + am.o1, 0), am.n1 - 1), xs = min(max(x + am.o2, 0), am.n2 - 1);
+    const ushort4 a = *reinterpret_cast<const ushort4*>(s10 + (((long)t * am.n1 + ys) * am.n2 + xs) * 4);
     v[0] = dec16(a.x); v[1] = dec16(a.y); v[2] = dec16(a.z); v[3] = dec16(a.w);
     const unsigned short* b = s20 + (long)t * h * w * 6;
     {
@@ -480,11 +482,13 @@ ttc_status dsen2_tile(ttc_ctx* c, float* d_s2, int T, int X, int Y, int quirks, 
     return TTC_OK;
 }
 
-ttc_status decode_upsample_u16(ttc_ctx* c, const uint16_t* d10, const uint16_t* d20, int T, int h, int w, float* d_out, hipStream_t s) {
+ttc_status decode_upsample_u16(ttc_ctx* c, const uint16_t* d10, const uint16_t* d20, int T, int h, int w, const AdjustMap* am10, float* d_out,
+                               hipStream_t s) {
     if (!d10 || !d20 || !d_out || T < 1) return c->fail(TTC_ERR_ARG, "decode_upsample: bad argument");
     KTimer kt(c, "upsample_20m", s);
     const int P = 4 * h * w;
-    hipLaunchKernelGGL(k_decode_upsample, dim3((P + 255) / 256, T), dim3(256), 0, s, d10, d20, h, w, h % 2, w % 2, d_out);
+    const AdjustMap am = am10 ? *am10 : AdjustMap{2 * h, 2 * w, 0, 0};
+    hipLaunchKernelGGL(k_decode_upsample, dim3((P + 255) / 256, T), dim3(256), 0, s, d10, d20, h, w, h % 2, w % 2, am, d_out);
     TTC_HIP(c, hipGetLastError());
     return TTC_OK;
 }

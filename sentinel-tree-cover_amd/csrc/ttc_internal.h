@@ -253,6 +253,25 @@ struct ttc_ctx {
     void* pinned_buf(const std::string& key, size_t bytes);
 };
 
+// adjust_shape (src/download_and_predict_job.py:260-310) as an index map: element (i, j) of the [width, height] result reads element
+// (clamp(i + o1, 0, n1 - 1), clamp(j + o2, 0, n2 - 1)) of the [n1, n2] source -- an edge pad is a negative offset, a crop a positive one.
+struct AdjustMap { int n1, n2, o1, o2; };
+// false where the reference's rule does not produce `want` (odd differences of 3 or more: its own result keeps the wrong length and the next
+// statement of process_tile raises on the broadcast)
+inline bool adjust_axis(int n, int want, int* off) {
+    *off = 0;
+    if (n < 1 || want < 1) return false;
+    if (n == want) return true;
+    const int d = n < want ? want - n : n - want, amt = d / 2;
+    if (amt != 0 && (d & 1)) return false;
+    *off = (n < want ? -1 : 1) * (amt == 0 ? 1 : amt);       // pad: (1, 0) or (amt, amt), :271-283; crop: [1:] or [amt:-amt], :285-307
+    return true;
+}
+inline bool adjust_map(int n1, int n2, int width, int height, AdjustMap* m) {
+    m->n1 = n1; m->n2 = n2;
+    return adjust_axis(n1, width, &m->o1) && adjust_axis(n2, height, &m->o2);
+}
+
 // model.hip
 ttc_status model_alloc(ttc_ctx* c);
 ttc_status model_load(ttc_ctx* c, const ttc_tensor* t, int n);

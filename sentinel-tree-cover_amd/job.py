@@ -148,8 +148,17 @@ def superresolve_large_tile(arr, sess):
     the superresolve tensor names stays available for callers that keep the reference's own Python loop)."""
     ctx, t = sess.ctx, sess.ctx.torch
     if isinstance(arr, t.Tensor):
-        if arr.dtype != t.float32 or not arr.is_contiguous():
-            raise ValueError("superresolve_large_tile: a cuda tensor must be contiguous float32 [T, X, Y, 10]")
+        if not arr.is_cuda:                                  # a host tensor takes the numpy route (its data_ptr() is not a device address)
+            a = arr.detach().numpy()
+            if a.ndim != 4 or a.shape[-1] != 10 or a.dtype != np.float32:
+                raise ValueError(f"superresolve_large_tile: expected a float32 (T, X, Y, 10) tensor, got {a.dtype} {tuple(a.shape)}")
+            superresolve_large_tile(a, sess)                 # shares the tensor's memory: refined in place
+            return arr
+        if arr.device.index != ctx.device:
+            raise ValueError(f"superresolve_large_tile: the tensor lives on {arr.device}, the session on cuda:{ctx.device}")
+        if arr.dtype != t.float32 or not arr.is_contiguous() or arr.dim() != 4 or int(arr.shape[-1]) != 10:
+            raise ValueError(f"superresolve_large_tile: a cuda tensor must be contiguous float32 [T, X, Y, 10], got {arr.dtype} {tuple(arr.shape)}"
+                             " (slice the band axis and call .contiguous() for the job's 17-channel stack)")
         ctx.superresolve_tile(arr, quirks=True)
         return arr
     a = np.asarray(arr)
@@ -423,18 +432,25 @@ class PinnedArena:
 
 
 def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None, want_clouds=True):
-    """Generator over load_raw_tile(x, y, local_path) for (x, y) in coords, read AHEAD by a small thread pool: the HDF5 reader is
+    """Iterator over load_raw_tile(x, y, local_path) for (x, y) in coords, read AHEAD by a small thread pool: the HDF5 reader is
     host C++ behind ctypes (the GIL is released for the duration of the call), so `workers` tiles are parsed / inflated in
     parallel while the GPU works on earlier ones -- feed it to predict_tiles.  At most `ahead` (default 2 x workers) tiles are
     resident.  Order is preserved; a failed read raises when its tile is reached.
     arena (PinnedArena with MORE sets than `ahead` + the tiles predict_tiles keeps in flight): the uploaded arrays are read into
-    its page-locked sets (raw["_arena_set"] names the set; predict_tiles(arena=...) releases it when the tile is finished)."""
+    its page-locked sets (raw["_arena_set"] names the set; predict_tiles(arena=...) releases it when the tile is finished).
+    A plain function that returns a generator: `arena.ahead` is set HERE, before the first next(), so that predict_tiles' up-front
+    size check sees the real read-ahead; closing the generator (or abandoning the loop: predict_tiles closes it on any
+    exception) waits for the reads in flight and hands their sets back to the arena."""
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     coords = list(coords)
     ahead = int(ahead) if ahead else 2 * int(workers)
+    if ahead < 1:
+        raise ValueError("iter_raw_tiles: ahead must be >= 1")
     if arena is not None:
         arena.ahead = ahead                      # predict_tiles checks the arena's size against ahead + its own depth
+        if len(arena.sets) < ahead + 1:
+            raise ValueError(f"iter_raw_tiles: the PinnedArena has {len(arena.sets)} sets for {ahead} tiles read ahead (+ the consumer's own)")
 
     def load(xy, aset):
         raw = load_raw_tile(xy[0], xy[1], local_path, alloc=arena.allocator(aset) if arena is not None else None, want_clouds=want_clouds)
@@ -442,21 +458,43 @@ def iter_raw_tiles(coords, local_path, workers=4, ahead=None, arena=None, want_c
             raw["_arena_set"] = aset
         return raw
 
-    def submit(pool, xy):                       # sets are taken in tile order, on the consumer's thread
-        return pool.submit(load, xy, arena.acquire() if arena is not None else None)
-    with ThreadPoolExecutor(max_workers=int(workers)) as pool:
-        q = deque()
-        it = iter(coords)
-        for xy in it:
-            q.append(submit(pool, xy))
-            if len(q) >= ahead:
-                break
-        while q:
-            raw = q.popleft().result()
-            nxt = next(it, None)
-            if nxt is not None:
-                q.append(submit(pool, nxt))
-            yield raw
+    def gen():
+        q = deque()                             # (future, arena set | None) of the tiles read ahead and not yet handed out
+
+        def submit(pool, xy):                   # sets are taken in tile order, on the consumer's thread
+            aset = arena.acquire() if arena is not None else None
+            try:
+                q.append((pool.submit(load, xy, aset), aset))
+            except BaseException:
+                if aset is not None:
+                    arena.release(aset)
+                raise
+        with ThreadPoolExecutor(max_workers=int(workers)) as pool:
+            try:
+                it = iter(coords)
+                for xy in it:
+                    submit(pool, xy)
+                    if len(q) >= ahead:
+                        break
+                while q:
+                    fut, aset = q[0]
+                    raw = fut.result()           # a failed read raises here with its set still in q: released below
+                    q.popleft()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        submit(pool, nxt)
+                    yield raw                    # from here on the set belongs to the consumer (predict_tiles releases it)
+            finally:
+                for fut, aset in q:              # abandoned (GeneratorExit) or failed: un-yielded reads give their sets back
+                    fut.cancel()
+                    try:
+                        fut.result()             # a read that already started still writes into the set: wait for it
+                    except BaseException:
+                        pass
+                    if aset is not None:
+                        arena.release(aset)
+                q.clear()
+    return gen()
 
 
 def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True, sampler="reference", cloudshad=None):
@@ -476,10 +514,19 @@ def process_tile(raw, sess, forest_mask=None, urban_masks=None, make_shadow=True
     s2_10 = adjust_shape(raw["s2_10"], width, height)
     if s2_10.ndim == 3:
         s2_10 = s2_10[np.newaxis]
-    s1 = ctx.s1_to_db(np.ascontiguousarray(adjust_shape(raw["s1"], width, height)))               # :699-708
-    dem = ctx.median5(np.ascontiguousarray(adjust_shape(np.asarray(raw["dem"], dtype=np.float32), width, height)))   # :713
+    # the reference scales Sentinel-1 (the per-image median over the image AS STORED) and median-filters the DEM BEFORE adjust_shape
+    # re-grids them (:699-721): same order here, the re-gridding on the device (ttc_adjust_shape)
+    s1 = ctx.adjust_shape(ctx.s1_to_db(np.ascontiguousarray(raw["s1"])), width, height)            # :699-708, :718
+    dem = ctx.adjust_shape(ctx.median5(np.ascontiguousarray(raw["dem"], dtype=np.float32)), width, height).contiguous()   # :713, :721
     clm = ctx.sen2cor_clean(np.asarray(raw["clm"], dtype=np.float32)) if raw.get("clm") is not None else None      # :688-697
     dates = np.array(raw["dates"], copy=True)
+    if s2_10.shape[0] != s2_20.shape[0] or len(dates) != s2_20.shape[0]:
+        raise ValueError(f"process_tile: s2_10 holds {s2_10.shape[0]} dates, s2_20 {s2_20.shape[0]}, the date list {len(dates)}")
+    if tuple(s2_10.shape[1:3]) != (width, height):
+        raise ValueError(f"process_tile: adjust_shape (job.py:260-310) cannot bring the 10 m bands {tuple(np.asarray(raw['s2_10']).shape)} onto the "
+                         f"{width} x {height} grid of the 20 m stack (an odd difference of 3 or more: the reference raises there too)")
+    if cloudshad is not None and tuple(np.shape(cloudshad)) != (s2_20.shape[0], width, height):
+        raise ValueError(f"process_tile: the given cloud / shadow mask is {tuple(np.shape(cloudshad))}, the tile is {(s2_20.shape[0], width, height)}")
     clouds = np.array(raw["clouds"], copy=True) if raw.get("clouds") is not None else np.zeros((len(dates), 1, 1), np.float32)
     s2 = ctx.upsample_20m(ctx.to_float32(np.ascontiguousarray(s2_10)), ctx.to_float32(np.ascontiguousarray(s2_20)))  # :727-782
     interp = None
@@ -654,6 +701,7 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
         raise ValueError("predict_tiles: every session must live on the same device (shard tiles across ranks with shard.py)")
     streams = [t.cuda.Stream(device=dev) for _ in sessions]
     depth = int(depth) if depth else 2 * len(sessions)
+    # iter_raw_tiles(arena=...) has set arena.ahead by the time it RETURNS (it is not a generator function), so this check sees it
     if arena is not None and len(arena.sets) < getattr(arena, "ahead", 0) + depth + 2:
         raise ValueError(f"predict_tiles: the PinnedArena has {len(arena.sets)} sets but the loop keeps up to "
                          f"{getattr(arena, 'ahead', 0)} tiles read ahead + {depth} in flight: it needs >= {getattr(arena, 'ahead', 0) + depth + 2}")
@@ -770,7 +818,21 @@ def predict_tiles(tiles, sessions, size=SIZE, sampler="expected", to_host=True, 
     try:
         return loop()
     except BaseException:
-        if arena is not None:                     # hand the sets of unfinished tiles back: an abandoned loop must not starve the next one
+        # an abandoned loop must not starve the next one on the same arena: (1) close the tile iterator -- iter_raw_tiles then waits for
+        # its reads in flight and releases the sets of the tiles it read ahead; (2) wait for the streams, because the sets of the pending
+        # tiles may still be the SOURCE of queued H2D copies; (3) hand those sets back
+        close = getattr(it, "close", None)
+        if close is not None:
+            try:
+                close()
+            except BaseException:
+                pass
+        if arena is not None:
+            for st in streams:
+                try:
+                    st.synchronize()
+                except BaseException:
+                    pass
             for rec in pending:
                 if isinstance(rec[1], dict) and rec[1].get("_arena_set") is not None:
                     arena.release(rec[1]["_arena_set"])

@@ -186,3 +186,29 @@ def synth_raw_files(seed=91, T=6, w20=40, h20=44, with_clm=True):
         clm[1, 5:12, 6:15] = 1.0; clm[2, 5:12, 6:15] = 1.0                # "two in a row" -> dropped (job.py:691-697)
         clm[min(4, T - 1), 20:30, 10:22] = 1.0
     return {"s2_10": s2_10, "s2_20": s2_20, "s1": s1u, "dem": dem.astype(np.float32), "dates": np.asarray(dates), "clouds": clouds, "clm": clm}
+
+
+def misshape_raw(raw, d10=(1, -1), ds1=(2, 1), ddem=(-1, 2)):
+    """`raw` (synth_raw_files) with the 10 m bands, Sentinel-1 and the DEM a pixel or two OFF the grid of the 20 m stack -- the case
+    adjust_shape (job.py:260-310) exists for: d* = (rows, cols) to add (reflect-padded at both ends) or to take away (cropped at both
+    ends).  Saturated Sentinel-1 samples are planted in rows that a crop removes, so that the order "per-image median over the image as
+    stored, THEN adjust_shape" (job.py:699-718) shows in the result."""
+    def grow(a, ax, d):
+        if d == 0:
+            return a
+        if d > 0:
+            pad = [(0, 0)] * a.ndim
+            pad[ax] = (d - d // 2, d // 2)
+            return np.pad(a, pad, mode="reflect")
+        d = -d
+        sl = [slice(None)] * a.ndim
+        sl[ax] = slice(d // 2, a.shape[ax] - (d - d // 2))
+        return a[tuple(sl)]
+    out = dict(raw)
+    out["s2_10"] = np.ascontiguousarray(grow(grow(raw["s2_10"], 1, d10[0]), 2, d10[1]))
+    s1 = np.ascontiguousarray(grow(grow(raw["s1"], 1, ds1[0]), 2, ds1[1]))
+    s1[3, 0, :, :] = 65535                       # first row: removed by a 1-pixel or an even crop
+    s1[5, :, 0, 0] = 65535
+    out["s1"] = s1
+    out["dem"] = np.ascontiguousarray(grow(grow(raw["dem"], 0, ddem[0]), 1, ddem[1]))
+    return out

@@ -231,3 +231,97 @@ def test_predict_tiles_pipeline_matches_per_tile_calls():
     print(f"[parity] predict_tiles: {len(tiles)} tiles on 2 sessions, {n_staged} re-run through the staged path, order and rasters match")
     for sx in sessions + [solo]:
         sx.close()
+
+
+@pytest.mark.parametrize("n10", [617, 619, 620])
+def test_tile_loop_reconciles_raw_shapes(n10):
+    """a raw folder whose arrays are not all on one grid -- the case adjust_shape (job.py:260-310) exists for -- through the
+    tile loop's FAST path.  The 20 m stack is 309 px (the tile is 618), the 10 m bands are 617 / 619 / 620 px, Sentinel-1 is two rows long and
+    one column short, the DEM one row long and one column short: ttc_predict_tile_shaped keys the grid on the 20 m stack (:716-717) and
+    re-indexes the others inside its decode passes.  Against the chained oracle (restate_e2e.single_call_chain, whose adjust_shape and the
+    scale-then-adjust order are pinned to the reference by tests/test_oracle_tile.py): model inputs of all 36 windows, probabilities of
+    the four corner windows + one interior window, status words clean."""
+    import torch
+    from scipy import ndimage as ndi
+    from oracle import restate_e2e as E, restate_model as M
+    from ttc import job, weights as Wt
+    Tn, size, L = 4, SIZE, 4
+    s2_10, s2_20, mask, dates, s1, dem90 = bench_tile(1236, dates_T=Tn)
+    assert s2_20.shape[1:3] == (309, 309)
+    d = n10 - TILE
+    raw = synth.misshape_raw({"s2_10": s2_10, "s2_20": s2_20, "s1": s1, "dem": (dem90 * 90.0).astype(np.float32), "dates": dates},
+                             d10=(d, 1 if d == 2 else -d), ds1=(2, -1), ddem=(1, -1))
+    assert raw["s2_10"].shape[1] == n10 and raw["s1"].shape[1:3] == (620, 617) and raw["dem"].shape == (619, 617)
+    sessions = [job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=L, max_windows=36) for _ in range(2)]
+    res = job.predict_tiles([(raw, mask), (raw, mask)], sessions, size=size, want_status=True)
+    assert [r[3] for r in res] == [False, False] and all(int(r[2][k]) == 0 for r in res for k in (0, 2, 3))
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][1].shape == (TILE, TILE)
+    # the same tile once more through the context call, with the model feed and the pre-rounding windows
+    ctx = sessions[0].ctx
+    dem_f = ctx.median5(raw["dem"])
+    u8, f32, frames, status = ctx.predict_tile_raw(raw["s2_10"], raw["s2_20"], raw["s1"], ctx.divide(dem_f.clone(), 90.0), mask, dates,
+                                                   job.min_all, job.max_all, size, want_float=True, want_inputs=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(u8.cpu().numpy(), res[0][1])
+    got_raw = ctx.debug_fetch("pt_windows_raw", (36, size, size))
+    frames = frames.cpu().numpy()
+    net = M.TreeCoverNet(Wt.synth_weights(0), dtype=torch.float32)
+    ds = M.DSen2Lite(Wt.load_dsen2(), dtype=torch.float32)
+    dem90_file = (ndi.median_filter(raw["dem"], size=5) / np.float32(90.0)).astype(np.float32)          # job.py:713, :993 on the file's own grid
+    ref = E.single_call_chain(raw["s2_10"], raw["s2_20"], raw["s1"], dem90_file, mask, dates, net, ds, size=size, length=L,
+                              only_windows={0, 5, 14, 30, 35})
+    fd = 0.0
+    for i, k in enumerate(ref["order"]):
+        if k in ref["feeds"]:
+            fd = max(fd, float(np.abs(frames[i][:, :, 1:-1, 1:-1].transpose(0, 2, 3, 1) - ref["feeds"][k]).max()))
+    ws = window_stats(got_raw, ref)
+    print(f"[parity] shapes 10 m {raw['s2_10'].shape[1:3]} / S1 {raw['s1'].shape[1:3]} / DEM {raw['dem'].shape} on a 618 tile: "
+          f"model inputs max|d| = {fd:.2e}, windows max|dprob| = {ws['max']:.2e} over {ws['n']} px")
+    assert fd < FEED_TOL["fp32"], fd
+    assert ws["max"] <= TOL["fp32"] and ws["n"] >= 5 * size * size - 10, ws
+    for sx in sessions:
+        sx.close()
+
+
+def test_fast_path_refuses_what_adjust_shape_cannot_reconcile():
+    """a mask that is not on the tile's grid, date counts that disagree, a 10 m array 3 px off (the reference's adjust_shape leaves the wrong
+    length there and process_tile raises): each is an error naming the array, never a silent read with the wrong strides"""
+    from ttc import job, weights as Wt
+    size = 30
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=4, dsen2_weights=None)
+    ctx = sess.ctx
+    raw = synth.synth_raw_files(91, 4, 40, 44, False)
+    T, X, Y = 4, 80, 88
+    mask = np.zeros((T, X, Y), np.float32)
+    dem = np.zeros((X, Y), np.float32)
+    args = lambda **kw: dict(dict(s2_10=raw["s2_10"], s2_20=raw["s2_20"], s1=raw["s1"], dem=dem, mask=mask, dates=raw["dates"]), **kw)  # noqa: E731
+
+    def call(**kw):
+        a = args(**kw)
+        return ctx.predict_tile_raw(a["s2_10"], a["s2_20"], a["s1"], a["dem"], a["mask"], a["dates"], job.min_all, job.max_all, size)
+    call()                                                                   # the well-formed tile goes through
+    with pytest.raises(ValueError, match="mask"):
+        call(mask=mask[:, :-1])
+    with pytest.raises(ValueError, match="mask"):
+        call(mask=mask[:-1])
+    with pytest.raises(ValueError, match="dates"):
+        call(dates=raw["dates"][:-1])
+    with pytest.raises(ValueError, match="s2_10"):
+        call(s2_10=raw["s2_10"][:-1])
+    with pytest.raises(ValueError, match="s1"):
+        call(s1=raw["s1"][:6])
+    with pytest.raises(ValueError, match="uint16"):
+        call(s2_10=raw["s2_10"].astype(np.float32))
+    with pytest.raises(RuntimeError, match="s2_10 is 83 x 88"):
+        call(s2_10=np.pad(raw["s2_10"], ((0, 0), (3, 0), (0, 0), (0, 0))))
+    with pytest.raises(RuntimeError, match="dem is 80 x 85"):
+        call(dem=dem[:, :-3])
+    # the tile loop: same errors, and the staged mirror refuses the same inputs
+    with pytest.raises(ValueError, match="mask"):
+        job.predict_tiles([(raw, mask[:, 1:])], [sess], size=size)
+    with pytest.raises(ValueError, match="mask"):
+        job.process_tile(dict(raw, clouds=None), sess, cloudshad=mask[:, 1:], sampler="expected")
+    with pytest.raises(ValueError, match="10 m bands"):
+        job.process_tile(dict(raw, clouds=None, s2_10=np.pad(raw["s2_10"], ((0, 0), (3, 0), (0, 0), (0, 0)))), sess, sampler="expected")
+    sess.close()

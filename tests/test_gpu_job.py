@@ -61,6 +61,15 @@ def test_superresolve_large_tile_dropin():
     assert out is d and np.abs(d.cpu().numpy() - ref).max() < 5e-5
     with pytest.raises(ValueError):
         job.superresolve_large_tile(np.zeros((2, 8, 8, 9), np.float32), sess)
+    # the tensor branch validates like the numpy branch -- a HOST tensor never reaches the device kernels as a pointer (it takes the
+    # numpy route and is refined in place), a tensor that is not [T, X, Y, 10] is refused instead of being read with stride 10
+    import torch
+    ht = torch.from_numpy(arr.copy())
+    assert job.superresolve_large_tile(ht, sess) is ht and np.abs(ht.numpy() - ref).max() < 5e-5
+    for bad in (torch.zeros((2, 8, 8, 11), device="cuda"), torch.zeros((8, 8, 10), device="cuda"),
+                torch.zeros((2, 8, 8, 17), device="cuda")[..., :10], torch.zeros((2, 8, 8, 10), device="cuda", dtype=torch.float64)):
+        with pytest.raises(ValueError):
+            job.superresolve_large_tile(bad, sess)
 
 
 def test_tile_loop_honours_sen2cor_mask():
@@ -94,3 +103,61 @@ def test_arena_size_is_checked_up_front():
     arena.ahead = 8
     with pytest.raises(ValueError, match="PinnedArena"):
         job.predict_tiles([], [sess], size=30, arena=arena)
+
+
+def test_arena_is_sized_through_the_real_reader_and_survives_an_abandoned_loop(tmp_path):
+    """(1) iter_raw_tiles sets arena.ahead BEFORE the first next() (it is a plain function returning a generator), so predict_tiles'
+    up-front check refuses an undersized arena instead of stalling 120 s in acquire(); (2) a loop that dies half way hands every set back --
+    the ones of the tiles in flight and the ones iter_raw_tiles had read ahead -- so the next loop on the same arena runs."""
+    import importlib.util
+    import os
+    import torch
+    from ttc import job, weights as Wt
+    from tests.helpers import ROOT
+    spec = importlib.util.spec_from_file_location("write_hdf5_fixture", os.path.join(ROOT, "tools", "write_hdf5_fixture.py"))
+    WF = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(WF)
+    size = 30
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=4)
+    raw = synth.synth_raw_files(92, 4, 40, 44, False)
+    coords = [(10 + i, 20) for i in range(6)]
+    for (x, y) in coords:
+        idx = f"{x}X{y}Y"
+        for rel, a in {f"clouds/clouds_{idx}.hkl": raw["clouds"], f"s1/{idx}.hkl": raw["s1"], f"s2_10/{idx}.hkl": raw["s2_10"],
+                       f"s2_20/{idx}.hkl": raw["s2_20"], f"misc/dem_{idx}.hkl": raw["dem"],
+                       f"misc/s2_dates_{idx}.hkl": np.asarray(raw["dates"], dtype=np.int64)}.items():
+            w = WF.Writer()
+            w.finish({"data": w.contiguous_dataset(np.ascontiguousarray(a))}, str(tmp_path / str(x) / str(y) / "raw" / rel))
+    local = f"{tmp_path}/"
+    # (1) undersized: 2 workers read 4 ahead, the loop keeps 2 in flight -> needs 8 sets
+    small = job.PinnedArena(torch, 5)
+    it = job.iter_raw_tiles(coords, local, workers=2, arena=small, want_clouds=False)
+    assert small.ahead == 4
+    with pytest.raises(ValueError, match="PinnedArena"):
+        job.predict_tiles(((r, None) for r in it), [sess], size=size, arena=small)
+    it.close()
+    assert all(small.free)
+    # (2) abandoned loop
+    arena = job.PinnedArena(torch, 8)
+
+    class Boom(RuntimeError):
+        pass
+
+    def tiles():
+        src = job.iter_raw_tiles(coords, local, workers=2, arena=arena, want_clouds=False)
+        try:
+            for k, r in enumerate(src):
+                if k == 3:
+                    raise Boom("the caller's generator fails on the fourth tile")
+                yield r, None
+        finally:
+            src.close()
+    with pytest.raises(Boom):
+        job.predict_tiles(tiles(), [sess], size=size, arena=arena)
+    assert all(arena.free), arena.free
+    res = job.predict_tiles(((r, None) for r in job.iter_raw_tiles(coords, local, workers=2, arena=arena, want_clouds=False)), [sess],
+                            size=size, arena=arena)
+    assert len(res) == len(coords) and all(arena.free)
+    for r in res[1:]:
+        np.testing.assert_array_equal(r[1], res[0][1])
+    sess.close()

@@ -158,3 +158,44 @@ def test_errors_are_loud():
         _lib.Context(win_in=44, win_rows=50, length=1, max_windows=1)
     with pytest.raises(RuntimeError, match="precision"):
         _lib.Context(win_in=44, length=1, max_windows=1, precision=7)
+
+
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_non_finite_window_stays_in_its_window(form):
+    """the Winograd kernels clamp pad channels / out-of-plane patch positions onto in-plane values instead of staging zeros.
+    A NaN in ONE window (at the plane's last pixel of the last channel: the position those clamped reads land on) makes THAT window's
+    probabilities NaN in every form -- its GroupNorm statistics span the window, as in the reference -- and leaves the other windows of
+    the batch bit-identical to a clean run (include/ttc.h, "Non-finite inputs")."""
+    from ttc import _lib, weights as Wt
+    W, L, N = 44, 2, 3
+    ctx = _lib.Context(win_in=W, length=L, max_windows=N, fp32_conv_form=form)
+    ctx.load_weights(Wt.synth_weights(3))
+    x = synth.synth_windows(seed=4, N=N, L=L, W=W)
+    clean = ctx.forward_windows(x).cpu().numpy()
+    bad = x.copy()
+    bad[1, :, W - 1, W - 1, 16] = np.nan
+    got = ctx.forward_windows(bad).cpu().numpy()
+    assert np.isnan(got[1]).all()
+    np.testing.assert_array_equal(got[[0, 2]], clean[[0, 2]])
+    np.testing.assert_array_equal(ctx.forward_windows(x).cpu().numpy(), clean)        # nothing non-finite is left behind in the workspace
+    ctx.close()
+
+
+def test_create_v2_accepts_an_older_shorter_config():
+    """ttc_config grows at its end; ttc_create_v2 takes the caller's sizeof -- a binding built against the round-2 header
+    (fields up to win_rows) gets the defaults for everything newer, a struct longer than the library's is refused"""
+    import ctypes as C
+    from ttc import _lib
+    lib = _lib.load()
+    cfg = _lib.TTCConfig(44, 1, 1, 17, 32, 64, 0.75, 0, 0, 0, 0, 0, 0)
+    # poison the tail the "old" caller does not know: v2 must not read it
+    cfg.fp32_conv_form, cfg.dsen2_precision, cfg.two_term_layers = 77, 99, 0xFFFF
+    old_size = _lib.TTCConfig.one_term_layers.offset
+    h = C.c_void_p()
+    assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), old_size) == 0, lib.ttc_last_error(h)
+    lib.ttc_destroy(h)
+    h = C.c_void_p()
+    assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), C.sizeof(cfg) + 8) == 1 and not h       # TTC_ERR_ARG, no context
+    assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), 8) == 1
+    assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), C.sizeof(cfg)) == 1 and h                # the full struct IS read: 77 is refused
+    lib.ttc_destroy(h)

@@ -116,3 +116,51 @@ def test_raw_to_raster_end_to_end_vs_oracle():
     d = np.abs(got_u8.astype(int) - want_u8.astype(int))
     print(f"[parity] raw -> uint8 raster: > 1 count {np.mean(d > 1):.2e}, == 1 count {np.mean(d == 1):.2e}")
     assert (d > 1).mean() < 1e-4 and (d > 0).mean() < 3e-2
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_process_tile_reconciles_shapes_like_reference(sess, tag):
+    """the staged mirror on raw arrays a pixel or two off the 20 m grid, against the REFERENCE's process_tile (process_tile_shapes.npz,
+    tools/gen_golden_shapes.py): Sentinel-1 scaled and the DEM filtered on their own grids, THEN re-gridded (job.py:699-721) -- on the device
+    (ttc_adjust_shape)"""
+    from ttc import job
+    g = golden("process_tile_shapes.npz")
+    seed, T, w20, h20, *d = (int(v) for v in g[f"{tag}_cfg"])
+    raw = synth.misshape_raw(synth.synth_raw_files(seed, T, w20, h20, False), d[0:2], d[2:4], d[4:6])
+    random.seed(4)
+    s2, dates, interp, s1, dem, cloudshad, snow = job.process_tile(dict(raw, clouds=None), sess)
+    np.testing.assert_array_equal(dates, g[f"{tag}_dates"])
+    shp = tuple(int(v) for v in g[f"{tag}_cloudshad_shape"])
+    np.testing.assert_array_equal(cloudshad.cpu().numpy() > 0, np.unpackbits(g[f"{tag}_cloudshad"])[:np.prod(shp)].reshape(shp).astype(bool))
+    np.testing.assert_array_equal(interp.cpu().numpy()[:, ::2, ::2], g[f"{tag}_interp_sub"])
+    np.testing.assert_array_equal(dem.cpu().numpy(), g[f"{tag}_dem"])
+    e1 = np.abs(s1.cpu().numpy() - g[f"{tag}_s1"]).max()
+    s2n = s2.cpu().numpy()
+    e2 = np.abs(s2n[:, ::3, ::3, :] - g[f"{tag}_s2_sub"])
+    edges = np.concatenate([s2n[:, :2].reshape(s2n.shape[0], -1), s2n[:, -2:].reshape(s2n.shape[0], -1),
+                            s2n[:, :, :2].reshape(s2n.shape[0], -1), s2n[:, :, -2:].reshape(s2n.shape[0], -1)], 1)
+    e3 = np.abs(edges - g[f"{tag}_s2_edges"]).max()
+    print(f"[parity] process_tile shapes {tag}: s1 max|d| = {e1:.2e} (whole array), s2 max|d| = {e2.max():.2e}, edge rows / columns {e3:.2e}")
+    assert e1 < 2e-6 and e2.max() < 1e-5 and e2.mean() < 1e-7 and e3 < 1e-5
+
+
+def test_adjust_shape_on_the_device_matches_reference():
+    """ttc_adjust_shape against the reference's own adjust_shape outputs (adjust_shape.npz): identical where the rule reaches the requested
+    size, TTC_ERR_ARG where it does not"""
+    from ttc import _lib
+    ctx = _lib.Context(win_in=44, length=1, max_windows=1)
+    g = golden("adjust_shape.npz")
+    n_ok = n_bad = 0
+    for i in range(int(g["n"])):
+        a, want = g[f"c{i}_in"], g[f"c{i}_out"]
+        w, h = (int(v) for v in g[f"c{i}_want"])
+        a4 = a[:, :, :, None] if a.ndim == 3 else (a[None, :, :, None] if a.ndim == 2 else a)
+        if all(abs(n - t) in (0, 1) or abs(n - t) % 2 == 0 for n, t in ((a4.shape[1], w), (a4.shape[2], h))):
+            np.testing.assert_array_equal(ctx.adjust_shape(a, w, h).cpu().numpy().squeeze(), want)
+            n_ok += 1
+        else:
+            with pytest.raises(RuntimeError, match="adjust_shape"):
+                ctx.adjust_shape(a, w, h)
+            n_bad += 1
+    assert n_ok >= 60 and n_bad >= 6
+    ctx.close()
