@@ -69,20 +69,24 @@ def wino4_on():
     return winograd_on() and os.environ.get("TTC_WINO4", "1") != "0"
 
 
-def pmc_traffic(precision, win):
-    """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the timed
-    process).  Only valid for the configuration the counters were collected on."""
-    for name in {"fp32": (("r05_pmc_conv_f32_gates.json",) if wino4_on() else ("r04_pmc_conv_f32_gates.json",)) if winograd_on() else ("r03_pmc_conv_f32_gates.json",),
-                 "fp16": ("r04_pmc_conv_h16_gates.json", "r03_pmc_conv_h16_gates.json")}.get(precision, ()):
-        p = os.path.join(ROOT, "profiles", name)
-        if win == 172 and os.path.exists(p):
-            with open(p) as f:
-                d = json.load(f)
-            return d["traffic_bytes_per_launch"], name
+def pmc_traffic(precision, win, length=4):
+    """HBM bytes per conv_gates launch from the committed PMC passes (profiles/; rocprofv3 cannot run inside the timed process): the newest
+    profiles/r*_pmc_gates_<precision>_w<win>_l<length>.json (tools/pmc_json.py; separate --pmc passes, FETCH_SIZE x 2 on gfx950), else -- for the
+    default geometry -- the files of earlier rounds.  Only valid for the kernel the counters were collected on: the file names it."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gates_%s_w%d_l%d.json" % (precision, win, length))))
+    if not cands and win == 172 and length == 4:
+        legacy = {"fp32": (("r05_pmc_conv_f32_gates.json",) if wino4_on() else ("r04_pmc_conv_f32_gates.json",)) if winograd_on() else ("r03_pmc_conv_f32_gates.json",),
+                  "fp16": ("r04_pmc_conv_h16_gates.json", "r03_pmc_conv_h16_gates.json")}.get(precision, ())
+        cands = [os.path.join(ROOT, "profiles", n) for n in legacy if os.path.exists(os.path.join(ROOT, "profiles", n))][:1]
+    if cands:
+        with open(cands[-1]) as f:
+            d = json.load(f)
+        return d["traffic_bytes_per_launch"], os.path.relpath(cands[-1], ROOT)
     return None, None
 
 
-def roofline(precision, win, n_windows, gates_ms, gates_n, length=4):
+def roofline(precision, win, n_windows, gates_ms, gates_n, length=4, issued_lib=None):
     """dominant kernel family = the ConvGRU gates convolution (49 -> 64, both directions, all windows of a tile per launch).
     gates_ms is the mean over the L launches of a forward; the launch of step 0 (hidden state identically zero) convolves the 17
     frame channels only when the engine can skip channels (16-bit engine; fp32 Winograd), so the mean launch is priced at the
@@ -91,7 +95,7 @@ def roofline(precision, win, n_windows, gates_ms, gates_n, length=4):
     share = ((length - 1) + 17.0 / 49.0) / length if skip0 else 1.0
     flops = conv_gates_flops(win, n_windows) * share
     ach = flops / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0
-    traffic, src = pmc_traffic(precision, win)
+    traffic, src = pmc_traffic(precision, win, length)
     if precision == "fp32" and wino4_on():
         # Winograd F(4x4, 3x3) (conv3x3_wino4.hip): 36 / 144 of the direct form's multiply-accumulates.  `frac` is the matrix pipe's own
         # utilisation = the flops of the matrix instructions the kernel ISSUES / launch time / peak; `algorithmic_frac` keeps SURVEY 8(d)'s
@@ -101,6 +105,10 @@ def roofline(precision, win, n_windows, gates_ms, gates_n, length=4):
         # per workgroup tile: 8 waves x (6 full 8-channel chunks x 72 + one k-step of the 7th x 36) MFMAs for Cin = 49; 2 x 72 + 36 at step 0
         mfmas = wg_tiles * 8 * ((length - 1) * (6 * 72 + 36) + (2 * 72 + 36)) / length
         issued = mfmas * 2.0 * 16 * 16 * 4
+        if issued_lib:                       # the library's own count of the launches it made (conv_issued_flops); the formula above is its cross-check
+            if abs(issued_lib / issued - 1.0) > 0.02:
+                print(f"[bench] note: library-counted issued flops {issued_lib:.4g} vs the closed form {issued:.4g}", file=sys.stderr)
+            issued = issued_lib
         fi = issued / (gates_ms * 1e-3) / (FP32_MFMA_PEAK_TF * 1e12) if gates_ms > 0 else 0.0
         return {"kernel": "conv3x3_wino4<EPI_RAW> (ConvGRU gates, 49->64, both directions; Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32)",
                 "bound": "mfma", "achieved": issued / (gates_ms * 1e-3) / 1e12 if gates_ms > 0 else 0.0, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -136,11 +144,68 @@ def roofline(precision, win, n_windows, gates_ms, gates_n, length=4):
     # 7 chunks = 3 chunk pairs (28 K-block products each: tap 8 of the two hi-tile products shares a K block) + 1 single (15),
     # against 3 x 9 / 2 = 13.5 per chunk without any padding
     issued = 3.0 * conv_gates_flops(win, n_windows) * (10.0 / 9) * (((length - 1) * (56.0 / 49) * (99.0 / 105) + (24.0 / 49) * (43.0 / 45)) / length)   # step 0: 3 chunks = 1 pair (28) + 1 single (15) of 45
+    if issued_lib:
+        issued = issued_lib                  # conv_issued_flops_h16: K-block products of the launches really made (incl. the 512-position tile quantisation)
     return {"kernel": "conv3x3_h16<TERMS=3,NCG=2,EPI_RAW> (ConvGRU gates, 49->64, both directions)", "bound": "mfma", "achieved": ach,
             "peak": H16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / H16_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": src,
-            "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops,
+            "launch_ms": gates_ms, "launches_timed": gates_n, "flops_per_launch": flops, "mfma_flops_issued_per_launch": issued,
             "mfma_issue_frac": issued / (gates_ms * 1e-3) / (H16_MFMA_PEAK_TF * 1e12) if gates_ms > 0 else 0.0,
             "hbm_frac": nbytes / (gates_ms * 1e-3) / (HBM_PEAK_GBS * 1e9) if gates_ms > 0 else 0.0, "bytes_per_launch": nbytes}
+
+
+CONV_FAMILIES = ("conv_gates", "conv_cand", "conv_median", "conv_concat", "conv1", "conv2", "conv_up2", "conv_up2_out", "conv_up3", "out_conv",
+                 "dsen2_conv")          # the KTimer names of every conv-engine launch (model.hip, dsen2.hip)
+# rocprofv3 kernel name (prefix) of the ConvGRU gates launch per engine: the row of profiles/*_kernel_stats.md the roofline can be recomputed from
+GATES_KERNEL = {"fp32": "conv3x3_wino4<0, 0>", "fp16": "conv3x3_h16<0, 3, 2, 0, 1", "bf16": "conv3x3_h16<1, 3, 2, 0, 1"}
+
+
+def conv_table(ctx):
+    """per conv family of ONE context since the last reset: mean launch ms (HIP events on the launch stream), launches, and the flops of the
+    matrix instructions a launch issues (ttc_debug_kernel_flops: tiles x k-steps x flops per MFMA, padding included)"""
+    t = {}
+    for fam in CONV_FAMILIES:
+        ms, n = ctx.kernel_ms(fam)
+        fl, _ = ctx.kernel_flops(fam)
+        if n:
+            t[fam] = {"ms": ms, "n": int(n), "flops": fl}
+    return t
+
+
+def table_totals(t, tiles):
+    """-> (conv kernel ms per tile, matrix flops issued per tile) of a conv_table collected over `tiles` tiles"""
+    tiles = max(1, tiles)
+    return sum(v["ms"] * v["n"] for v in t.values()) / tiles, sum(v["flops"] * v["n"] for v in t.values()) / tiles
+
+
+def profile_ref():
+    """the committed rocprofv3 reference of this round (profiles/r*_bench_profile.json, written by tools/profile_ref.py from the kernel-stats
+    summaries of `bench.py --profile-leg isolated|live ...` runs): per leg the command, the stats file and every kernel's calls / average"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_profile.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
+def profile_check(leg, key, precision, bench_ms, tol=0.10):
+    """in-bench HIP-event time of the gates launch vs the committed rocprofv3 average of the SAME command's leg: the roofline's launch time
+    must be recomputable from a file under profiles/.  -> dict for the JSON line (agree = within `tol`)"""
+    ref, path = profile_ref()
+    if not ref or leg not in ref or not bench_ms:
+        return {"file": path, "leg": leg, "agree": None, "note": "no committed profile for this leg"}
+    ent = ref[leg].get(key) or {}
+    rows = [(k, v) for k, v in (ent.get("kernels") or {}).items() if k.startswith(GATES_KERNEL.get(precision, "?"))]
+    if not rows:
+        return {"file": path, "leg": leg, "agree": None, "note": "kernel row not in the committed profile (another engine / form was profiled)"}
+    name, row = rows[0]
+    ratio = bench_ms * 1e3 / row["avg_us"]
+    out = {"file": path, "stats_file": ent.get("stats_file"), "command": ent.get("command"), "kernel_row": name, "profile_avg_us": row["avg_us"],
+           "profile_calls": row["calls"], "bench_event_ms": bench_ms, "ratio_bench_over_profile": ratio, "tolerance": tol, "agree": abs(ratio - 1.0) <= tol}
+    if not out["agree"]:
+        print(f"[bench] WARNING: the {leg} gates launch measured {bench_ms * 1e3:.1f} us in this run, {row['avg_us']:.1f} us in {ent.get('stats_file')} "
+              f"(ratio {ratio:.3f}, tolerance {tol}): re-profile (tools/gpu_profiles.sh) before quoting roofline.frac from that file", file=sys.stderr, flush=True)
+    return out
 
 
 def oracle_pass(args, host_tile, weights, size=None, length=None, cache=None):
@@ -196,6 +261,9 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra legs (alt_fp16 / alt_bf16 / l12_w168 / preprocess_only)")
     ap.add_argument("--no-dprob", action="store_true", help="skip max |dprob| (HIP vs the oracle on windows of the bench's own tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle pass (also drops max_dprob_e2e)")
+    ap.add_argument("--profile-leg", choices=["isolated", "live"], default=None,
+                    help="run ONE leg only and exit (for rocprofv3: tools/gpu_profiles.sh): isolated = --steps tiles one after the other through one "
+                         "session; live = the headline's timed region (--inflight tiles in flight)")
     ap.add_argument("--job-level-only", action="store_true", help="run the job-level leg alone (files -> rasters -> GeoTIFFs) and print its JSON")
     ap.add_argument("--job-readers", type=int, default=4, help="host threads that read tile folders ahead in the job-level leg")
     ap.add_argument("--job-no-arena", action="store_true", help="job-level leg: stage the raw arrays through pinned buffers on the loop's thread instead of reading into a PinnedArena")
@@ -323,6 +391,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last = {}                     # conv-family table of the most recent measure() (sessions[0] only: its timers are the ones switched on)
+
     def measure(sessions, steps, warmup, flags=base_flags, size=args.win - 14, want_out=True):
         """W untimed + K timed steps bracketed by barrier + synchronize; -> (max-over-ranks seconds, gates ms, launches, flagged)"""
         ctx = sessions[0].ctx
@@ -346,6 +416,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         gates_ms, gates_n = ctx.kernel_ms("conv_gates")
+        last["table"], last["tiles"] = conv_table(ctx), steps       # sessions[0] ran one tile per step
         ctx.timing(0)
         bad = int(((status[..., 0] != 0) | (status[..., 2] != 0) | (status[..., 3] != 0)).sum().item())
         return shard.max_over_ranks(dt, dev, world), gates_ms, gates_n, bad
@@ -398,20 +469,57 @@ def main():
 
     iso_extra = {}
 
-    def isolated_gates(sess):
-        """the gates launch without a second tile competing for the CUs (informational)"""
+    def isolated_gates(sess, tiles=3):
+        """`tiles` tiles through ONE session with nothing else on the GPU: the launch times a rocprofv3 run of `--profile-leg isolated`
+        sees -- the reproducible basis of roofline.frac (with several tiles in flight the streams' kernels time-share the CUs and a launch's
+        duration depends on what the other streams happen to run).  -> mean gates launch ms; iso_extra['table'] = every conv family"""
         c0 = sess.ctx
-        c0.timing(2); c0.kernel_ms(None)
         tile = pool[0][1]
-        for _ in range(3):
+        c0.predict_tile_raw(tile["s2_10"], tile["s2_20"], tile["s1"], tile["dem"], tile["mask"], tile["dates"], job.min_all, job.max_all,
+                            sess.win_in - 14, dem_m=tile["dem_m"], flags=base_flags)          # warm (first use of this session after other legs)
+        torch.cuda.synchronize()
+        c0.timing(2); c0.kernel_ms(None)
+        t0 = time.perf_counter()
+        for k in range(tiles):
+            tile = pool[k % len(pool)][1]
             c0.predict_tile_raw(tile["s2_10"], tile["s2_20"], tile["s1"], tile["dem"], tile["mask"], tile["dates"], job.min_all, job.max_all,
                                 sess.win_in - 14, dem_m=tile["dem_m"], flags=base_flags)
         torch.cuda.synchronize()
+        iso_extra["tile_ms"] = (time.perf_counter() - t0) / tiles * 1e3      # with event timers on the conv launches: an upper bound
         ms, _ = c0.kernel_ms("conv_gates")
         ds_ms, ds_n = c0.kernel_ms("dsen2_conv")
+        iso_extra["table"], iso_extra["tiles"] = conv_table(c0), tiles
         c0.timing(0)
-        iso_extra["dsen2_conv"] = (ds_ms, ds_n // 3)          # mean launch, launches per tile (three tiles were run)
+        iso_extra["dsen2_conv"] = (ds_ms, ds_n // tiles)          # mean launch, launches per tile
         return ms
+
+    def leg_roofline(precision, win, length, sess, live_ms, live_n, step_ms, inflight, live_table, live_tiles, check_leg):
+        """the roofline object of one measured leg, every fraction recomputable from profiles/: `frac` / `achieved` / `launch_ms` are the
+        ISOLATED gates launch (one tile in flight; `profile` names the committed rocprofv3 row it must agree with), `live_*` the same
+        launch while `inflight` tiles share the GPU, `step_*` all conv launches of a step against the step's wall time"""
+        iso_ms = isolated_gates(sess)
+        tab = iso_extra["table"]
+        peak = FP32_MFMA_PEAK_TF if precision == "fp32" else H16_MFMA_PEAK_TF
+        r = roofline(precision, win, 36, iso_ms, tab.get("conv_gates", {}).get("n", 0), length, issued_lib=tab.get("conv_gates", {}).get("flops"))
+        rl = roofline(precision, win, 36, live_ms, live_n, length, issued_lib=tab.get("conv_gates", {}).get("flops"))
+        r["launch_basis"] = "isolated: one tile in flight (bench.py --profile-leg isolated is the same launch sequence under rocprofv3)"
+        r["live_launch_ms"], r["live_frac"], r["live_launches_timed"] = live_ms, rl["frac"], live_n
+        if "algorithmic_frac" in rl:
+            r["live_algorithmic_frac"] = rl["algorithmic_frac"]
+        r["live_note"] = "%d tiles in flight: the other streams' kernels share the CUs, so a launch's duration depends on what they run" % inflight
+        conv_ms_tile, issued_tile = table_totals(tab, iso_extra["tiles"])
+        _, issued_live = table_totals(live_table, live_tiles)
+        r["step"] = {"mfma_flops_issued_per_tile": issued_live or issued_tile, "ms_per_tile": step_ms / inflight,
+                     "achieved": (issued_live or issued_tile) * inflight / (step_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                     "frac": (issued_live or issued_tile) * inflight / (step_ms * 1e-3) / 1e12 / peak,
+                     "what": "matrix flops ISSUED by every conv launch of a tile (ConvGRU, U-Net, DSen2) x tiles per step / step wall time / MFMA peak"}
+        r["isolated_conv_families"] = {k: {"launch_ms": round(v["ms"], 4), "launches_per_tile": v["n"] // iso_extra["tiles"],
+                                           "mfma_gflop_issued_per_launch": round(v["flops"] / 1e9, 3),
+                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None} for k, v in tab.items()}
+        r["isolated_conv_ms_per_tile"], r["isolated_tile_ms"] = conv_ms_tile, iso_extra["tile_ms"]
+        r["profile"] = profile_check("isolated", check_leg, precision, iso_ms)
+        r["live_profile"] = profile_check("live", check_leg, precision, live_ms)
+        return r
 
     def hip_tile0(sess):
         """tile 0 through the timed entry point (ttc_predict_tile) -> model inputs, pre-rounding window probabilities"""
@@ -620,8 +728,25 @@ def main():
         return
 
     # ---- headline: EXACTLY K timed steps after W warm-up steps ------------------------------------------------------------
+    if args.profile_leg:
+        # what tools/gpu_profiles.sh runs under rocprofv3: ONE leg, nothing else in the process, so that a kernel's average in the stats file
+        # is the average of that leg's launches.  isolated = tiles one after the other through one session; live = the headline's timed region
+        if args.profile_leg == "isolated":
+            isolated_gates(sessions[0], tiles=max(3, args.steps))
+            print(json.dumps({"profile_leg": "isolated", "tiles": max(3, args.steps), "tile_ms_with_timers": iso_extra["tile_ms"],
+                              "conv_families": {k: {"launch_ms": v["ms"], "n": v["n"], "flops": v["flops"]} for k, v in iso_extra["table"].items()}}))
+        else:
+            dt, gates_ms, gates_n, bad = measure(sessions, args.steps, args.warmup)
+            print(json.dumps({"profile_leg": "live", "inflight": args.inflight, "steps": args.steps, "ms_per_step": dt / args.steps * 1e3,
+                              "conv_families": {k: {"launch_ms": v["ms"], "n": v["n"], "flops": v["flops"]} for k, v in last["table"].items()}}))
+        return
     dt, gates_ms, gates_n, bad = measure(sessions, args.steps, args.warmup)
-    iso_ms = isolated_gates(sessions[0]) if (args.inflight > 1 and rank == 0) else None
+    live_table, live_tiles = dict(last["table"]), last["tiles"]
+    head_roof = None
+    if rank == 0:
+        leg = "w%d_l%d_%s" % (args.win, args.length, args.precision)
+        head_roof = leg_roofline(args.precision, args.win, args.length, sessions[0], gates_ms, gates_n, dt / args.steps * 1e3, args.inflight,
+                                 live_table, live_tiles, leg)
     ref, cpu, stages = None, None, {}
     if world == 1 and not args.no_cpu_baseline:           # the CPU oracle pass (cpu_baseline + the e2e reference): N = 1 only
         ref, cpu = oracle_pass(args, host_tile, weights, cache=stages)
@@ -647,15 +772,17 @@ def main():
         close(sessions)
         for other in [p for p in ("fp16", "bf16", "fp32") if p != args.precision]:
             ss = make_sessions(other)
-            dt2, g2, _, _ = measure(ss, alt_steps, 2)
+            dt2, g2, gn2, _ = measure(ss, alt_steps, 2)
+            tab2, tiles2 = dict(last["table"]), last["tiles"]
             extra["alt_" + other] = {"precision": other, "dtype": DTYPES[other], "value": args.inflight * TILE * TILE * alt_steps / dt2, "unit": "px/s",
                                      "ms_per_step": dt2 / alt_steps * 1e3, "steps": alt_steps, "conv_gates_launch_ms": g2,
                                      "max_dprob": None if args.no_dprob else max_dprob(ss[0]),
                                      "max_dprob_e2e": None if args.no_dprob else dprob_e2e(ss[0], ref),
                                      "note": "same step with the other conv engine; informational, not the headline value"}
-            if other in ("fp16", "bf16"):
-                r16 = roofline(other, args.win, 36, g2, 0, args.length)
-                extra["alt_" + other]["roofline"] = {k: r16[k] for k in ("kernel", "achieved", "peak", "frac", "mfma_issue_frac", "hbm_frac")}
+            # the same object as the headline's: frac = the isolated launch (algorithmic flops against the dense 16-bit peak; mfma_issue_frac = the
+            # matrix instructions really issued), live_* with the tiles in flight, step.* = all conv launches against the step, traffic from the PMC passes
+            extra["alt_" + other]["roofline"] = leg_roofline(other, args.win, args.length, ss[0], g2, gn2, dt2 / alt_steps * 1e3, args.inflight, tab2, tiles2,
+                                                             "w%d_l%d_%s" % (args.win, args.length, other))
             close(ss)
         # the fp16 engine with the two ConvGRU convs on TWO products, x_hi * (w_hi + w_lo) (ttc_config.two_term_layers = 3):
         # an accuracy option inside the 1e-3 contract, outside the 2e-4 the default engines keep
@@ -681,16 +808,20 @@ def main():
                                                     "power-bound on the direct fp32 kernel) the fp16-pair engine"}
             close(ss)
         # BASELINE's "168x168", "12-step" wording: the 168-window / 12-step geometry (2.82 TFLOP of model per tile instead of 1.51)
-        l12 = {"win_in": 168, "length": 12, "model_tflop_per_tile": 36 * model_flops(168, 12) / 1e12}
+        l12 = {"win_in": 168, "length": 12, "model_tflop_per_tile": 36 * model_flops(168, 12) / 1e12,
+               "what": "BASELINE.json's literal geometry: 36 overlapping 168 x 168 windows, 12 ConvGRU steps (1.87 x the model work per pixel of the "
+                       "headline's 172 / L = 4, which is the reference code's default: SURVEY F6)"}
         ref12 = None
         if ref is not None and not args.no_dprob:           # the oracle at this geometry (gap-fill / DSen2 stages shared with the first pass)
             ref12, _ = oracle_pass(args, host_tile, weights, size=154, length=12, cache=stages)
         for prec in ("fp32", "fp16"):
             ss = make_sessions(prec, win=168, length=12)
-            steps12 = max(2, min(args.steps, 6))
-            dt3, g3, _, _ = measure(ss, steps12, 1, size=154)
+            steps12 = max(20, args.steps)                       # a first-class leg: as many timed steps as the headline, its own roofline
+            dt3, g3, gn3, _ = measure(ss, steps12, 2, size=154)
+            tab3, tiles3 = dict(last["table"]), last["tiles"]
             l12[prec] = {"value": args.inflight * TILE * TILE * steps12 / dt3, "unit": "px/s", "ms_per_step": dt3 / steps12 * 1e3, "steps": steps12,
-                         "conv_gates_launch_ms": g3, "max_dprob_e2e": dprob_e2e(ss[0], ref12)}
+                         "warmup": 2, "conv_gates_launch_ms": g3, "max_dprob_e2e": dprob_e2e(ss[0], ref12),
+                         "roofline": leg_roofline(prec, 168, 12, ss[0], g3, gn3, dt3 / steps12 * 1e3, args.inflight, tab3, tiles3, "w168_l12_%s" % prec)}
             close(ss)
         extra["l12_w168"] = l12
 
@@ -744,26 +875,20 @@ def main():
                 "win_in": args.win, "length": args.length, "dates": args.dates,
                 "model_tflop_per_tile": 36 * model_flops(args.win, args.length) / 1e12,
             },
-            "roofline": roofline(args.precision, args.win, 36, gates_ms, gates_n, args.length),
+            "roofline": head_roof,
         }
-        if iso_ms:
-            out["roofline"]["isolated_launch_ms"] = iso_ms
-            out["roofline"]["isolated_frac"] = out["roofline"]["frac"] * gates_ms / iso_ms
-            if out["roofline"].get("algorithmic_frac") is not None:
-                out["roofline"]["isolated_algorithmic_frac"] = out["roofline"]["algorithmic_frac"] * gates_ms / iso_ms
-            out["roofline"]["note"] = ("launch_ms / frac are live values with %d tiles in flight (kernels of the other tile share the CUs); "
-                                       "isolated_* = the same launch with one tile in flight" % args.inflight)
-            if iso_extra.get("dsen2_conv") and iso_extra["dsen2_conv"][1] > 0 and args.precision == "fp32":
-                # the largest kernel FAMILY of the fp32 tile by time: DSen2's six convs on the direct fp32 kernel (31 windows x T dates of 118 x 118)
-                ds_ms, ds_n = iso_extra["dsen2_conv"]
-                ds_flops = 2.0 * 9 * (10 * 32 + 4 * 32 * 32 + 32 * 6) * 118 * 118 * 31 * args.dates
-                ds_tf = ds_flops / (ds_ms * ds_n * 1e-3) / 1e12
-                out["roofline"]["other_families"] = {"dsen2_conv": {
-                    "kernel": "conv3x3_f32<CK,1,EPI_BIAS_*> direct implicit GEMM on v_mfma_f32_32x32x2_f32 (+ the 32 -> 6 head), one tile in flight",
-                    "ms_per_tile": ds_ms * ds_n, "launches_per_tile": ds_n, "flops_per_tile": ds_flops, "achieved": ds_tf,
-                    "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ds_tf / FP32_MFMA_PEAK_TF,
-                    "note": "direct form: issued = algorithmic flops; power-bound (1.84 GHz with the matrix pipe 83 % busy, DESIGN.md 7); "
-                            "ttc_config.dsen2_precision = fp16 runs these convs on the 16-bit engine (alt_fp32_dsen2_fp16)"}}
+        if iso_extra.get("dsen2_conv") and iso_extra["dsen2_conv"][1] > 0 and args.precision == "fp32":
+            # the largest kernel FAMILY of the fp32 tile by time: DSen2's six convs on the direct fp32 kernel (31 windows x T dates of 118 x 118)
+            ds_ms, ds_n = iso_extra["dsen2_conv"]
+            ds_flops = 2.0 * 9 * (10 * 32 + 4 * 32 * 32 + 32 * 6) * 118 * 118 * 31 * args.dates
+            ds_tf = ds_flops / (ds_ms * ds_n * 1e-3) / 1e12
+            out["roofline"]["other_families"] = {"dsen2_conv": {
+                "kernel": "conv3x3_f32<CK,1,EPI_BIAS_*> direct implicit GEMM on v_mfma_f32_32x32x2_f32 (+ the 32 -> 6 head), one tile in flight",
+                "ms_per_tile": ds_ms * ds_n, "launches_per_tile": ds_n, "flops_per_tile": ds_flops, "achieved": ds_tf,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ds_tf / FP32_MFMA_PEAK_TF,
+                "note": "direct form: issued = algorithmic flops up to tile padding (isolated_conv_families.dsen2_conv has the issued count); power-bound "
+                        "(1.84 GHz with the matrix pipe 83 % busy, DESIGN.md 7); ttc_config.dsen2_precision = fp16 runs these convs on the 16-bit engine "
+                        "(alt_fp32_dsen2_fp16)"}}
         out.update(extra)
         sus = extra.get("sustained") or {}
         if sus.get("value") and sus["value"] < 0.97 * out["value"]:

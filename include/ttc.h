@@ -445,6 +445,11 @@ ttc_status ttc_debug_fetch(ttc_ctx* ctx, const char* name, float* h_dst, size_t 
  * (cheap enough to leave on inside a timed benchmark region). */
 ttc_status ttc_debug_timing(ttc_ctx* ctx, int32_t enable);
 ttc_status ttc_debug_kernel_ms(ttc_ctx* ctx, const char* name, double* avg_ms, int64_t* launches);
+/* conv-engine families ("conv_gates", "conv_cand", the U-Net block names, "dsen2_conv") only: the flops of the MATRIX INSTRUCTIONS the
+ * average launch since the last reset issues -- workgroup tiles x k-steps x flops per MFMA with the padding the kernel really multiplies;
+ * the Winograd forms issue 2.25 / 4 multiply-accumulates where the direct form issues 9.  flops / avg_ms = the matrix pipe's rate, the
+ * number bench.py prices against the MFMA peak.  Collected under the same ttc_debug_timing levels. */
+ttc_status ttc_debug_kernel_flops(ttc_ctx* ctx, const char* name, double* flops_per_launch, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ EXPORTS = [
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
     "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error",
-    "ttc_create_v2", "ttc_predict_tile_shaped", "ttc_adjust_shape",
+    "ttc_create_v2", "ttc_predict_tile_shaped", "ttc_adjust_shape", "ttc_debug_kernel_flops",
 ]
 
 # exported for tools/probes and the detector-stage tests, declared in csrc/ttc_internal.h -- not part of the drop-in surface (include/ttc.h)
@@ -142,6 +142,7 @@ def load():
     lib.ttc_debug_timing.argtypes = [P, I32]
     lib.ttc_debug_knob.argtypes = [I32, I32]
     lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.ttc_debug_kernel_flops.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)          # AttributeError here == missing export
         if name not in ("ttc_version", "ttc_destroy", "ttc_last_error", "ttc_device_bytes", "ttc_read_hkl_error"):
@@ -768,3 +769,9 @@ class Context:
         self._check(self.lib.ttc_debug_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(cnt)),
                     "ttc_debug_kernel_ms")
         return ms.value, cnt.value
+
+    def kernel_flops(self, name):
+        """-> (matrix-instruction flops ISSUED per launch of the conv family `name`, launches noted) since the last kernel_ms(None)"""
+        fl, cnt = C.c_double(0), C.c_int64(0)
+        self._check(self.lib.ttc_debug_kernel_flops(self._h, name.encode(), C.byref(fl), C.byref(cnt)), "ttc_debug_kernel_flops")
+        return fl.value, cnt.value

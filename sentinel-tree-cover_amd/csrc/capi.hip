@@ -489,4 +489,13 @@ ttc_status ttc_debug_kernel_ms(ttc_ctx* c, const char* name, double* avg_ms, int
     return TTC_OK;
 }
 
+ttc_status ttc_debug_kernel_flops(ttc_ctx* c, const char* name, double* flops_per_launch, int64_t* launches) {
+    if (!c || !name) return TTC_ERR_ARG;
+    auto it = c->timing.recs.find(name);
+    const bool have = it != c->timing.recs.end() && it->second.nf > 0;
+    if (flops_per_launch) *flops_per_launch = have ? it->second.flops / (double)it->second.nf : 0.0;
+    if (launches) *launches = have ? it->second.nf : 0;
+    return TTC_OK;
+}
+
 }  // extern "C"

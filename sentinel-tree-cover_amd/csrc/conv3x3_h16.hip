@@ -730,6 +730,16 @@ long conv_pack_h16(const float* const* hwio, int nsets, int Cin, int C0, int Cou
 }
 
 
+// matrix-instruction flops of a launch: tile = 512 flat positions x BN couts; a K-block product (K = 16: the 8 channels of two taps) is
+// 2 * BN * 512 * 16 flops.  TERMS = 3: 28 K-block products per chunk PAIR (tap 8 of the two hi-tile products shares a block), 15 for a
+// single chunk; TERMS = 2 (the two hi-tile products): 18 / 10; TERMS = 1: 5 per chunk.
+double conv_issued_flops_h16(const H16Args& a, const PackedConv& pw, int n) {
+    const double tiles = (double)conv_q_blocks(a.c.Hp, a.c.Wp) * pw.ncb * n;
+    const int pairs = a.nchunk / 2, single = a.nchunk & 1;
+    const double kprod = pw.terms == 1 ? 5.0 * a.nchunk : (pw.terms == 2 ? 18.0 * pairs + 10.0 * single : 28.0 * pairs + 15.0 * single);
+    return tiles * kprod * 2.0 * pw.BN * kBQ * 16.0;
+}
+
 hipError_t conv_launch_h16(const H16Args& a, const PackedConv& pw, int mode, int epi, int out_kind, int n, hipStream_t s) {
     const bool bf = mode == 1;
     const int terms = pw.terms == 1 ? 1 : (pw.terms == 2 ? 2 : 3);

@@ -478,6 +478,31 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
     return TTC_OK;
 }
 
+double conv_issued_flops(const ConvArgs& a, const PackedConv& pw, int epi, int n) {
+    const int H = a.Hp - 2, W = a.Wp - 2;
+    const int cin_run = (a.cin_run > 0 && a.cin_run < a.Cin) ? a.cin_run : a.Cin;
+    switch (conv_kernel_for(pw, epi, a.Hp, a.Wp, a.Cin, n, a.n_per_set)) {
+        case CONV_WINO4: {       // conv3x3_wino4.hip launch_w4: tile = two 16 x 16-pixel sub-regions x 64 couts, 8 waves, v_mfma_f32_16x16x4_f32
+            const long RR = (long)((W + 15) / 16) * ((H + 15) / 16), nsets = (n + a.n_per_set - 1) / a.n_per_set;
+            const long pps = (RR * std::min(n, a.n_per_set) + 1) / 2, ntiles = pps * nsets * (a.Cout / 64);
+            const int nrun = std::max(3, (cin_run + 7) / 8), rem = std::min(a.Cin, nrun * 8) - 8 * (nrun - 1), nks_last = (rem + 3) / 4;
+            return (double)ntiles * 8.0 * ((nrun - 1) * 72.0 + nks_last * 36.0) * (2.0 * 16 * 16 * 4);
+        }
+        case CONV_WINO2: {       // conv3x3_wino.hip launch_w: tile = 32 * TB Winograd tiles x 32 * NCB couts, 4 waves, v_mfma_f32_32x32x2_f32
+            const int NCB = pw.Cout >= 64 ? 2 : 1, TB = 2 / NCB, TX = (W + 1) / 2, TY = (H + 1) / 2;
+            const long ntiles = (long)((TX + 7) / 8) * ((TY + 4 * TB - 1) / (4 * TB)) * ((a.Cout + 32 * NCB - 1) / (32 * NCB)) * n;
+            const int nrun = std::max(3, (cin_run + 7) / 8), rem = std::min(a.Cin, nrun * 8) - 8 * (nrun - 1), nks_last = (rem + 1) / 2;
+            return (double)ntiles * 4.0 * ((nrun - 1) * 32.0 + nks_last * 8.0) * (2.0 * 32 * 32 * 2);
+        }
+        default: break;
+    }
+    // direct implicit GEMM: tile = 512 flat positions x BN couts (the 32 -> 6 head: 16 rows), K = 9 taps x nchunk x CK channels
+    const double tiles = (double)conv_q_blocks(a.Hp, a.Wp) * pw.ncb * n;
+    const bool head = pw.CK == 8 && pw.BN == 32 && epi == EPI_BIAS_TANH_ADD && pw.Cout <= 16 && pw.ncb == 1 && a.seg[1].C == 0 &&
+                      ((a.Hp * a.Wp) & 3) == 0 && a.Wp <= 255 && a.n_per_set >= n;
+    return tiles * 2.0 * (9.0 * pw.nchunk * pw.CK) * kBQ * (head ? 16 : pw.BN);
+}
+
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s) {
     switch (conv_kernel_for(pw, epi, a.Hp, a.Wp, a.Cin, n, a.n_per_set)) {
         case CONV_WINO4: return conv_launch_wino4(a, pw, epi, n, s);

@@ -309,7 +309,7 @@ static ttc_status dsen2_core(ttc_ctx* c, const float* xin, const float* bil, int
         // extra launches 0.6 ms -- kept in the epilogue)
         if (padded_out) { a.out_stride_n = 32 * PP; a.out_plane = PP; a.out_pitch = Wp; a.oy = a.ox = 1; a.reflect_out = (H >= 4 && W >= 4); }
         else { a.out_stride_n = 6 * P; a.out_plane = P; a.out_pitch = W; a.oy = a.ox = 0; }
-        { KTimer kt(c, "dsen2_conv", s); TTC_HIP(c, conv_launch(a, c->w_ds[l], epi, n, s)); }
+        { KTimer kt(c, "dsen2_conv", s); kt.flops(conv_issued_flops(a, c->w_ds[l], epi, n)); TTC_HIP(c, conv_launch(a, c->w_ds[l], epi, n, s)); }
         if (padded_out && !a.reflect_out) {                  // degenerate sizes only: the epilogue writes the rim otherwise
             KTimer kt(c, "dsen2_border", s);
             hipLaunchKernelGGL(k_reflect_border, dim3((2 * Wp + 2 * Hp + 255) / 256, n * 32), dim3(256), 0, s, dst, Hp, Wp);
@@ -357,7 +357,7 @@ static ttc_status dsen2_core_h16(ttc_ctx* c, const B16& xin, const float* bil, i
         } else {
             a.c.out = out; a.c.res = bil; a.c.out_stride_n = 6 * P; a.c.out_plane = P; a.c.out_pitch = W;
         }
-        { KTimer kt(c, "dsen2_conv", s); TTC_HIP(c, conv_launch_h16(a, pw, BF, epi, kind, n, s)); }
+        { KTimer kt(c, "dsen2_conv", s); kt.flops(conv_issued_flops_h16(a, pw, n)); TTC_HIP(c, conv_launch_h16(a, pw, BF, epi, kind, n, s)); }
         if (dst && !rim) {
             hipLaunchKernelGGL(k_reflect_border_b16, dim3((2 * Wp + 2 * Hp + 255) / 256, n * 4), dim3(256), 0, s, dst->hi, dst->lo, Hp, Wp);
             TTC_HIP(c, hipGetLastError());

@@ -860,7 +860,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
         a.c.stats = c->stats;
         const bool h0 = st == 0;
         a.nchunk = h0 ? Cx8 : 0;
-        { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2, c->yg)); }
+        { KTimer kt(c, "conv_gates", s); TTC_CHECK(launch(a, c->w_gates, EPI_RAW, N2, c->yg)); kt.flops(conv_issued_flops_h16(a, c->w_gates, N2)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, nblk_full, 4.0 * P, s));
         if (!h0) {
             KTimer kt(c, "gru_apply1", s);
@@ -872,7 +872,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
         a.nchunk = h0 ? Cx8 : 0;
         a.c.Cout = Hd;
         a.c.aux = gp.base + 4 * 32; a.c.aux_set_stride = gp.dir_stride;
-        { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2, c->yc)); }
+        { KTimer kt(c, "conv_cand", s); TTC_CHECK(launch(a, c->w_cand, EPI_SSE, N2, c->yc)); kt.flops(conv_issued_flops_h16(a, c->w_cand, N2)); }
         TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, nblk_full, 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply2", s);
@@ -893,7 +893,7 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
         a.c.Hp = in.h; a.c.Wp = in.w; a.c.Cout = kBlockCout[b]; a.c.n_per_set = N;
         const long Po = (long)(in.h - 2) * (in.w - 2);
         a.c.stats = c->stats; a.c.same_pad = same;
-        { KTimer kt(c, tname, s); TTC_CHECK(launch(a, c->w_block[b], EPI_SWISH, N, out)); }
+        { KTimer kt(c, tname, s); TTC_CHECK(launch(a, c->w_block[b], EPI_SWISH, N, out)); kt.flops(conv_issued_flops_h16(a, c->w_block[b], N)); }
         return gn_fin(c, gn_slot[b], N, a.c.Cout, 8, conv_stat_slots(in.h, in.w), (double)(a.c.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
@@ -933,13 +933,13 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
     TTC_CHECK(block_conv(3, seg(c->p2_16, 2L * F8 * h2.area(), 0, 2 * F8), none, h2, 0, c->y_c2, "conv2"));
     TTC_CHECK(fin(3, G_UP, c->y_c2, c2, c->u2in16, u2p, 1, 0, 4 * F8, 0));
     // up2 (SAME) on nearest x2
-    TTC_CHECK(block_conv(4, seg(c->u2in16, 4L * F8 * u2p.area(), 0, 4 * F8), none, u2p, 1, c->y_u2, "up2"));
+    TTC_CHECK(block_conv(4, seg(c->u2in16, 4L * F8 * u2p.area(), 0, 4 * F8), none, u2p, 1, c->y_u2, "conv_up2"));
     TTC_CHECK(fin(4, G_COPY, c->y_u2, u2, c->u2a16, u2p, 1, 0, 4 * F8, 0));
     TTC_CHECK(fin(2, G_COPY, c->y_c1, c1, c->u2a16, u2p, 1, 2, 4 * F8, 2 * F8));            // crop(conv1, 2)
-    TTC_CHECK(block_conv(5, seg(c->u2a16, 4L * F8 * u2p.area(), 0, 4 * F8), none, u2p, 1, c->y_u2o, "up2_out"));
+    TTC_CHECK(block_conv(5, seg(c->u2a16, 4L * F8 * u2p.area(), 0, 4 * F8), none, u2p, 1, c->y_u2o, "conv_up2_out"));
     TTC_CHECK(fin(5, G_UP, c->y_u2o, u2, c->u3in16, u3p, 1, 0, 2 * F8, 0));
     // up3 (SAME)
-    TTC_CHECK(block_conv(6, seg(c->u3in16, 2L * F8 * u3p.area(), 0, 2 * F8), none, u3p, 1, c->y_u3, "up3"));
+    TTC_CHECK(block_conv(6, seg(c->u3in16, 2L * F8 * u3p.area(), 0, 2 * F8), none, u3p, 1, c->y_u3, "conv_up3"));
     TTC_CHECK(fin(6, G_COPY, c->y_u3, u3, c->oa16, u3, 0, 0, 2 * F8, 0));
     TTC_CHECK(fin(1, G_COPY, c->y_cat, full, c->oa16, u3, 0, 6, 2 * F8, F8));               // crop(concat, 6)
     // out (VALID)
@@ -999,7 +999,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.stats = c->stats;
         const bool h0 = skip_h0 && st == 0;
         a.cin_run = h0 ? Cx : 0;
-        { KTimer kt(c, "conv_gates", s); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
+        { KTimer kt(c, "conv_gates", s); kt.flops(conv_issued_flops(a, c->w_gates, EPI_RAW, N2)); TTC_HIP(c, conv_launch(a, c->w_gates, EPI_RAW, N2, s)); }
         TTC_CHECK(gn_fin(c, gn_slot[8], N2, 2 * Hd, 16, conv_stat_slots_for(c->w_gates, EPI_RAW, Hp, Wp, a.Cin, N2, N), 4.0 * P, s));
         if (!h0) {
             KTimer kt(c, "gru_apply1", s);
@@ -1011,7 +1011,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         a.Cout = Hd; a.w = c->w_cand.d_w; a.w_set_stride = c->w_cand.set_stride;
         a.out = c->yc; a.out_stride_n = (long)Hd * Pr;
         a.aux = gp.base + 4 * 32; a.aux_set_stride = gp.dir_stride;
-        { KTimer kt(c, "conv_cand", s); TTC_HIP(c, conv_launch(a, c->w_cand, EPI_SSE, N2, s)); }
+        { KTimer kt(c, "conv_cand", s); kt.flops(conv_issued_flops(a, c->w_cand, EPI_SSE, N2)); TTC_HIP(c, conv_launch(a, c->w_cand, EPI_SSE, N2, s)); }
         TTC_CHECK(gn_fin(c, gn_slot[9], N2, Hd, 8, conv_stat_slots_for(c->w_cand, EPI_SSE, Hp, Wp, a.Cin, N2, N), 4.0 * P, s));
         {
             KTimer kt(c, "gru_apply2", s);
@@ -1033,7 +1033,7 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
         const long Po = (long)(in.h - 2) * (in.w - 2), Pro = (long)(in.h - 2) * in.w;
         a.out = out; a.out_stride_n = (long)a.Cout * Pro; a.out_plane = Pro; a.out_pitch = in.w; a.oy = a.ox = 0;
         a.stats = c->stats; a.same_pad = same;
-        { KTimer kt(c, tname, s); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
+        { KTimer kt(c, tname, s); kt.flops(conv_issued_flops(a, c->w_block[b], EPI_SWISH, N)); TTC_HIP(c, conv_launch(a, c->w_block[b], EPI_SWISH, N, s)); }
         return gn_fin(c, gn_slot[b], N, a.Cout, 8, conv_stat_slots_for(c->w_block[b], EPI_SWISH, in.h, in.w, a.Cin, N, N), (double)(a.Cout / 8) * Po, s);
     };
     auto prm = [&](int b) { return sm + c->small_off[std::string(kBlockNames[b]) + "/"]; };
@@ -1063,13 +1063,13 @@ ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, 
     TTC_CHECK(block_conv(3, {c->p2, 2L * F * h2.area(), {0, 0}, 2 * F}, none, h2, 0, c->y_c2, "conv2"));
     TTC_CHECK(fin(3, G_UP, c->y_c2, c2, c->u2in, u2p, 1, 0, 4L * F * u2p.area(), 0));
     // up2 (SAME) on nearest x2
-    TTC_CHECK(block_conv(4, {c->u2in, 4L * F * u2p.area(), {0, 0}, 4 * F}, none, u2p, 1, c->y_u2, "up2"));
+    TTC_CHECK(block_conv(4, {c->u2in, 4L * F * u2p.area(), {0, 0}, 4 * F}, none, u2p, 1, c->y_u2, "conv_up2"));
     TTC_CHECK(fin(4, G_COPY, c->y_u2, u2, c->u2a, u2p, 1, 0, 4L * F * u2p.area(), 0));
     TTC_CHECK(fin(2, G_COPY, c->y_c1, c1, c->u2a, u2p, 1, 2, 4L * F * u2p.area(), 2 * F));   // crop(conv1, 2)
-    TTC_CHECK(block_conv(5, {c->u2a, 4L * F * u2p.area(), {0, 0}, 4 * F}, none, u2p, 1, c->y_u2o, "up2_out"));
+    TTC_CHECK(block_conv(5, {c->u2a, 4L * F * u2p.area(), {0, 0}, 4 * F}, none, u2p, 1, c->y_u2o, "conv_up2_out"));
     TTC_CHECK(fin(5, G_UP, c->y_u2o, u2, c->u3in, u3p, 1, 0, 2L * F * u3p.area(), 0));
     // up3 (SAME)
-    TTC_CHECK(block_conv(6, {c->u3in, 2L * F * u3p.area(), {0, 0}, 2 * F}, none, u3p, 1, c->y_u3, "up3"));
+    TTC_CHECK(block_conv(6, {c->u3in, 2L * F * u3p.area(), {0, 0}, 2 * F}, none, u3p, 1, c->y_u3, "conv_up3"));
     TTC_CHECK(fin(6, G_COPY, c->y_u3, u3, c->oa, u3, 0, 0, 2L * F * u3.area(), 0));
     TTC_CHECK(fin(1, G_COPY, c->y_cat, full, c->oa, u3, 0, 6, 2L * F * u3.area(), F));     // crop(concat, 6)
     // out (VALID)

@@ -163,6 +163,11 @@ long conv_pack(const float* const* hwio, int nsets, int Cin, int Cout, int CK, i
 int conv_q_blocks(int Hp, int Wp);   // 512-position tiles of a plane
 int conv_stat_slots(int Hp, int Wp); // GroupNorm partial sums per (window, channel quad): one per tile and wave
 hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
+// flops of the MATRIX INSTRUCTIONS the launch conv_launch() makes for these arguments issues: workgroup tiles x k-steps x flops per MFMA, with
+// the channel / region / cout padding the kernel really multiplies (Winograd forms: 2.25 or 4 multiply-accumulates per output and tap set
+// instead of 9).  bench.py's roofline prices kernels with it (ttc_debug_kernel_flops); the algorithmic 2*9*Cin*Cout per pixel stays beside it.
+double conv_issued_flops(const ConvArgs& a, const PackedConv& pw, int epi, int n);
+double conv_issued_flops_h16(const H16Args& a, const PackedConv& pw, int n);
 // Winograd F(2x2, 3x3) kernels of the fp32 engine (conv3x3_wino.hip): EPI_RAW / EPI_SSE / EPI_SWISH layers with Cout % 32 == 0
 long conv_pack_wino(const float* const* hwio, int nsets, int Cin, int Cout, std::vector<float>& out, int* nchunk);
 hipError_t conv_launch_wino(const ConvArgs& a, const PackedConv& pw, int epi, int n, hipStream_t s);
@@ -190,7 +195,7 @@ ttc_status conv_upload(ttc_ctx* c, PackedConv& pc, const float* const* hwio, int
 // ----------------------------------------------------------------------------- context
 struct Timing {
     int level = 0;
-    struct Rec { double ms = 0; int64_t n = 0; };
+    struct Rec { double ms = 0; int64_t n = 0; double flops = 0; int64_t nf = 0; };   // flops: matrix-instruction flops ISSUED by the nf launches noted
     std::map<std::string, Rec> recs;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
 };
@@ -293,6 +298,8 @@ ttc_status dsen2_load(ttc_ctx* c, const ttc_tensor* t, int n);
 // timing helper: wraps a launch in HIP events on stream s when enabled
 struct KTimer {
     ttc_ctx* c; const char* name; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    // conv launches: the flops of the matrix instructions the launch issues (conv_issued_flops), summed per family next to the event times
+    void flops(double f) { if (a) { auto& r = c->timing.recs[name]; r.flops += f; r.nf += 1; } }
     KTimer(ttc_ctx* c_, const char* n_, hipStream_t s_) : c(c_), name(n_), s(s_) {
         // level 1: every kernel family; level 2: only the conv engine launches (names "conv_*", "dsen2_conv")
         if (c->timing.level == 1 || (c->timing.level == 2 && strstr(name, "conv") != nullptr)) {

@@ -289,10 +289,10 @@ def test_fast_path_refuses_what_adjust_shape_cannot_reconcile():
     length there and process_tile raises): each is an error naming the array, never a silent read with the wrong strides"""
     from ttc import job, weights as Wt
     size = 30
-    sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=4, dsen2_weights=None)
+    sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=4)
     ctx = sess.ctx
-    raw = synth.synth_raw_files(91, 4, 40, 44, False)
-    T, X, Y = 4, 80, 88
+    raw = synth.synth_raw_files(91, 4, 60, 64, False)          # 120 x 128: at least one 110-px DSen2 window
+    T, X, Y = 4, 120, 128
     mask = np.zeros((T, X, Y), np.float32)
     dem = np.zeros((X, Y), np.float32)
     args = lambda **kw: dict(dict(s2_10=raw["s2_10"], s2_20=raw["s2_20"], s1=raw["s1"], dem=dem, mask=mask, dates=raw["dates"]), **kw)  # noqa: E731
@@ -313,9 +313,9 @@ def test_fast_path_refuses_what_adjust_shape_cannot_reconcile():
         call(s1=raw["s1"][:6])
     with pytest.raises(ValueError, match="uint16"):
         call(s2_10=raw["s2_10"].astype(np.float32))
-    with pytest.raises(RuntimeError, match="s2_10 is 83 x 88"):
+    with pytest.raises(RuntimeError, match="s2_10 is 123 x 128"):
         call(s2_10=np.pad(raw["s2_10"], ((0, 0), (3, 0), (0, 0), (0, 0))))
-    with pytest.raises(RuntimeError, match="dem is 80 x 85"):
+    with pytest.raises(RuntimeError, match="dem is 120 x 125"):
         call(dem=dem[:, :-3])
     # the tile loop: same errors, and the staged mirror refuses the same inputs
     with pytest.raises(ValueError, match="mask"):

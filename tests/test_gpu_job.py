@@ -64,7 +64,7 @@ def test_superresolve_large_tile_dropin():
     # the tensor branch validates like the numpy branch -- a HOST tensor never reaches the device kernels as a pointer (it takes the
     # numpy route and is refined in place), a tensor that is not [T, X, Y, 10] is refused instead of being read with stride 10
     import torch
-    ht = torch.from_numpy(arr.copy())
+    ht = torch.from_numpy(keep[..., :10].copy())
     assert job.superresolve_large_tile(ht, sess) is ht and np.abs(ht.numpy() - ref).max() < 5e-5
     for bad in (torch.zeros((2, 8, 8, 11), device="cuda"), torch.zeros((8, 8, 10), device="cuda"),
                 torch.zeros((2, 8, 8, 17), device="cuda")[..., :10], torch.zeros((2, 8, 8, 10), device="cuda", dtype=torch.float64)):
@@ -119,7 +119,7 @@ def test_arena_is_sized_through_the_real_reader_and_survives_an_abandoned_loop(t
     spec.loader.exec_module(WF)
     size = 30
     sess = job.TTCSession(Wt.synth_weights(0), win_in=size + 14, length=4)
-    raw = synth.synth_raw_files(92, 4, 40, 44, False)
+    raw = synth.synth_raw_files(92, 4, 60, 64, False)          # 120 x 128: at least one 110-px DSen2 window
     coords = [(10 + i, 20) for i in range(6)]
     for (x, y) in coords:
         idx = f"{x}X{y}Y"

@@ -15,9 +15,15 @@ prof() {  # name, bench args...
     (cd $R && python tools/rocpd_stats.py $f > $O/${TAG}_${name}_kernel_stats.md)
     rm -rf $O/prof_${TAG}_$name
 }
+# round 6: one bench LEG per rocprofv3 run (bench.py --profile-leg), so that a kernel's average in a stats file is the average of that leg's
+# launches; tools/profile_ref.py turns the summaries into profiles/<round>_bench_profile.json, which bench.py checks its own event times against.
+# LEGS="w172_l4_fp32 w172_l4_fp16 ..." selects the legs (default: the headline's three engines + BASELINE's literal geometry)
 if want stats; then
-prof fp32 --inflight 1 --no-dprob --no-alt --no-cpu-baseline --steps 10
-prof fp16 --precision fp16 --inflight 1 --no-dprob --no-alt --no-cpu-baseline --steps 10
+for key in ${LEGS:-w172_l4_fp32 w172_l4_fp16 w172_l4_bf16 w168_l12_fp32 w168_l12_fp16}; do
+    win=$(echo $key | sed 's/w\([0-9]*\)_l.*/\1/'); len=$(echo $key | sed 's/.*_l\([0-9]*\)_.*/\1/'); prec=${key##*_}
+    prof isolated_$key --profile-leg isolated --steps 10 --win $win --length $len --precision $prec
+    prof live_$key --profile-leg live --steps 20 --warmup 3 --win $win --length $len --precision $prec
+done
 prof preprocess --preprocess-only --tiles 64 --inflight 1 --no-cpu-baseline
 fi
 cd $R
