@@ -102,8 +102,9 @@ def roofline(precision, win, n_windows, gates_ms, gates_n, length=4, issued_lib=
         # 2 * 9 * Cin * Cout flops per output pixel (it exceeds 1: no kernel of the direct form could reach it).
         rr = (-(-win // 16)) ** 2                                                    # 16 x 16-pixel sub-regions per plane
         wg_tiles = 2 * (-(-rr * n_windows // 2))                                       # pairs of sub-regions per direction, two directions
-        # per workgroup tile: 8 waves x (6 full 8-channel chunks x 72 + one k-step of the 7th x 36) MFMAs for Cin = 49; 2 x 72 + 36 at step 0
-        mfmas = wg_tiles * 8 * ((length - 1) * (6 * 72 + 36) + (2 * 72 + 36)) / length
+        # per workgroup tile: 8 waves x (6 full 8-channel chunks x 72 + one k-step of the 7th x 36) MFMAs for Cin = 49; step 0 runs the 3 chunks that hold
+        # the 17 frame channels + the 7 cleared state planes beside channel 16: 2 x 72 + two k-steps x 36
+        mfmas = wg_tiles * 8 * ((length - 1) * (6 * 72 + 36) + (2 * 72 + 2 * 36)) / length
         issued = mfmas * 2.0 * 16 * 16 * 4
         if issued_lib:                       # the library's own count of the launches it made (conv_issued_flops); the formula above is its cross-check
             if abs(issued_lib / issued - 1.0) > 0.02:
@@ -264,6 +265,7 @@ def main():
     ap.add_argument("--profile-leg", choices=["isolated", "live"], default=None,
                     help="run ONE leg only and exit (for rocprofv3: tools/gpu_profiles.sh): isolated = --steps tiles one after the other through one "
                          "session; live = the headline's timed region (--inflight tiles in flight)")
+    ap.add_argument("--cal-budget", type=float, default=5e-4, help="alt_fp16_calibrated: max |dprob| budget of ttc_calibrate_precision on the sample windows")
     ap.add_argument("--job-level-only", action="store_true", help="run the job-level leg alone (files -> rasters -> GeoTIFFs) and print its JSON")
     ap.add_argument("--job-readers", type=int, default=4, help="host threads that read tile folders ahead in the job-level leg")
     ap.add_argument("--job-no-arena", action="store_true", help="job-level leg: stage the raw arrays through pinned buffers on the loop's thread instead of reading into a PinnedArena")
@@ -311,9 +313,9 @@ def main():
             os._exit(3)
     weights = Wt.synth_weights(0)
 
-    def make_sessions(precision, win=args.win, length=args.length, n=args.inflight, dsen2_precision=None, two_term_layers=0):
+    def make_sessions(precision, win=args.win, length=args.length, n=args.inflight, dsen2_precision=None, two_term_layers=0, one_term_layers=None):
         return [job.TTCSession(weights, win_in=win, length=length, max_windows=36, device=local, precision=precision,
-                               dsen2_precision=dsen2_precision, two_term_layers=two_term_layers) for _ in range(n)]
+                               dsen2_precision=dsen2_precision, two_term_layers=two_term_layers, one_term_layers=one_term_layers) for _ in range(n)]
 
     # ---- the tile pool: tile_id = k * world + rank, seed 1234 + tile_id; raw arrays as stored (uint16, tof_downloading.py:51-61)
     def u16(a):
@@ -795,6 +797,28 @@ def main():
                                       "max_dprob_e2e": None if args.no_dprob else dprob_e2e(ss[0], ref),
                                       "note": "informational, not the headline value; default off (max_dprob_e2e above the 2e-4 of the default engines)"}
         close(ss)
+        # the fp16 engine with its product map CALIBRATED for these weights on the model feed of tile 0 (ttc_calibrate_precision): budget
+        # = max |dprob| against the in-library fp32 engine on the 36 sample windows; max_dprob_e2e is then measured like every other leg's
+        try:
+            cal = job.TTCSession(weights, win_in=args.win, length=args.length, max_windows=36, device=local, precision="auto")
+            frames0, _ = hip_tile0(cal)
+            x0 = frames0[:, :, :, 1:-1, 1:-1].permute(0, 1, 3, 4, 2).contiguous()
+            rep = cal.calibrate(x0, args.cal_budget)
+            cal.close()
+            ss = make_sessions("fp16", one_term_layers=rep["one_term_layers"], two_term_layers=rep["two_term_layers"])
+            dt2, g2, gn2, _ = measure(ss, alt_steps, 2)
+            tab2, tiles2 = dict(last["table"]), last["tiles"]
+            extra["alt_fp16_calibrated"] = {
+                "precision": "fp16, product map calibrated (ttc_calibrate_precision, budget %.1e on the model feed of tile 0)" % args.cal_budget,
+                "dtype": DTYPES["fp16"] + "; per layer 1 / 2 / 3 products as calibrated", "value": args.inflight * TILE * TILE * alt_steps / dt2, "unit": "px/s",
+                "ms_per_step": dt2 / alt_steps * 1e3, "steps": alt_steps, "conv_gates_launch_ms": g2, "calibration": rep,
+                "max_dprob": None if args.no_dprob else max_dprob(ss[0]), "max_dprob_e2e": None if args.no_dprob else dprob_e2e(ss[0], ref),
+                "step_mfma_flops_issued_per_tile": table_totals(tab2, tiles2)[1],
+                "note": "informational, not the headline value.  The map is a property of THESE (seeded stand-in) weights and this tile: "
+                        "profiles/r06_precision_calibration.json tabulates it over weight seeds / scales and held-out tiles"}
+            close(ss)
+        except Exception as e:
+            extra["alt_fp16_calibrated"] = {"error": f"{type(e).__name__}: {e}"}
         if args.precision == "fp32":
             # the fp32 step with ONLY the DSen2 super-resolution convs on the 16-bit engine (fp16 hi + lo pairs, three products: <= 1e-5 on
             # reflectance; ttc_config.dsen2_precision).  An option, reported beside the headline -- never the headline.

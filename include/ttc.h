@@ -133,6 +133,32 @@ ttc_status ttc_load_dsen2_weights(ttc_ctx* ctx, const ttc_tensor* tensors, int32
  * d_out: [n, H-14, W-14]    float32 probabilities                                      */
 ttc_status ttc_forward_windows(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, void* stream);
 
+/* ---- precision calibration of the 16-bit engine ----------------------------------------------------------------------------------
+ * Which conv layers of a 16-bit context (precision 2 / 3) need all three split products is a property of the WEIGHTS (GroupNorm,
+ * src/train/src/model.py:100-121, divides by the per-group deviation of the conv output and amplifies a 2^-11 operand error where that
+ * deviation is small) and of how smooth the inputs are.  This call measures it for the caller's model and data instead of assuming it:
+ * d_windows [n, L+1, H, W, 17] -- normalised model inputs of REAL windows, e.g. the d_model_in of ttc_predict_tile (white-noise windows
+ * under-state the error of real, spatially smooth tiles by ~8 x: DESIGN.md 4.1c) -- go through `ref_ctx` (an fp32 context of the same
+ * geometry on the same device with the same weights loaded) and through candidate maps on `ctx`; layers are visited by matrix work,
+ * largest first, and each takes ONE product (x_hi * w_hi), else TWO (x_hi * (w_hi + w_lo), fp16 only), where the probabilities of the
+ * WHOLE map stay within `budget` of the fp32 engine's.  The chosen map is left applied to `ctx` (as if it had been created with these
+ * `one_term_layers` / `two_term_layers`; the DSen2 bits keep their configured value) and reported.  BASELINE's contract is 1e-3 on
+ * probabilities: a budget of 5e-4 leaves half of it to the rest of the chain.  Synchronises the stream (about 45 forwards of n windows). */
+#define TTC_CAL_LAYERS 10    /* bits 0..9 of one_term_layers: ConvGRU gates, candidate, conv_median, conv_concat, conv1, conv2, up2, up2_out, up3, out */
+typedef struct {
+    uint32_t one_term_layers, two_term_layers;   /* the map applied */
+    float    max_dprob;                          /* max |p(map) - p(fp32)| over the sample windows                                  */
+    float    dprob_all_three;                    /* the same with three products everywhere: the floor no map can get under         */
+    float    layer_dprob_one[TTC_CAL_LAYERS];    /* layer l ALONE on one product, the others on three                               */
+    float    layer_dprob_two[TTC_CAL_LAYERS];    /* ... on two products (NaN for bf16 contexts)                                     */
+    float    budget;
+    int32_t  within_budget;                      /* 0: even three products everywhere exceed the budget on these windows            */
+    double   matrix_work_ratio;                  /* matrix work of the map / matrix work with three products everywhere (1/3 .. 1)  */
+    int32_t  trials, n_windows;
+} ttc_precision_report;
+ttc_status ttc_calibrate_precision(ttc_ctx* ctx, ttc_ctx* ref_ctx, const float* d_windows, int32_t n, float budget,
+                                   ttc_precision_report* report, void* stream);
+
 /* Forward + the two feature tensors of --gen_feats (job.py:1429-1445; tensors named at :1808-1809):
  * d_early [n, H, W, 64]       == sess.run("predict/gru_drop/drop_block2d/cond/Merge:0")  (bi-ConvGRU output)
  * d_late  [n, H-14, W-14, 64] == sess.run("predict/csse_out_mul/mul:0")                  (last block after its sSE gate)

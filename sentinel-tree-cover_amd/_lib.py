@@ -25,7 +25,7 @@ EXPORTS = [
     "ttc_sen2cor_clean", "ttc_median5", "ttc_snow_map", "ttc_merge_cloud_masks", "ttc_count_positive", "ttc_clip01", "ttc_divide",
     "ttc_border_subtiles", "ttc_seam_adjust", "ttc_reseg_mosaic", "ttc_smooth_strip", "ttc_superresolve_windows", "ttc_count_equal", "ttc_write_geotiff_u8",
     "ttc_predict_tile", "ttc_read_hkl", "ttc_read_hkl_error",
-    "ttc_create_v2", "ttc_predict_tile_shaped", "ttc_adjust_shape", "ttc_debug_kernel_flops",
+    "ttc_create_v2", "ttc_predict_tile_shaped", "ttc_adjust_shape", "ttc_debug_kernel_flops", "ttc_calibrate_precision",
 ]
 
 # exported for tools/probes and the detector-stage tests, declared in csrc/ttc_internal.h -- not part of the drop-in surface (include/ttc.h)
@@ -51,6 +51,16 @@ PRECISIONS = {"fp32": 0, "fp16": 2, "bf16": 3}     # 1 / 4 were the retired bf16
 class TTCTileShapes(C.Structure):
     """ttc_tile_shapes: rows x cols of each raw array as stored (ttc_predict_tile_shaped)"""
     _fields_ = [("s2_10", C.c_int32 * 2), ("s2_20", C.c_int32 * 2), ("s1", C.c_int32 * 2), ("dem", C.c_int32 * 2), ("mask", C.c_int32 * 2)]
+
+
+CAL_LAYERS = ("gates", "candidate", "conv_median", "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out")     # bits 0..9 of one_term_layers
+
+
+class TTCPrecisionReport(C.Structure):
+    """ttc_precision_report (ttc_calibrate_precision)"""
+    _fields_ = [("one_term_layers", C.c_uint32), ("two_term_layers", C.c_uint32), ("max_dprob", C.c_float), ("dprob_all_three", C.c_float),
+                ("layer_dprob_one", C.c_float * 10), ("layer_dprob_two", C.c_float * 10), ("budget", C.c_float), ("within_budget", C.c_int32),
+                ("matrix_work_ratio", C.c_double), ("trials", C.c_int32), ("n_windows", C.c_int32)]
 
 
 class TTCResegWindow(C.Structure):
@@ -132,6 +142,7 @@ def load():
     lib.ttc_predict_tile.argtypes = [P, VP, VP, VP, VP, VP, VP, VP, I32, I32, I32, F64P, F64P, I32, I32, VP, VP, VP, VP, VP]
     lib.ttc_predict_tile_shaped.argtypes = [P, VP, VP, VP, VP, VP, VP, VP, I32, C.POINTER(TTCTileShapes), F64P, F64P, I32, I32, VP, VP, VP, VP, VP]
     lib.ttc_adjust_shape.argtypes = [P, VP, I32, I32, I32, I32, I32, I32, VP, VP]
+    lib.ttc_calibrate_precision.argtypes = [P, P, VP, I32, C.c_float, C.POINTER(TTCPrecisionReport), VP]
     lib.ttc_border_subtiles.argtypes = [P, VP, VP, VP, I32, I32P, I32, F32P, F32P, I32, I32, VP, F32P, I32P, VP]
     lib.ttc_smooth_strip.argtypes = [P, VP, I32, I32, I32, F32P, VP, VP]
     lib.ttc_superresolve_windows.argtypes = [P, VP, I32, I32, I32, I32, I32, I32, VP]
@@ -294,6 +305,27 @@ class Context:
                                                  C.c_void_p(out.data_ptr()), self._stream()),
                     "ttc_forward_windows")
         return out
+
+    def calibrate_precision(self, ref_ctx, windows, budget=5e-4):
+        """ttc_calibrate_precision: windows [n, L+1, H, W, 17] (numpy / cuda: REAL model inputs) through `ref_ctx` (fp32 Context, same
+        geometry, same weights) and through candidate product maps on this 16-bit context; the cheapest map within `budget` of the fp32
+        probabilities stays applied.  -> dict (one_term_layers, two_term_layers, max_dprob, per-layer table, matrix_work_ratio ...)"""
+        t = self.torch
+        xd = self._dev(windows, t.float32)
+        W, H = self.cfg.win_in, self.cfg.win_rows or self.cfg.win_in
+        if xd.dim() != 5 or tuple(xd.shape[1:]) != (self.cfg.length + 1, H, W, 17):
+            raise ValueError(f"calibrate_precision: windows must be [n, {self.cfg.length + 1}, {H}, {W}, 17], got {tuple(xd.shape)}")
+        rep = TTCPrecisionReport()
+        self._check(self.lib.ttc_calibrate_precision(self._h, ref_ctx._h, C.c_void_p(xd.data_ptr()), int(xd.shape[0]), float(budget),
+                                                     C.byref(rep), self._stream()), "ttc_calibrate_precision")
+        self.cfg.one_term_layers, self.cfg.two_term_layers = rep.one_term_layers | (self.cfg.one_term_layers & ~0x3FF), rep.two_term_layers
+        terms = {name: (1 if (rep.one_term_layers >> i) & 1 else (2 if (rep.two_term_layers >> i) & 1 else 3)) for i, name in enumerate(CAL_LAYERS)}
+        return {"one_term_layers": int(rep.one_term_layers), "two_term_layers": int(rep.two_term_layers), "products_per_layer": terms,
+                "max_dprob": float(rep.max_dprob), "dprob_all_three": float(rep.dprob_all_three), "budget": float(rep.budget),
+                "within_budget": bool(rep.within_budget), "matrix_work_ratio": float(rep.matrix_work_ratio), "trials": int(rep.trials),
+                "n_windows": int(rep.n_windows),
+                "layer_alone_one_product": {name: float(rep.layer_dprob_one[i]) for i, name in enumerate(CAL_LAYERS)},
+                "layer_alone_two_products": {name: float(rep.layer_dprob_two[i]) for i, name in enumerate(CAL_LAYERS)}}
 
     # -- per-tile core -------------------------------------------------------------------
     def tile_fix_missing(self, s2d, do_nan=True, do_zero_one=False):

@@ -955,6 +955,20 @@ static ttc_status forward_h16(ttc_ctx* c, int n, float* d_out, hipStream_t s, Fr
     return TTC_OK;
 }
 
+// products per conv layer of the 16-bit engine, switchable after load: the packed weight images hold hi | lo for every layer and every
+// producer writes both halves of its output, so a layer's product count is only the kernel instantiation its launch picks (ttc_calibrate_precision)
+ttc_status model_set_terms(ttc_ctx* c, uint32_t one, uint32_t two) {
+    if (!c->half()) return c->fail(TTC_ERR_ARG, "set_terms: not a 16-bit-engine context");
+    if (c->cfg.precision != 2) two = 0;
+    c->cfg.one_term_layers = one;
+    c->cfg.two_term_layers = two;
+    auto terms_of = [&](int bit) { return ((one >> bit) & 1u) ? 1 : (((two >> bit) & 1u) ? 2 : 3); };
+    c->w_gates.terms = terms_of(0);
+    c->w_cand.terms = terms_of(1);
+    for (int b = 0; b < 8; ++b) c->w_block[b].terms = terms_of(2 + b);
+    return TTC_OK;
+}
+
 ttc_status model_forward_frames(ttc_ctx* c, int n, float* d_out, hipStream_t s, FramesForm form) {
     if (!c->have_model) return c->fail(TTC_ERR_STATE, "ttc_load_weights has not been called");
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");

@@ -60,7 +60,7 @@ class TTCSession:
 
     def __init__(self, weights=None, win_in=SIZE + 14, length=LEN, max_windows=36, device=0, zoneout=0.75,
                  dsen2_weights="package", precision="fp32", win_rows=0, one_term_layers=None, fp32_conv_form=0, dsen2_precision=None,
-                 two_term_layers=0):
+                 two_term_layers=0, budget=5e-4, calibration_windows=None):
         """precision: "fp32" = exact fp32 MFMA chains (default); "fp16" / "bf16" = the 16-bit engine (conv inputs stored
         as hi + lo 16-bit pairs, fp32 accumulate; per layer three split products or one, `one_term_layers` bit mask as in
         ttc.h -- default 0: EVERY layer multiplies three products; any single layer on one plain fp16 product measured
@@ -68,19 +68,46 @@ class TTCSession:
         fp32_conv_form (precision fp32): 0 = fastest (Winograd F(4x4,3x3) / F(2x2,3x3)), 1 = F(2x2,3x3) at most, 2 = direct only: ttc.h.
         dsen2_precision: None = the session's precision; "fp16" / "bf16" = run the DSen2 super-resolution convs on the 16-bit engine (hi + lo
         pairs, three products: <= 1e-5 on reflectance for fp16) inside an fp32 session -- 2.4 instead of 5.0 ms per tile (ttc.h).
-        two_term_layers (precision fp16): bit mask of layers that multiply x_hi * (w_hi + w_lo) only (ttc.h; 3 = both ConvGRU convs)."""
+        two_term_layers (precision fp16): bit mask of layers that multiply x_hi * (w_hi + w_lo) only (ttc.h; 3 = both ConvGRU convs).
+        precision="auto" (+ budget, calibration_windows): the fp16 engine with the product count of every conv layer CALIBRATED for these
+        weights -- `calibration_windows` [n, L+1, W, W, 17] (real, normalised model inputs: e.g. the model feed of a tile the job already
+        processed) run through an fp32 context and through candidate maps, and the cheapest map whose probabilities stay within `budget`
+        of the fp32 engine's is kept (ttc_calibrate_precision; `self.calibration` holds the report).  Without windows the session starts on
+        three products everywhere and `calibrate(windows)` can be called later."""
+        auto = precision == "auto"
+        if auto:
+            precision, one_term_layers, two_term_layers = "fp16", 0, 0
         prec = _lib.PRECISIONS.get(precision, precision)
         # win_rows: rows of a non-square window (the 220 x 684 border graph of resegment_tiles_wide.py); 0 = square
         self.ctx = _lib.Context(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout,
                                 precision=prec, win_rows=win_rows, one_term_layers=one_term_layers, fp32_conv_form=fp32_conv_form,
                                 dsen2_precision=dsen2_precision, two_term_layers=two_term_layers)
         self.win_in, self.length = win_in, length
+        self._geom = dict(win_in=win_in, length=length, max_windows=max_windows, device=device, zoneout=zoneout, win_rows=win_rows)
+        self._weights = None
+        self.calibration = None
         if weights is not None:
-            self.ctx.load_weights(_weights.validate(dict(weights)))
+            self._weights = _weights.validate(dict(weights))
+            self.ctx.load_weights(self._weights)
         if dsen2_weights == "package":
             dsen2_weights = _weights.load_dsen2()
         if dsen2_weights is not None:
             self.ctx.load_dsen2_weights(dict(dsen2_weights))
+        if auto and calibration_windows is not None:
+            self.calibrate(calibration_windows, budget)
+
+    def calibrate(self, windows, budget=5e-4):
+        """ttc_calibrate_precision for this (16-bit) session: an fp32 context with the same weights is built for the duration of the call.
+        windows [n <= max_windows, L+1, W, W, 17] normalised model inputs.  -> the report (also kept as self.calibration); the map stays applied."""
+        if self._weights is None:
+            raise RuntimeError("TTCSession.calibrate: the session has no model weights")
+        ref = _lib.Context(precision=0, **self._geom)
+        try:
+            ref.load_weights(self._weights)
+            self.calibration = self.ctx.calibrate_precision(ref, windows, budget)
+        finally:
+            ref.close()
+        return self.calibration
 
     # -- tf.Session.run look-alike ---------------------------------------------------------
     def run(self, fetches, feed_dict=None):

@@ -198,3 +198,53 @@ def test_tile_16bit_vs_oracle(precision, size, length):
     assert np.array_equal(np.isnan(f32), np.isnan(ref_f))
     d = np.abs(u8.astype(int) - ref_u8.astype(int))
     assert (d > 1).mean() < 1e-4 and (d > 0).mean() < 3e-2
+
+
+def test_calibrate_precision_keeps_the_budget_and_is_reproducible():
+    """ttc_calibrate_precision: on smooth windows (a real tile's texture, not white noise) the chosen map's probabilities stay within
+    the budget of the in-library fp32 engine's, the map is what a context CREATED with those masks computes (bit-identical), a zero budget
+    returns three products everywhere with within_budget = False, and a generous budget buys at least one cheaper layer."""
+    import torch
+    from ttc import _lib, job, weights as Wt
+    W, L, N = 60, 4, 4
+    w = Wt.synth_weights(5)
+    x = synth.synth_windows(seed=9, N=N, L=L, W=W)
+    ref = _lib.Context(win_in=W, length=L, max_windows=N, precision="fp32")
+    ref.load_weights(w)
+    p32 = ref.forward_windows(x).cpu().numpy()
+    c16 = _lib.Context(win_in=W, length=L, max_windows=N, precision="fp16")
+    c16.load_weights(w)
+    tight = c16.calibrate_precision(ref, x, budget=0.0)
+    assert tight["one_term_layers"] == 0 and tight["two_term_layers"] == 0 and not tight["within_budget"] and tight["matrix_work_ratio"] == 1.0
+    assert 0 < tight["dprob_all_three"] < 2e-4
+    rep = c16.calibrate_precision(ref, x, budget=2e-2)
+    print("[calibrate] budget 2e-2:", {k: rep[k] for k in ("products_per_layer", "max_dprob", "dprob_all_three", "matrix_work_ratio", "trials")})
+    assert rep["within_budget"] and rep["max_dprob"] <= 2e-2 and rep["matrix_work_ratio"] < 1.0
+    assert (rep["one_term_layers"] | rep["two_term_layers"]) != 0 and (rep["one_term_layers"] & rep["two_term_layers"]) == 0
+    got = c16.forward_windows(x).cpu().numpy()                                   # the map is left applied
+    assert abs(float(np.abs(got - p32).max()) - rep["max_dprob"]) < 1e-7
+    fresh = _lib.Context(win_in=W, length=L, max_windows=N, precision="fp16", one_term_layers=rep["one_term_layers"],
+                         two_term_layers=rep["two_term_layers"])
+    fresh.load_weights(w)
+    np.testing.assert_array_equal(fresh.forward_windows(x).cpu().numpy(), got)
+    # a budget between the all-three floor and the cheapest single-layer error changes nothing
+    floor, cheapest = rep["dprob_all_three"], min(min(rep["layer_alone_one_product"].values()), min(rep["layer_alone_two_products"].values()))
+    if cheapest > 1.5 * floor:
+        mid = c16.calibrate_precision(ref, x, budget=(floor + cheapest) / 2)
+        assert mid["one_term_layers"] == 0 and mid["two_term_layers"] == 0 and mid["within_budget"]
+    # the session-level spelling
+    sa = job.TTCSession(w, win_in=W, length=L, max_windows=N, precision="auto", budget=2e-2, calibration_windows=x, dsen2_weights=None)
+    assert sa.calibration["one_term_layers"] == rep["one_term_layers"] and sa.calibration["two_term_layers"] == rep["two_term_layers"]
+    np.testing.assert_array_equal(sa.ctx.forward_windows(x).cpu().numpy(), got)
+    # refusals: an fp32 context cannot be calibrated, the reference must be fp32, geometry must match
+    with pytest.raises(RuntimeError, match="16-bit"):
+        ref.calibrate_precision(ref, x)
+    with pytest.raises(RuntimeError, match="fp32"):
+        c16.calibrate_precision(fresh, x)
+    other = _lib.Context(win_in=44, length=L, max_windows=N, precision="fp32")
+    other.load_weights(w)
+    with pytest.raises(RuntimeError, match="geometry"):
+        c16.calibrate_precision(other, x)
+    for cx in (ref, c16, fresh, other):
+        cx.close()
+    sa.close()
