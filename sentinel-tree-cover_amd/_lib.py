@@ -29,7 +29,8 @@ EXPORTS = [
 ]
 
 # exported for tools/probes and the detector-stage tests, declared in csrc/ttc_internal.h -- not part of the drop-in surface (include/ttc.h)
-INTERNAL_EXPORTS = ["ttc_debug_clouds_stage", "ttc_debug_knob"]
+INTERNAL_EXPORTS = ["ttc_debug_clouds_stage", "ttc_debug_knob", "ttc_debug_check_guards"]
+GUARD_STATS = {"contexts_checked": 0, "buffers_checked": 0, "violations": []}      # TTC_GUARD runs (tools/run_guarded_gpu_tests.sh)
 
 SAMPLER_FN = C.CFUNCTYPE(C.c_int64, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64), C.c_int64, C.c_void_p)
 
@@ -152,6 +153,7 @@ def load():
     lib.ttc_debug_fetch.argtypes = [P, C.c_char_p, F32P, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.ttc_debug_timing.argtypes = [P, I32]
     lib.ttc_debug_knob.argtypes = [I32, I32]
+    lib.ttc_debug_check_guards.argtypes = [P, C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
     lib.ttc_debug_kernel_ms.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ttc_debug_kernel_flops.argtypes = [P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     for name in EXPORTS:
@@ -267,8 +269,22 @@ class Context:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def check_guards(self):
+        """TTC_GUARD=<KiB> runs only: scan the guard zones around every device buffer the context owns -> (bytes overwritten, first offender)"""
+        n, msg = C.c_int64(0), C.create_string_buffer(400)
+        self._check(self.lib.ttc_debug_check_guards(self._h, C.byref(n), msg, 400), "ttc_debug_check_guards")
+        return int(n.value), msg.value.decode()
+
     def close(self):
         if getattr(self, "_h", None):
+            if os.environ.get("TTC_GUARD", "0") not in ("", "0"):
+                try:                                             # a device-memory check of everything this context ran (csrc/ttc_internal.h)
+                    n, msg = self.check_guards()
+                    GUARD_STATS["contexts_checked"] += 1
+                    if n:
+                        GUARD_STATS["violations"].append(msg)
+                finally:
+                    pass
             self.lib.ttc_destroy(self._h)
             self._h = C.c_void_p()
 

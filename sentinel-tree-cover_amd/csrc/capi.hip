@@ -66,7 +66,51 @@ static void flush_timing(ttc_ctx* c) {
     c->timing.pending.clear();
 }
 
+// bytes of a guard zone that no longer hold the pattern; first[0] = smallest offending offset
+__global__ void k_guard_scan(const unsigned char* __restrict__ z, size_t n, unsigned long long* __restrict__ bad, unsigned long long* __restrict__ first) {
+    unsigned long long mine = 0, lo = ~0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (z[i] != 0xA5) { ++mine; lo = lo < i ? lo : i; }
+    if (mine) { atomicAdd(bad, mine); atomicMin(first, lo); }
+}
+
 extern "C" {
+
+ttc_status ttc_debug_check_guards(ttc_ctx* c, int64_t* n_bad, char* msg, size_t cap) {
+    if (!c || !n_bad) return TTC_ERR_ARG;
+    *n_bad = 0;
+    if (msg && cap) msg[0] = 0;
+    const size_t G = ttc_ctx::guard_bytes();
+    if (!G) return c->fail(TTC_ERR_STATE, "check_guards: the library runs without guard zones (set TTC_GUARD=<KiB> before the first context)");
+    TTC_HIP(c, hipSetDevice(c->device));
+    TTC_HIP(c, hipDeviceSynchronize());
+    unsigned long long* d = nullptr;
+    TTC_HIP(c, hipMalloc(&d, 16));
+    std::string first_msg;
+    for (auto& kv : c->guarded) {
+        const auto& g = kv.second;
+        const size_t user = (g.user_bytes + 255) & ~(size_t)255;
+        struct Z { const char* what; const char* p; size_t n; } zones[2] = {{"before", g.base, G}, {"after", g.base + G + g.user_bytes, user - g.user_bytes + G}};
+        for (auto& z : zones) {
+            unsigned long long h[2] = {0ull, ~0ull};
+            TTC_HIP(c, hipMemcpy(d, h, 16, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_guard_scan, dim3(64), dim3(256), 0, 0, reinterpret_cast<const unsigned char*>(z.p), z.n, d, d + 1);
+            TTC_HIP(c, hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+            if (h[0]) {
+                *n_bad += (int64_t)h[0];
+                if (first_msg.empty()) {
+                    char b[320];
+                    snprintf(b, sizeof b, "%s (%zu bytes): %llu byte(s) overwritten %s the buffer, first at %s%llu", g.name.c_str(), g.user_bytes, h[0], z.what,
+                             z.what[0] == 'a' ? "end+" : "start-", z.what[0] == 'a' ? h[1] : (unsigned long long)G - h[1]);
+                    first_msg = b;
+                }
+            }
+        }
+    }
+    (void)hipFree(d);
+    if (msg && cap) snprintf(msg, cap, "%s", first_msg.c_str());
+    return TTC_OK;
+}
 
 const char* ttc_version(void) { return "ttc-hip 0.1 (gfx950)"; }
 
@@ -112,8 +156,8 @@ void ttc_destroy(ttc_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     flush_timing(c);
-    for (void* p : c->allocs) (void)hipFree(p);
-    for (auto& kv : c->scratch) (void)hipFree(kv.second.first);
+    for (void* p : c->allocs) c->guarded_free(p);
+    for (auto& kv : c->scratch) c->guarded_free(kv.second.first);
     for (auto& kv : c->pinned) (void)hipHostFree(kv.second.first);
     for (hipEvent_t e : c->wmat_events) if (e) (void)hipEventDestroy(e);
     delete c;

@@ -590,9 +590,34 @@ const int kBlockCout[8] = {64, 64, 128, 256, 128, 128, 64, 64};
 
 }  // namespace
 
-float* ttc_ctx::alloc_f(size_t n, const char* name) {
+size_t ttc_ctx::guard_bytes() {
+    static const size_t g = [] { const char* e = getenv("TTC_GUARD"); const long k = e ? atol(e) : 0; return k > 0 ? (size_t)k * 1024 : (size_t)0; }();
+    return g;
+}
+
+// hipMalloc with (TTC_GUARD) a 0xA5-filled zone before and after the buffer; the user pointer keeps hipMalloc's 4-KiB alignment
+void* ttc_ctx::guarded_malloc(size_t bytes, const std::string& name) {
+    const size_t G = guard_bytes();
     void* p = nullptr;
-    if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) return nullptr;
+    if (!G) return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+    const size_t user = (bytes + 255) & ~(size_t)255;             // the zone after the buffer starts at the next 256-byte boundary
+    if (hipMalloc(&p, user + 2 * G) != hipSuccess) return nullptr;
+    char* base = static_cast<char*>(p);
+    if (hipMemset(base, 0xA5, G) != hipSuccess || hipMemset(base + G + bytes, 0xA5, user - bytes + G) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    guarded[base + G] = Guarded{base, bytes, name};
+    return base + G;
+}
+
+void ttc_ctx::guarded_free(void* user) {
+    auto it = guarded.find(user);
+    if (it == guarded.end()) { (void)hipFree(user); return; }
+    (void)hipFree(it->second.base);
+    guarded.erase(it);
+}
+
+float* ttc_ctx::alloc_f(size_t n, const char* name) {
+    void* p = guarded_malloc(n * sizeof(float), name ? name : "alloc#" + std::to_string(allocs.size()));
+    if (!p) return nullptr;
     allocs.push_back(p);
     dev_bytes += n * sizeof(float);
     if (name) named[name] = {static_cast<float*>(p), n};
@@ -608,9 +633,9 @@ bool ttc_ctx::alloc_b16(B16& b, size_t units) {
 void* ttc_ctx::scratch_buf(const std::string& key, size_t bytes) {
     auto it = scratch.find(key);
     if (it != scratch.end() && it->second.second >= bytes) return it->second.first;
-    if (it != scratch.end()) { hipFree(it->second.first); dev_bytes -= it->second.second; }
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { scratch.erase(key); return nullptr; }
+    if (it != scratch.end()) { guarded_free(it->second.first); dev_bytes -= it->second.second; }
+    void* p = guarded_malloc(bytes, "scratch:" + key);
+    if (!p) { scratch.erase(key); return nullptr; }
     scratch[key] = {p, bytes};
     dev_bytes += bytes;
     return p;

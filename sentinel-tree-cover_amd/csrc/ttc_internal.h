@@ -16,6 +16,12 @@
 extern "C" {
 /* stage != 0: ttc_identify_clouds_shadows returns the flag planes after that stage of the detector (bisecting aid). */
 ttc_status ttc_debug_clouds_stage(ttc_ctx* ctx, int32_t stage);
+/* Device-side memory check without a sanitizer (GPU AddressSanitizer / xnack are not available on the target pool): with TTC_GUARD=<KiB> in the
+ * environment every device buffer the library owns (weights, workspace, scratch) is allocated with a guard zone of that size before and after
+ * it, filled with 0xA5.  This call scans every guard zone on the device and reports the bytes that no longer hold the pattern (an out-of-bounds
+ * WRITE of some kernel) and the first offending buffer in msg ("<name> +<offset> after|before").  *n_bad = 0 and TTC_OK = clean;
+ * TTC_ERR_STATE when the library runs without guards.  Synchronises the device. */
+ttc_status ttc_debug_check_guards(ttc_ctx* ctx, int64_t* n_bad, char* msg, size_t cap);
 /* PROBE ONLY -- not part of the drop-in surface.  Process-wide knobs of the 16-bit conv engine (tools/probes/h16_knobs.py, h16_trace.py):
  * which 0 = persistent grid size (-1 default = 2 per CU, 0 = one workgroup per tile), 1 = start offset of the odd wave slot in
  * s_sleep(127) units (-1 default), 2 | 3 = halves of a device pointer to a trace buffer, 4 = epilogue kind to trace.  They are plain
@@ -206,6 +212,12 @@ struct ttc_ctx {
     std::string err;
     size_t dev_bytes = 0;
     std::vector<void*> allocs;
+    // TTC_GUARD: guard zones around every owned device buffer (ttc_debug_check_guards)
+    struct Guarded { char* base; size_t user_bytes; std::string name; };
+    std::map<void*, Guarded> guarded;            // user pointer -> allocation
+    static size_t guard_bytes();                  // 0 = off
+    void* guarded_malloc(size_t bytes, const std::string& name);
+    void guarded_free(void* user);
     std::map<std::string, std::pair<float*, size_t>> named;   // debug-visible activations
 
     // model weights
