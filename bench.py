@@ -393,6 +393,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    stagger_ms = float(os.environ.get("TTC_BENCH_STAGGER_MS", "0"))
+    spin = {}
+
+    def stagger():
+        """probe (TTC_BENCH_STAGGER_MS=<ms>): delay stream i by i x ms INSIDE the timed region, so that the tiles in flight are in different phases
+        (one in its HBM-bound preprocessing while another runs convolutions) instead of entering every phase together -- what a job's tile loop
+        does by itself (tiles arrive one after the other).  The delay is a device-side spin (torch.cuda._sleep), calibrated once."""
+        if stagger_ms <= 0 or len(streams) < 2:
+            return
+        if "cyc_per_ms" not in spin:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); torch.cuda._sleep(20_000_000); b.record(); torch.cuda.synchronize()
+            spin["cyc_per_ms"] = 20_000_000 / max(a.elapsed_time(b), 1e-3)
+        for i, st in enumerate(streams):
+            if i:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(int(i * stagger_ms * spin["cyc_per_ms"]))
+
     last = {}                     # conv-family table of the most recent measure() (sessions[0] only: its timers are the ones switched on)
 
     def measure(sessions, steps, warmup, flags=base_flags, size=args.win - 14, want_out=True):
@@ -410,6 +428,7 @@ def main():
         ctx.timing(2)                 # HIP events around the conv-engine launches only (on the launch stream)
         ctx.kernel_ms(None)
         sync()
+        stagger()
         t0 = time.perf_counter()
         for _ in range(steps):
             step(sessions, flags, size, want_out)
@@ -562,13 +581,26 @@ def main():
 
     alg_bytes = (4.0 * args.dates * 15 + 4.0 * (args.length + 1) * 17) * TILE * TILE           # raw in + model input out
 
+    def preprocess_traffic():
+        """HBM bytes the whole preprocessing chain moves per tile, from the committed PMC passes (tools/pmc_preprocess_json.py)"""
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_preprocess_total.json")))
+        if not files or args.dates != 12:
+            return None, None, None
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d["traffic_bytes_per_tile"], d["traffic_over_algorithmic"], os.path.relpath(files[-1], ROOT)
+
     def preprocess_leg(sessions, n_tiles, warmup):
         steps = max(1, n_tiles // args.inflight)
         dt, _, _, bad = measure(sessions, steps, warmup, flags=base_flags | 2 | 4, want_out=False)
         tiles = world * steps * args.inflight
         gbs = tiles / world * alg_bytes / dt / 1e9
+        traffic, ratio, src = preprocess_traffic()
         return {"value": tiles * TILE * TILE / dt, "unit": "px/s", "tiles": tiles, "ms_per_tile": dt / (steps * args.inflight) * 1e3,
                 "achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "bytes_per_tile": alg_bytes,
+                "traffic": traffic, "traffic_over_algorithmic": ratio, "traffic_source": src,
+                "traffic_GBps": (traffic * tiles / world / dt / 1e9) if traffic else None,
                 "tiles_flagged_for_staged_path": bad, "steps": steps, "dt": dt}
 
     def job_level_leg(sessions, n_tiles):
@@ -721,7 +753,8 @@ def main():
                                        f"date screening, indices + 12xT temporal operator + medians, window assembly + normalisation (L={args.length})",
                            "tiles": pre["tiles"], "ms_per_tile": pre["ms_per_tile"], "tiles_flagged_for_staged_path": pre["tiles_flagged_for_staged_path"]},
                 "roofline": {"kernel": "whole preprocessing chain (per tile)", "bound": "hbm", "achieved": pre["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": pre["frac"], "traffic": None, "bytes_per_tile": alg_bytes,
+                             "unit": "GB/s", "frac": pre["frac"], "traffic": pre["traffic"], "traffic_over_algorithmic": pre["traffic_over_algorithmic"],
+                             "traffic_source": pre["traffic_source"], "traffic_GBps": pre["traffic_GBps"], "bytes_per_tile": alg_bytes,
                              "note": "algorithmic bytes = raw [T,15,618,618] f32-equivalent in + model input [L+1,17,618,618] out (SURVEY 8d); "
                                      "north_star target 0.40"}}))
         if world > 1:
@@ -764,7 +797,8 @@ def main():
         except Exception as e:
             extra["sustained"] = {"error": f"{type(e).__name__}: {e}"}
         pre = preprocess_leg(sessions, 256, 2)                                                   # BASELINE configs[2]: 256 tiles
-        extra["preprocess_only"] = {k: pre[k] for k in ("value", "unit", "tiles", "ms_per_tile", "achieved_GBps", "peak_GBps", "frac", "bytes_per_tile")}
+        extra["preprocess_only"] = {k: pre[k] for k in ("value", "unit", "tiles", "ms_per_tile", "achieved_GBps", "peak_GBps", "frac", "bytes_per_tile",
+                                                         "traffic", "traffic_over_algorithmic", "traffic_GBps", "traffic_source")}
         extra["preprocess_only"]["note"] = ("BASELINE configs[2], 256 tiles (python bench.py --preprocess-only --tiles 256 prints it as its own line): decode, "
                                             "bilinear, gap-fill, temporal stage, window assembly; algorithmic bytes per SURVEY 8(d); north_star target frac 0.40")
         try:

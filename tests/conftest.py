@@ -36,3 +36,25 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """TTC_GUARD=<KiB> runs (tools/run_guarded_gpu_tests.sh): every libttc context scans the guard zones around its device buffers when it is
+    closed (sentinel-tree-cover_amd/_lib.py, csrc/ttc_internal.h); the tally goes to gpurun_out/device_guard_report.txt and a violation fails the run"""
+    if os.environ.get("TTC_GUARD", "0") in ("", "0"):
+        return
+    import gc
+    gc.collect()
+    try:
+        from ttc import _lib
+    except Exception:
+        return
+    st = _lib.GUARD_STATS
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "device_guard_report.txt"), "a") as f:
+        f.write("TTC_GUARD=%s KiB before and after every device buffer the library owns; pytest exit status %s; contexts checked at close: %d; "
+                "violations: %d\n" % (os.environ["TTC_GUARD"], exitstatus, st["contexts_checked"], len(st["violations"])))
+        for v in st["violations"]:
+            f.write("  VIOLATION " + v + "\n")
+    if st["violations"]:
+        session.exitstatus = 1

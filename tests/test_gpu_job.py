@@ -146,10 +146,10 @@ def test_arena_is_sized_through_the_real_reader_and_survives_an_abandoned_loop(t
     def tiles():
         src = job.iter_raw_tiles(coords, local, workers=2, arena=arena, want_clouds=False)
         try:
-            for k, r in enumerate(src):
-                if k == 3:
+            for k in range(len(coords)):
+                if k == 3:                       # before the fourth tile is TAKEN from the reader: a set that was handed out is the taker's to release
                     raise Boom("the caller's generator fails on the fourth tile")
-                yield r, None
+                yield next(src), None
         finally:
             src.close()
     with pytest.raises(Boom):

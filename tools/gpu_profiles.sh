@@ -44,6 +44,16 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do
     want pmc_pre && pmc $O/${TAG}_pmc_preprocess.txt "k_med_count|k_med_final|k_med_bracket|k_med_sample|k_tile_temporal|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all|k_decode_upsample" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
 done
+# the WHOLE preprocessing chain's HBM traffic per tile (VERDICT r5 #4d): each counter in its own pass, summed over every dispatch of 1 warm-up + 8 tiles
+if want pmc_pre_total; then
+for c in FETCH_SIZE WRITE_SIZE; do
+    t=${TAG}_pmctot_$c
+    bash tools/gpu_pmc.sh $t "$c" -- $R/bench.py --preprocess-only --tiles 8 --inflight 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    f=$(find gpurun_out/pmc_$t -name "*results.db" | head -1)
+    python tools/rocpd_pmc_total.py $f $c 9 > $O/${TAG}_pmc_preprocess_total_$c.json
+    rm -rf gpurun_out/pmc_$t
+done
+fi
 want bench || exit 0
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python bench.py --precision fp16 --no-cpu-baseline --no-alt > $O/${TAG}_bench_fp16.json 2>> $O/${TAG}_bench.err
