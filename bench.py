@@ -434,6 +434,7 @@ def main():
             step(sessions, flags, size, want_out)
         if state["pos"]:
             flush(state["pos"])
+        last["host_enqueue_s"] = time.perf_counter() - t0        # the host's share: when it approaches dt the loop is enqueue-bound, not GPU-bound
         sync()
         dt = time.perf_counter() - t0
         gates_ms, gates_n = ctx.kernel_ms("conv_gates")
@@ -601,6 +602,7 @@ def main():
                 "achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "bytes_per_tile": alg_bytes,
                 "traffic": traffic, "traffic_over_algorithmic": ratio, "traffic_source": src,
                 "traffic_GBps": (traffic * tiles / world / dt / 1e9) if traffic else None,
+                "host_enqueue_ms_per_tile": last.get("host_enqueue_s", 0.0) / (steps * args.inflight) * 1e3,
                 "tiles_flagged_for_staged_path": bad, "steps": steps, "dt": dt}
 
     def job_level_leg(sessions, n_tiles):
@@ -751,7 +753,8 @@ def main():
                 "config": {"workload": f"BASELINE.json configs[2]: preprocessing only on {pre['tiles']} synthetic 618x618 T={args.dates} tiles "
                                        f"({args.inflight} in flight per GPU): uint16 decode + S1 dB, bilinear 20 m->10 m, cloud gap-fill, NaN repair + "
                                        f"date screening, indices + 12xT temporal operator + medians, window assembly + normalisation (L={args.length})",
-                           "tiles": pre["tiles"], "ms_per_tile": pre["ms_per_tile"], "tiles_flagged_for_staged_path": pre["tiles_flagged_for_staged_path"]},
+                           "tiles": pre["tiles"], "ms_per_tile": pre["ms_per_tile"], "host_enqueue_ms_per_tile": pre["host_enqueue_ms_per_tile"],
+                           "tiles_flagged_for_staged_path": pre["tiles_flagged_for_staged_path"]},
                 "roofline": {"kernel": "whole preprocessing chain (per tile)", "bound": "hbm", "achieved": pre["achieved_GBps"], "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": pre["frac"], "traffic": pre["traffic"], "traffic_over_algorithmic": pre["traffic_over_algorithmic"],
                              "traffic_source": pre["traffic_source"], "traffic_GBps": pre["traffic_GBps"], "bytes_per_tile": alg_bytes,
