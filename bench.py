@@ -889,11 +889,12 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         size = args.win - 14
-        e2e_file = os.path.join(ROOT, "profiles", "r05_e2e_dprob.json")
+        import glob
+        e2e_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_e2e_dprob.json")))          # the newest round's
         sampler_effect = None
-        if os.path.exists(e2e_file):
-            with open(e2e_file) as f:
-                sampler_effect = dict(json.load(f), source="profiles/r05_e2e_dprob.json (tests/test_gpu_e2e.py, all 36 windows; not re-measured here)")
+        if e2e_files:
+            with open(e2e_files[-1]) as f:
+                sampler_effect = dict(json.load(f), source="%s (tests/test_gpu_e2e.py, all 36 windows; not re-measured here)" % os.path.relpath(e2e_files[-1], ROOT))
         r2r_file = os.path.join(ROOT, "profiles", "r05_reference_run_to_run.json")
         run_to_run = None
         if os.path.exists(r2r_file):

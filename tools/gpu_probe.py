@@ -38,7 +38,7 @@ for _ in range(3):
     ctx.forward_windows(x)
 tot = 0
 for k in ["frames_from_nhwc", "frames_to_b16", "conv_gates", "conv_cand", "gn_finalize", "gru_apply1", "gru_apply2", "conv_median",
-          "conv_concat", "conv1", "conv2", "up2", "up2_out", "up3", "out_conv", "block_finalize", "head"]:
+          "conv_concat", "conv1", "conv2", "conv_up2", "conv_up2_out", "conv_up3", "out_conv", "block_finalize", "head"]:
     ms, n = ctx.kernel_ms(k)
     per_fwd = ms * n / 3
     tot += per_fwd

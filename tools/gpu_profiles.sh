@@ -37,9 +37,13 @@ pmc() {  # out-file, kernel substring(s) separated by |, counters, command...
     for sname in "${SS[@]}"; do python tools/rocpd_pmc.py $f "$sname" >> $out; done
     rm -rf gpurun_out/pmc_$t
 }
+# the ConvGRU gates launch of every engine / geometry bench.py prices (tools/pmc_json.py -> profiles/<round>_pmc_gates_<precision>_w<win>_l<len>.json)
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
-    want pmc_f32 && pmc $O/${TAG}_pmc_f32_gates.txt "conv3x3_wino4<0|conv3x3_wino4<1|conv3x3_wino<2, 0|conv3x3_wino<1, 1" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
-    want pmc_h16 && pmc $O/${TAG}_pmc_h16_gates.txt "conv3x3_h16<0, 3, 2, 0, 1|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
+    want pmc_f32 && pmc $O/${TAG}_pmc_gates_fp32_w172_l4.txt "conv3x3_wino4<0|conv3x3_wino4<2|conv3x3_wino<1, 1" "$c" $R/tools/gpu_probe.py 172 4 36 fp32
+    want pmc_h16 && pmc $O/${TAG}_pmc_gates_fp16_w172_l4.txt "conv3x3_h16<0, 3, 2, 0, 1|k_gru_apply2_b16|k_gru_apply1_b16" "$c" $R/tools/gpu_probe.py 172 4 36 fp16
+    want pmc_b16 && pmc $O/${TAG}_pmc_gates_bf16_w172_l4.txt "conv3x3_h16<1, 3, 2, 0, 1" "$c" $R/tools/gpu_probe.py 172 4 36 bf16
+    want pmc_l12 && pmc $O/${TAG}_pmc_gates_fp32_w168_l12.txt "conv3x3_wino4<0" "$c" $R/tools/gpu_probe.py 168 12 36 fp32
+    want pmc_l12 && pmc $O/${TAG}_pmc_gates_fp16_w168_l12.txt "conv3x3_h16<0, 3, 2, 0, 1" "$c" $R/tools/gpu_probe.py 168 12 36 fp16
 done
 for c in FETCH_SIZE WRITE_SIZE; do
     want pmc_pre && pmc $O/${TAG}_pmc_preprocess.txt "k_med_count|k_med_final|k_med_bracket|k_med_sample|k_tile_temporal|k_assemble|k_ref_all|k_gram_all|k_gram_snow|k_accum_final_all|k_decode_upsample" "$c" $R/bench.py --preprocess-only --tiles 4 --inflight 1 --warmup 1 --no-cpu-baseline
