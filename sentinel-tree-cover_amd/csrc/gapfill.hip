@@ -488,6 +488,59 @@ __global__ void k_snow_prob_all(const float* __restrict__ tiles, int npix, float
         if ((threadIdx.x & 63) == 0) { if (sn) atomicAdd(&screen[2 * t], sn); if (miss) atomicAdd(&screen[2 * t + 1], miss); }
     }
 }
+// ONE pass over the stack for the three per-pixel products the gap-fill takes from it before its date loop (round 6).  Before: k_water<false>
+// (aligned mosaic, CR.py:580-584), k_water<true> (CR.py:936-939) and k_snow_prob_all each fetched all T x 40-byte records of every pixel for 8
+// to 40 of their bytes -- 3 x 183 MB per T = 12 tile (profiles/r06_pmc_preprocess_total.json).  Same expressions, same order per output:
+// bit-identical masks and probabilities.  Thread = pixel; the per-date screening counts go through LDS (2 T global atomics per workgroup).
+template <int TM>
+__global__ __launch_bounds__(256) void k_water_snow(const float* __restrict__ tiles, int T, int npix, unsigned char* __restrict__ water_ndwi,
+                                                    unsigned char* __restrict__ water_med, float* __restrict__ snowp, int* __restrict__ screen) {
+#pragma clang fp contract(off)
+    __shared__ int sc[2 * TM];
+    if (threadIdx.x < 2 * TM) sc[threadIdx.x] = 0;
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < npix;
+    float g[TM], n[TM], v[TM];
+    bool nan = false;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        g[t] = INFINITY; n[t] = INFINITY; v[t] = INFINITY;
+        if (t < T) {
+            int sn = 0, miss = 0;
+            if (live) {
+                const float2* src = reinterpret_cast<const float2*>(tiles + ((long)t * npix + p) * 10);
+                float r[10];
+#pragma unroll
+                for (int b = 0; b < 5; ++b) { const float2 u = src[b]; r[2 * b] = u.x; r[2 * b + 1] = u.y; }
+                g[t] = r[1]; n[t] = r[3];
+                v[t] = (r[1] - r[3]) / (r[1] + r[3]);
+                nan |= isnan(v[t]);
+                const float pr = snow_prob_px(r);
+                snowp[(long)t * npix + p] = pr;
+                if (screen) {
+                    int bad = 0;
+#pragma unroll
+                    for (int b = 0; b < 10; ++b) bad += (r[b] == 0.0f) + (r[b] >= 1.0f);
+                    sn = pr > 0.f; miss = bad > 1;
+                }
+            }
+            if (screen) {
+                for (int k = 32; k >= 1; k >>= 1) { sn += __shfl_xor(sn, k); miss += __shfl_xor(miss, k); }
+                if ((threadIdx.x & 63) == 0) { if (sn) atomicAdd(&sc[2 * t], sn); if (miss) atomicAdd(&sc[2 * t + 1], miss); }
+            }
+        }
+    }
+    if (live) {
+        water_ndwi[p] = nan ? 0 : (median_T<TM>(v, T) > 0.0f);                 // k_water<TM, false>
+        const float gm = median_T<TM>(g, T), nm = median_T<TM>(n, T);          // k_water<TM, true>
+        water_med[p] = ((gm - nm) / (gm + nm)) > 0.0f;
+    }
+    if (screen) {
+        __syncthreads();
+        if (threadIdx.x < 2 * T && sc[threadIdx.x]) atomicAdd(&screen[threadIdx.x], sc[threadIdx.x]);
+    }
+}
 __global__ void k_snow_mean_cached(const float* __restrict__ snowp, int T, int npix, float* __restrict__ snow) {
 #pragma clang fp contract(off)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1805,8 +1858,15 @@ __global__ void k_redo_flag(const AlignPar* __restrict__ ap, int T, int* __restr
     }
 }
 
+// water_raw (may be null): the undilated NDWI water mask of k_water<false>, already computed by the caller's fused pass (k_water_snow)
+static ttc_status aligned_mosaic_impl(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
+                                      const unsigned char* water_raw, hipStream_t s);
 ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
                                   hipStream_t s) {
+    return aligned_mosaic_impl(c, d_tiles, d_w, T, X, Y, d_mosaic, nullptr, s);
+}
+static ttc_status aligned_mosaic_impl(ttc_ctx* c, const float* d_tiles, float* d_w, int T, int X, int Y, float* d_mosaic,
+                                      const unsigned char* water_raw, hipStream_t s) {
     if (!d_tiles || !d_w || !d_mosaic || T < 1 || T > kMaxT) return c->fail(TTC_ERR_ARG, "aligned_mosaic: bad argument (T in [1,32])");
     const int npix = X * Y;
     const long total = (long)npix * 10;
@@ -1831,7 +1891,12 @@ ttc_status gapfill_aligned_mosaic(ttc_ctx* c, const float* d_tiles, float* d_w, 
     const int med_force = [] { const char* e = getenv("TTC_MEDIAN_FORCE_FALLBACK"); return e ? atoi(e) : 0; }();
     {
         KTimer kt(c, "aligned_mosaic", s);
-        TTC_CHECK(water_mask(c, d_tiles, T, X, Y, false, true, water, s));
+        if (water_raw) {     // binary_dilation(1 - water, 2) then binary_dilation(1 - that, 5)  (CR.py:585-586), as in water_mask()
+            unsigned char* tmp = static_cast<unsigned char*>(c->scratch_buf("gf_wtmp", 2 * (size_t)npix));
+            if (!tmp) return c->fail(TTC_ERR_NOMEM, "water scratch");
+            TTC_CHECK(dilate_diamond(c, water_raw, X, Y, 2, 1, tmp + npix, s));
+            TTC_CHECK(dilate_diamond(c, tmp + npix, X, Y, 5, 1, water, s));
+        } else TTC_CHECK(water_mask(c, d_tiles, T, X, Y, false, true, water, s));
         const dim3 grid((npix + 255) / 256), blk(256);
         TTC_HIP(c, hipMemsetAsync(ctl, 0, ctl_bytes, s));
         hipLaunchKernelGGL(k_divisor, grid, blk, 0, s, d_w, T, npix, divisor);
@@ -1913,9 +1978,17 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     if (n_to_remove) *n_to_remove = 0;
     const dim3 grid((npix + 255) / 256), b256(256);
 
+    // the stack is read-only until the date loop: the aligned mosaic's NDWI water mask (CR.py:580-584), the median water mask of CR.py:936-939,
+    // the per-date snow probabilities (CR.py:348-372) and the screening counts of the single-call path all come out of ONE pass over it
+    unsigned char* water_raw = static_cast<unsigned char*>(c->scratch_buf("gf_water_raw", (size_t)npix));
+    if (!water_raw) return c->fail(TTC_ERR_NOMEM, "gap-fill scratch");
+    TTC_HIP(c, hipMemsetAsync(date_counts, 0, sizeof(int) * 6 * kMaxT, s));
+    {
+        KTimer kt0(c, "water_snow", s);
+        GF_T(k_water_snow, T, grid, b256, 0, s, d_tiles, T, npix, water_raw, water2, snowp, c->spec_status ? screen : nullptr);
+    }
     TTC_CHECK(gapfill_feather(c, d_probs, T, X, Y, 20, 0, d_interp, s));                       // CR.py:910-923
-    TTC_CHECK(gapfill_aligned_mosaic(c, d_tiles, d_interp, T, X, Y, mosaic, s));               // CR.py:925
-    TTC_CHECK(water_mask(c, d_tiles, T, X, Y, true, false, water2, s));                        // CR.py:936-939
+    TTC_CHECK(aligned_mosaic_impl(c, d_tiles, d_interp, T, X, Y, mosaic, water_raw, s));       // CR.py:925
     char* ctl = static_cast<char*>(c->scratch_buf("gf_ctl", 65536));
     if (!ctl) return c->fail(TTC_ERR_NOMEM, "gap-fill control block");
     DatePlan* plans = reinterpret_cast<DatePlan*>(ctl + 32768);            // [kMaxT]
@@ -1926,14 +1999,13 @@ ttc_status gapfill_remove_clouds(ttc_ctx* c, float* d_tiles, const float* d_prob
     unsigned* hist = reinterpret_cast<unsigned*>(ctl + 4096);              // 12 * 256 * 4 = 12288 B
     double* Zdev = gpart + 1024L * gram_blocks;
     TTC_HIP(c, hipMemsetAsync(ctl, 0, 4096 + 12288, s));
-    TTC_HIP(c, hipMemsetAsync(date_counts, 0, sizeof(int) * 6 * kMaxT, s));
+    TTC_HIP(c, hipMemsetAsync(date_counts, 0, sizeof(int) * 4 * kMaxT, s));      // [T][4]; the screening counts behind them were filled by k_water_snow
     const PctList pl6{{2, 20, 40, 60, 80, 98, 0, 0}};
     const int nb3 = (int)((3L * npix + 255) / 256);
 
     KTimer kt(c, "gapfill_dates", s);
     // date-loop invariants, all dates at once: clear-pixel counts -> plans (which dates train which fit) -> row lists
     int* const spec = c->spec_status;            // single-call tile path: report instead of deciding on the host
-    hipLaunchKernelGGL(k_snow_prob_all, dim3((unsigned)((npix + 255) / 256), T), b256, 0, s, d_tiles, npix, snowp, spec ? screen : nullptr);
     hipLaunchKernelGGL(k_date_counts_all, dim3(32, T), b256, 0, s, d_interp, npix, date_counts);
     hipLaunchKernelGGL(k_date_plan, dim3(1), dim3(64), 0, s, date_counts, npix, X, T, plans, remove_flags, screen, spec);
     hipLaunchKernelGGL(k_rows_count, dim3(nb3, T), b256, 0, s, d_interp, water2, npix, 0, 0, plans, blk);

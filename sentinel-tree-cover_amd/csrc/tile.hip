@@ -537,6 +537,27 @@ __global__ void k_missing_counts(const float* __restrict__ s2, int npix, int* __
 
 // interpolate_na_vals (interpolation.py:42-56): any NaN in a pixel-band series makes bn.median NaN -> 0,
 // so every NaN of that series becomes 0;  optional 0/1 repair (job.py:1039-1047) in place.
+// interpolate_na_vals' NaN -> 0 (interpolation.py:42-56 as tile_fix_missing(do_nan) applies it: element-wise) and id_missing_px's per-date
+// counts (job.py:1032) in ONE pass over the stack (round 6: the single-call path ran k_fix_missing and k_missing_counts back to back, 2 x 183 MB
+// fetched to rewrite the rare NaN).  A record is re-written only where a NaN was found.
+__global__ void k_nanfix_counts(float* __restrict__ s2, int npix, int* __restrict__ counts) {
+    const int t = blockIdx.y;
+    int c = 0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += gridDim.x * blockDim.x) {
+        float2* v = reinterpret_cast<float2*>(s2 + ((long)t * npix + p) * 10);
+        int bad = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            float2 u = v[b];
+            const bool fx = isnan(u.x), fy = isnan(u.y);
+            if (fx | fy) { if (fx) u.x = 0.0f; if (fy) u.y = 0.0f; v[b] = u; }
+            bad += (u.x == 0.0f) + (u.x >= 1.0f) + (u.y == 0.0f) + (u.y >= 1.0f);
+        }
+        c += bad > 1;
+    }
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[t], c);
+}
 template <int TM>
 __global__ void k_fix_missing(float* __restrict__ s2, int T, int npix, int do_nan, int do_zero_one) {
     // thread = the float2 of two neighbouring bands of one pixel (round 5: 8-byte loads / stores; one band per thread before)
@@ -931,8 +952,12 @@ ttc_status tile_process_subtiles_dev(ttc_ctx* c, float* d_s2, int T, int X, int 
         TTC_HIP(c, hipMemcpy(d_minv, M, sizeof(M), hipMemcpyHostToDevice));
         c->minv_ready = true;
     }
-    TTC_CHECK(tile_fix_missing(c, d_s2, T, X, Y, 1, 0, s));                 // interpolate_na_vals, job.py:1149
-    TTC_CHECK(tile_missing_counts(c, d_s2, T, X, Y, counts, s));            // id_missing_px(arr, 10), job.py:1032
+    {   // interpolate_na_vals (job.py:1149) + id_missing_px(arr, 10) (job.py:1032), one pass
+        TTC_HIP(c, hipMemsetAsync(counts, 0, sizeof(int32_t) * T, s));
+        KTimer kt(c, "nanfix_counts", s);
+        hipLaunchKernelGGL(k_nanfix_counts, dim3(128, T), dim3(256), 0, s, d_s2, X * Y, counts);
+        TTC_HIP(c, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_build_wmat, dim3(1), dim3(64), 0, s, counts, (X * X) / 10 + ((X * X) % 10 ? 1 : 0), d_dates, T, d_minv, d_wm, c->spec_status);
     TTC_HIP(c, hipGetLastError());
     return tile_core(c, d_s2, T, X, Y, d_wm, d_interp, d_s1, d_dem, h_min, h_max, size, -1, d_windows, d_windows_raw, stop_after_inputs, s);
