@@ -199,3 +199,32 @@ def test_create_v2_accepts_an_older_shorter_config():
     assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), 8) == 1
     assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), C.sizeof(cfg)) == 1 and h                # the full struct IS read: 77 is refused
     lib.ttc_destroy(h)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_zoneout_is_a_parameter(precision):
+    """the zoneout 0.9 half of SURVEY's "F = 32 / zoneout 0.9" variant: state' = z state + (1 - z) new with z from ttc_config.zoneout (model.py:571-574).
+    (The F = 32 half stays a rejection: DESIGN.md 8.4.)  Both engines against the oracle at z = 0.9, and z matters: the result differs from z = 0.75."""
+    import torch
+    from oracle import restate_model as M
+    from ttc import _lib, weights as Wt
+    W, L, N = 44, 4, 2
+    w = Wt.synth_weights(7)
+    x = synth.synth_windows(seed=8, N=N, L=L, W=W)
+    ref9 = M.TreeCoverNet(w, zoneout=0.9, dtype=torch.float32)(x)[..., 0]
+    ref75 = M.TreeCoverNet(w, zoneout=0.75, dtype=torch.float32)(x)[..., 0]
+    ctx = _lib.Context(win_in=W, length=L, max_windows=N, zoneout=0.9, precision=precision)
+    ctx.load_weights(w)
+    got = ctx.forward_windows(x).cpu().numpy()
+    e = float(np.abs(got - ref9).max())
+    print(f"[parity] zoneout 0.9 {precision}: max|dprob| = {e:.2e} (vs the 0.75 graph: {float(np.abs(got - ref75).max()):.2e})")
+    assert e < (PROB_TOL if precision == "fp32" else 2e-4)
+    assert float(np.abs(ref9 - ref75).max()) > 1e-3 and float(np.abs(got - ref75).max()) > 1e-3
+    ctx.close()
+    # F = 32 is refused with a message, not mis-computed
+    import ctypes as C
+    lib = _lib.load()
+    cfg = _lib.TTCConfig(W, L, N, 17, 16, 32, 0.9, 0, 0, 0, 0, 0, 0)
+    h = C.c_void_p()
+    assert lib.ttc_create_v2(C.byref(h), 0, C.byref(cfg), C.sizeof(cfg)) == 1 and b"base_filters" in lib.ttc_last_error(h)
+    lib.ttc_destroy(h)
