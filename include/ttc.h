@@ -162,7 +162,8 @@ ttc_status ttc_calibrate_precision(ttc_ctx* ctx, ttc_ctx* ref_ctx, const float* 
 /* Forward + the two feature tensors of --gen_feats (job.py:1429-1445; tensors named at :1808-1809):
  * d_early [n, H, W, 64]       == sess.run("predict/gru_drop/drop_block2d/cond/Merge:0")  (bi-ConvGRU output)
  * d_late  [n, H-14, W-14, 64] == sess.run("predict/csse_out_mul/mul:0")                  (last block after its sSE gate)
- * either may be NULL. */
+ * either may be NULL.  With d_late the eight U-Net blocks of THIS forward run in the F(2x2) form whatever `fp32_conv_form` says (the late
+ * features leave as int16 thousandths, job.py:174-180: they keep round 4's <= 5e-5-class raw-output accuracy); d_out comes from the same forward. */
 ttc_status ttc_forward_taps(ttc_ctx* ctx, const float* d_in, int32_t n, float* d_out, float* d_early, float* d_late,
                             void* stream);
 

@@ -191,7 +191,16 @@ ttc_status ttc_forward_taps(ttc_ctx* c, const float* d_in, int32_t n, float* d_o
     if (n <= 0 || n > c->cfg.max_windows) return c->fail(TTC_ERR_ARG, "window count exceeds max_windows");
     hipStream_t s = static_cast<hipStream_t>(stream);
     TTC_CHECK(model_frames_from_nhwc(c, d_in, n, s));
-    TTC_CHECK(model_forward_frames(c, n, d_out, s, FRAMES_PLANAR));
+    // Feature export (job.py:1429-1445) hands the LATE features out as int16 thousandths; the F(4x4) form's rounding on the deep U-Net blocks
+    // (raw outputs <= 2e-4 of the fp64 graph on values of magnitude 13) is a visible share of that quantum, so a forward whose late tap is
+    // requested runs the eight blocks in the F(2x2) form (<= 5e-5: round 4's tolerances) -- ~1.3 ms more per 36-window forward, on the export
+    // path only.  The probabilities returned by this call come from the same forward.
+    int saved[8];
+    const bool calm = d_late && c->cfg.precision == 0;
+    for (int b = 0; b < 8; ++b) { saved[b] = c->w_block[b].form; if (calm && saved[b] == 0) c->w_block[b].form = 1; }
+    ttc_status st = model_forward_frames(c, n, d_out, s, FRAMES_PLANAR);
+    for (int b = 0; b < 8; ++b) c->w_block[b].form = saved[b];
+    TTC_CHECK(st);
     return model_taps(c, n, d_early, d_late, s);
 }
 
