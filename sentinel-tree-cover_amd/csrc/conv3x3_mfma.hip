@@ -364,6 +364,137 @@ __global__ __launch_bounds__(kThreads, 3) void conv3x3_f32_head(ConvArgs a, int 
     }
 }
 
+
+// ---- DSen2's head 32 -> 6 (+ bias, tanh, + bilinear bands) on the VECTOR ALU (round 6) -----------------------------------------------------
+// Six output channels fill 6 of the 16 rows of the narrowest fp32 MFMA tile: conv3x3_f32_head issues 2.7 x the algorithmic matrix work and ran
+// 286 us per launch (0.57 ms of a tile's 5.05 ms of DSen2 convs).  The same sums cost 2 * 9 * 32 * 6 = 3456 flops per pixel on the vector ALU,
+// whose packed fp32 FMA has the fp32 MFMA's peak rate: thread = 4 pixels of a row x 6 couts = 12 packed accumulators (cout pairs), weights are
+// workgroup-uniform -> scalar loads straight from the layer's packed image (no LDS for them), inputs staged 4 channels at a time as whole
+// padded rows (double-buffered, one barrier per chunk), each (channel, tap row) = one ds_read_b128 + one ds_read_b64 for 36 packed FMAs.
+// Same products as the MFMA form, summed channel-major instead of tap-major: <= 1e-6 apart (tests/test_gpu_tile.py: DSen2 vs the oracle, 2e-5).
+constexpr int kHvCk = 4, kHvRows = 8, kHvPitch = 136, kHvThreads = 256;
+typedef float v2fh __attribute__((ext_vector_type(2)));
+// tanh on v_exp_f32 / v_rcp_f32: 1 - 2 / (e^(2|x|) + 1), sign restored.  Absolute error <= ~1.2e-7 (one ulp of 1 from the final subtraction plus
+// the 2-ulp relative error of v_exp_f32 scaled by 2 e^(2|x|) / (e^(2|x|) + 1)^2 <= 1/2), i.e. a few ulps of the reflectance it is added to; libm's
+// tanhf is ~60 instructions and was a third of this kernel's time for 24 calls per thread
+__device__ __forceinline__ float tanh_fast(float v) {
+    const float e = __expf(2.0f * fabsf(v));
+    return copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), v);
+}
+__global__ __launch_bounds__(kHvThreads, 2) void conv3x3_head_valu(ConvArgs a, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float st[2][kHvCk][kHvRows + 2][kHvPitch];
+    __shared__ __attribute__((aligned(16))) float wl[32 * 9 * 8];             // the layer's weights [channel][tap][8: couts 0..5, 2 unused]
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int n = blockIdx.x / tiles_y, Y0 = (blockIdx.x - n * tiles_y) * kHvRows;
+    const int Wp = a.Wp, Hp = a.Hp, W4 = Wp >> 2;
+    const long plane = (long)Hp * Wp;
+    const float* src = a.seg[0].base + (long)n * a.seg[0].stride_n + a.seg[0].set_off[0];
+    const int nchunk = a.Cin / kHvCk;
+    // columns Wp .. pitch-1 of every staged row are never written by the loads: they only feed pixels x >= W, which are not stored
+    {
+        const int ncol = kHvPitch - Wp;
+        for (int i = tid; i < 2 * kHvCk * (kHvRows + 2) * ncol; i += kHvThreads) {
+            const int r = i / ncol, cidx = Wp + i % ncol;
+            (&st[0][0][0][0])[r * kHvPitch + cidx] = 0.f;
+        }
+    }
+    // weights: packed image [chunk of 8][tap][8 channels][32 couts] -> LDS [channel][tap][8]; every lane of a wave reads the same address later
+    for (int i = tid; i < a.Cin * 9 * 2; i += kHvThreads) {
+        const int h = i & 1, ct = i >> 1, g = ct / 9, t = ct - g * 9;
+        *reinterpret_cast<float4*>(&wl[ct * 8 + 4 * h]) =
+            *reinterpret_cast<const float4*>(a.w + (((long)(g >> 3) * 9 + t) * 8 + (g & 7)) * 32 + 4 * h);
+    }
+    // staging pieces of this thread: the same (channel, row, float4 column) in every chunk
+    constexpr int NLD = 5;                                        // 4 channels x 10 rows x Wp / 4 <= 5 x 256 pieces: Wp <= 128
+    const int per_chunk = kHvCk * (kHvRows + 2) * W4;
+    int goff[NLD], loff[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * kHvThreads;
+        const int ch = i / ((kHvRows + 2) * W4), rem = i - ch * ((kHvRows + 2) * W4), r = rem / W4, c4 = rem - r * W4;
+        const bool ok = i < per_chunk && (Y0 + r) < Hp;
+        goff[k] = ok ? (int)(ch * plane + (long)(Y0 + r) * Wp + 4 * c4) : -1;
+        loff[k] = i < per_chunk ? (ch * (kHvRows + 2) + r) * kHvPitch + 4 * c4 : -1;
+    }
+    float4 pre[2][NLD];                                           // TWO chunks in flight: a chunk's loads get a whole chunk of arithmetic to land
+    auto fetch = [&](int c, int slot) {
+        const float* base = src + (long)c * kHvCk * plane;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) pre[slot][k] = goff[k] >= 0 ? *reinterpret_cast<const float4*>(base + goff[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stash = [&](int buf, int slot) {
+        float* dst = &st[buf][0][0][0];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) if (loff[k] >= 0) *reinterpret_cast<float4*>(dst + loff[k]) = pre[slot][k];
+    };
+    v2fh acc[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[j][p] = v2fh{0.f, 0.f};
+    fetch(0, 0);
+    if (nchunk > 1) fetch(1, 1);
+    stash(0, 0);
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunk; c0 += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {                       // chunk parity is static: register sets and LDS buffers need no moves
+            const int c = c0 + par;
+            if (c < nchunk) {
+                if (c + 2 < nchunk) fetch(c + 2, par);            // set `par` was stored to LDS one chunk ago
+#pragma unroll 1
+                for (int ch = 0; ch < kHvCk; ++ch) {              // not unrolled: unrolled, the scheduler hoists every tap's weight reads (> 256 VGPRs, spills)
+                    const float* wg = wl + (c * kHvCk + ch) * 72;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const float* row = &st[par][0][ty + dy][4 * tx] + ch * ((kHvRows + 2) * kHvPitch);
+                        const float4 xa = *reinterpret_cast<const float4*>(row);
+                        const float2 xb = *reinterpret_cast<const float2*>(row + 4);
+                        const float x[6] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y};
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const float4 wa = *reinterpret_cast<const float4*>(wg + (dy * 3 + dx) * 8);          // wave-uniform address: one broadcast read
+                            const float2 wb = *reinterpret_cast<const float2*>(wg + (dy * 3 + dx) * 8 + 4);
+                            const v2fh w01 = v2fh{wa.x, wa.y}, w23 = v2fh{wa.z, wa.w}, w45 = v2fh{wb.x, wb.y};
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) {
+                                const v2fh xx = v2fh{x[dx + p], x[dx + p]};
+                                acc[0][p] = __builtin_elementwise_fma(w01, xx, acc[0][p]);
+                                acc[1][p] = __builtin_elementwise_fma(w23, xx, acc[1][p]);
+                                acc[2][p] = __builtin_elementwise_fma(w45, xx, acc[2][p]);
+                            }
+                        }
+                    }
+                }
+                if (c + 1 < nchunk) stash(par ^ 1, par ^ 1);      // chunk c + 1, requested a whole chunk ago
+                __syncthreads();
+            }
+        }
+    }
+    const int Hout = Hp - 2, Wout = Wp - 2, y = Y0 + ty;
+    if (y >= Hout) return;
+    float* outn = a.out + (long)n * a.out_stride_n;
+    const float* resn = a.res + (long)n * a.out_stride_n;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int x = 4 * tx + p;
+        if (x >= Wout) continue;
+        const long opix = (long)(y + a.oy) * a.out_pitch + (x + a.ox);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const long o0 = (long)(2 * j) * a.out_plane + opix, o1 = o0 + a.out_plane;
+            outn[o0] = resn[o0] + tanh_fast(acc[j][p].x + a.aux[2 * j]);
+            outn[o1] = resn[o1] + tanh_fast(acc[j][p].y + a.aux[2 * j + 1]);
+        }
+    }
+}
+// the launch limits of the vector-ALU head; TTC_HEAD_VALU=0 keeps the MFMA form (A/B runs)
+static bool head_valu_ok(const ConvArgs& a, const PackedConv& pw, int epi, int n) {
+    static const int on = [] { const char* e = getenv("TTC_HEAD_VALU"); return e ? atoi(e) : 1; }();
+    return on && pw.mode == 0 && epi == EPI_BIAS_TANH_ADD && a.Cout == 6 && pw.CK == 8 && pw.BN == 32 && pw.ncb == 1 && a.seg[1].C == 0 &&
+           a.Cin == 32 && (a.Wp & 3) == 0 && a.Wp <= 128 && (long)a.Cin * a.Hp * a.Wp < (1L << 31) && a.n_per_set >= n && !a.reflect_out && a.res != nullptr &&
+           (long)n * ((a.Hp - 2 + kHvRows - 1) / kHvRows) < (1L << 31);
+}
 template <int CK>
 hipError_t launch_head(const ConvArgs& a, const PackedConv& pw, int n, hipStream_t s) {
     const int TL = kBQ + 2 * a.Wp + 2;
@@ -496,6 +627,7 @@ double conv_issued_flops(const ConvArgs& a, const PackedConv& pw, int epi, int n
         }
         default: break;
     }
+    if (head_valu_ok(a, pw, epi, n)) return 0.0;          // the 32 -> 6 head runs on the vector ALU: no matrix instruction is issued
     // direct implicit GEMM: tile = 512 flat positions x BN couts (the 32 -> 6 head: 16 rows), K = 9 taps x nchunk x CK channels
     const double tiles = (double)conv_q_blocks(a.Hp, a.Wp) * pw.ncb * n;
     const bool head = pw.CK == 8 && pw.BN == 32 && epi == EPI_BIAS_TANH_ADD && pw.Cout <= 16 && pw.ncb == 1 && a.seg[1].C == 0 &&
@@ -519,6 +651,11 @@ hipError_t conv_launch(const ConvArgs& a, const PackedConv& pw, int epi, int n, 
     TTC_CONV_CASE(10, 1, EPI_BIAS_RELU)      // DSen2 in_conv        10 -> 32
     TTC_CONV_CASE(8, 1, EPI_BIAS_RELU)       // DSen2 x1_conv        32 -> 32
     TTC_CONV_CASE(8, 1, EPI_BIAS_RES)        // DSen2 x2_conv        32 -> 32 (+ residual)
+    if (head_valu_ok(a, pw, epi, n)) {      // DSen2 out_conv 32 -> 6 (+ bilinear) on the vector ALU
+        const int tiles_y = (a.Hp - 2 + kHvRows - 1) / kHvRows;
+        hipLaunchKernelGGL(conv3x3_head_valu, dim3((unsigned)(n * tiles_y)), dim3(kHvThreads), 0, s, a, tiles_y);
+        return hipGetLastError();
+    }
     {   // DSen2 out_conv 32 -> 6 (+ bilinear): the 16-row MFMA form when the plane is aligned and has one input segment
         static const int narrow = [] { const char* e = getenv("TTC_CONV_NARROW"); return e ? atoi(e) : 1; }();
         if (narrow && pw.CK == 8 && pw.BN == 32 && epi == EPI_BIAS_TANH_ADD && pw.Cout <= 16 && pw.ncb == 1 && a.seg[1].C == 0 &&
