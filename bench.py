@@ -541,6 +541,20 @@ def main():
         r["isolated_conv_ms_per_tile"], r["isolated_tile_ms"] = conv_ms_tile, iso_extra["tile_ms"]
         r["profile"] = profile_check("isolated", check_leg, precision, iso_ms)
         r["live_profile"] = profile_check("live", check_leg, precision, live_ms)
+        ds = tab.get("dsen2_conv")
+        if ds and ds["n"] and precision == "fp32":
+            # the largest kernel FAMILY of the fp32 tile by time: DSen2's six convs (31 windows x T dates of 118 x 118), priced by algorithmic flops
+            ds_n = ds["n"] // iso_extra["tiles"]
+            ds_flops = 2.0 * 9 * (10 * 32 + 4 * 32 * 32 + 32 * 6) * 118 * 118 * 31 * args.dates
+            ds_tf = ds_flops / (ds["ms"] * ds_n * 1e-3) / 1e12
+            r["other_families"] = {"dsen2_conv": {
+                "kernel": "conv3x3_f32<CK,1,EPI_BIAS_*> direct implicit GEMM on v_mfma_f32_32x32x2_f32; the 32 -> 6 head on the vector ALU (conv3x3_head_valu); one tile in flight",
+                "ms_per_tile": ds["ms"] * ds_n, "launches_per_tile": ds_n, "flops_per_tile": ds_flops, "achieved": ds_tf,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ds_tf / FP32_MFMA_PEAK_TF,
+                "mfma_flops_issued_per_tile": ds["flops"] * ds_n,
+                "note": "algorithmic flops of all six convs / their time / fp32 MFMA peak (the head issues no matrix instruction: mfma_flops_issued_per_tile "
+                        "counts the other five); power-limited clock, DESIGN.md 8.1; ttc_config.dsen2_precision = fp16 runs these convs on the 16-bit engine "
+                        "(alt_fp32_dsen2_fp16)"}}
         return r
 
     def hip_tile0(sess):
@@ -939,18 +953,6 @@ def main():
             },
             "roofline": head_roof,
         }
-        if iso_extra.get("dsen2_conv") and iso_extra["dsen2_conv"][1] > 0 and args.precision == "fp32":
-            # the largest kernel FAMILY of the fp32 tile by time: DSen2's six convs on the direct fp32 kernel (31 windows x T dates of 118 x 118)
-            ds_ms, ds_n = iso_extra["dsen2_conv"]
-            ds_flops = 2.0 * 9 * (10 * 32 + 4 * 32 * 32 + 32 * 6) * 118 * 118 * 31 * args.dates
-            ds_tf = ds_flops / (ds_ms * ds_n * 1e-3) / 1e12
-            out["roofline"]["other_families"] = {"dsen2_conv": {
-                "kernel": "conv3x3_f32<CK,1,EPI_BIAS_*> direct implicit GEMM on v_mfma_f32_32x32x2_f32 (+ the 32 -> 6 head), one tile in flight",
-                "ms_per_tile": ds_ms * ds_n, "launches_per_tile": ds_n, "flops_per_tile": ds_flops, "achieved": ds_tf,
-                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ds_tf / FP32_MFMA_PEAK_TF,
-                "note": "direct form: issued = algorithmic flops up to tile padding (isolated_conv_families.dsen2_conv has the issued count); power-bound "
-                        "(1.84 GHz with the matrix pipe 83 % busy, DESIGN.md 7); ttc_config.dsen2_precision = fp16 runs these convs on the 16-bit engine "
-                        "(alt_fp32_dsen2_fp16)"}}
         out.update(extra)
         sus = extra.get("sustained") or {}
         if sus.get("value") and sus["value"] < 0.97 * out["value"]:
