@@ -189,7 +189,7 @@ def profile_ref():
         return json.load(f), os.path.relpath(files[-1], ROOT)
 
 
-def profile_check(leg, key, precision, bench_ms, tol=0.10):
+def profile_check(leg, key, precision, bench_ms, tol=0.10, warn=True):
     """in-bench HIP-event time of the gates launch vs the committed rocprofv3 average of the SAME command's leg: the roofline's launch time
     must be recomputable from a file under profiles/.  -> dict for the JSON line (agree = within `tol`)"""
     ref, path = profile_ref()
@@ -203,7 +203,7 @@ def profile_check(leg, key, precision, bench_ms, tol=0.10):
     ratio = bench_ms * 1e3 / row["avg_us"]
     out = {"file": path, "stats_file": ent.get("stats_file"), "command": ent.get("command"), "kernel_row": name, "profile_avg_us": row["avg_us"],
            "profile_calls": row["calls"], "bench_event_ms": bench_ms, "ratio_bench_over_profile": ratio, "tolerance": tol, "agree": abs(ratio - 1.0) <= tol}
-    if not out["agree"]:
+    if not out["agree"] and warn:
         print(f"[bench] WARNING: the {leg} gates launch measured {bench_ms * 1e3:.1f} us in this run, {row['avg_us']:.1f} us in {ent.get('stats_file')} "
               f"(ratio {ratio:.3f}, tolerance {tol}): re-profile (tools/gpu_profiles.sh) before quoting roofline.frac from that file", file=sys.stderr, flush=True)
     return out
@@ -540,7 +540,8 @@ def main():
                                            "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 4) if v["ms"] > 0 else None} for k, v in tab.items()}
         r["isolated_conv_ms_per_tile"], r["isolated_tile_ms"] = conv_ms_tile, iso_extra["tile_ms"]
         r["profile"] = profile_check("isolated", check_leg, precision, iso_ms)
-        r["live_profile"] = profile_check("live", check_leg, precision, live_ms)
+        # reported, never warned about: under rocprofv3 kernels of different streams overlap less than in a plain run, so the live row is no stable reference
+        r["live_profile"] = profile_check("live", check_leg, precision, live_ms, warn=False)
         ds = tab.get("dsen2_conv")
         if ds and ds["n"] and precision == "fp32":
             # the largest kernel FAMILY of the fp32 tile by time: DSen2's six convs (31 windows x T dates of 118 x 118), priced by algorithmic flops
